@@ -1,0 +1,162 @@
+"""Deterministic synthetic inputs shared by tools/make_golden.py (which feeds them to the real
+reference) and by the tests (which feed the same values to the oracle / the HIP path).
+
+Everything derives from numpy's MT19937 `RandomState`, whose streams are stable across numpy
+versions and machines, so fixtures only need to store the reference's OUTPUTS.
+"""
+import zlib
+
+import numpy as np
+
+
+def _rng(seed, key=""):
+    return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def det_tensor(seed: int, key: str, shape) -> np.ndarray:
+    """Value of state-dict entry `key` for fixture `seed` (reference key schema)."""
+    rng = _rng(seed, key)
+    shape = tuple(shape)
+    if key.endswith("num_batches_tracked"):
+        return np.zeros(shape, np.int64)
+    if key.endswith("dfl.conv.weight"):
+        return np.arange(16, dtype=np.float32).reshape(shape)
+    if key.endswith("running_var"):
+        return rng.uniform(0.5, 1.5, shape).astype(np.float32)
+    if key.endswith("running_mean"):
+        return rng.normal(0, 0.1, shape).astype(np.float32)
+    if key.endswith("bn.weight"):
+        return rng.uniform(0.7, 1.3, shape).astype(np.float32)
+    if key.endswith("bn.bias"):
+        return rng.uniform(-0.2, 0.2, shape).astype(np.float32)
+    if key.endswith(".bias"):
+        return rng.uniform(-1.0, 1.0, shape).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    b = (3.0 / fan_in) ** 0.5
+    return rng.uniform(-b, b, shape).astype(np.float32)
+
+
+def det_image(seed: int, bs: int, imgsz: int) -> np.ndarray:
+    return _rng(seed, "image").uniform(0, 1, (bs, 3, imgsz, imgsz)).astype(np.float32)
+
+
+def det_array(seed: int, key: str, shape, lo=-0.5, hi=0.5) -> np.ndarray:
+    return _rng(seed, key).uniform(lo, hi, tuple(shape)).astype(np.float32)
+
+
+def make_batch(bs, n_per_img, nc, seed, empty_images=()):
+    """Label dict in the reference's collate format (data/datasets.py:440-459) as numpy arrays."""
+    rng = _rng(seed, "labels")
+    bi, cls, boxes = [], [], []
+    for i in range(bs):
+        if i in empty_images:
+            continue
+        for _ in range(n_per_img):
+            bi.append(i)
+            cls.append(rng.randint(0, nc))
+            boxes.append(np.concatenate((rng.uniform(0.2, 0.8, 2), rng.uniform(0.05, 0.35, 2))))
+    n = len(bi)
+    return dict(
+        batch_idx=np.asarray(bi, np.float32),
+        cls=np.asarray(cls, np.float32).reshape(n, 1),
+        prob=np.ones((n, 1), np.float32),
+        bboxes=np.asarray(boxes, np.float32).reshape(n, 4),
+    )
+
+
+def synth_feats(seed, bs, imgsz, nc, mode="near"):
+    """Three raw head maps [bs, 64+nc, h, w]. mode 'near' sharpens the DFL logits so that decoded
+    boxes are a few cells wide (positive CIoU for many anchors); 'rand' is plain N(0,1)."""
+    rng = _rng(seed, "feats")
+    feats = []
+    for s in (8, 16, 32):
+        h = imgsz // s
+        f = rng.normal(0, 1, (bs, 64 + nc, h, h)).astype(np.float32)
+        if mode == "near":
+            f[:, :64] *= 0.5
+            v = f[:, :64].reshape(bs, 4, 16, h, h)
+            v[:, :, 2:5] += 3.0
+            f[:, :64] = v.reshape(bs, 64, h, h)
+        feats.append(f)
+    return feats
+
+
+def synth_pred(bs, nc, na, n_obj, seed, dtype=np.float32, dup=True):
+    """Synthetic eval-mode prediction y [bs, 4+nc, A] in the style of SURVEY.md section 8d."""
+    rng = np.random.RandomState(seed)
+    y = np.zeros((bs, 4 + nc, na), np.float32)
+    y[:, 0:2] = rng.uniform(0, 640, (bs, 2, na))
+    y[:, 2:4] = rng.uniform(10, 110, (bs, 2, na))
+    y[:, 4:] = rng.uniform(0, 0.01, (bs, nc, na))
+    for b in range(bs):
+        if n_obj == 0:
+            break
+        idx = rng.choice(na, n_obj, replace=False)
+        cls = rng.randint(0, nc, n_obj)
+        y[b, 4 + cls, idx] = rng.uniform(0.25, 0.95, n_obj)
+        if dup:  # clusters of near-duplicates so that suppression actually happens
+            for k in range(0, n_obj - 1, 2):
+                y[b, :4, idx[k + 1]] = y[b, :4, idx[k]] + rng.uniform(-3, 3, 4)
+                y[b, 4:, idx[k + 1]] = 0.005
+                y[b, 4 + cls[k], idx[k + 1]] = rng.uniform(0.25, 0.95)
+    return y.astype(dtype)
+
+
+# fixture case tables (single source of truth for generator and tests) ------------------------------
+LOSS_CASES = {
+    # name: (bs, imgsz, nc, labels/img, empty images, seed, pred mode)
+    "basic": (2, 96, 20, 3, (), 11, "near"),
+    "empty_image": (3, 64, 19, 2, (1,), 12, "near"),
+    "no_labels": (2, 64, 12, 0, (0, 1), 13, "rand"),
+    "random_preds": (2, 96, 20, 4, (), 14, "rand"),
+    "many_gts": (2, 128, 20, 12, (), 15, "near"),
+}
+
+NMS_CASES = {
+    "infer_fp32": dict(bs=3, nc=20, na=2100, n_obj=120, seed=7, dtype="float32", kw=dict(conf_thres=0.25, iou_thres=0.45)),
+    "infer_fp16": dict(bs=2, nc=19, na=2100, n_obj=150, seed=8, dtype="float16", kw=dict(conf_thres=0.25, iou_thres=0.45)),
+    "val_multilabel": dict(bs=2, nc=12, na=525, n_obj=60, seed=9, dtype="float32",
+                           kw=dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)),
+    "agnostic_maxdet": dict(bs=2, nc=20, na=2100, n_obj=400, seed=10, dtype="float32",
+                            kw=dict(conf_thres=0.25, iou_thres=0.45, agnostic=True, max_det=50)),
+    "classes_filter": dict(bs=2, nc=20, na=525, n_obj=80, seed=11, dtype="float32",
+                           kw=dict(conf_thres=0.25, iou_thres=0.45, classes=[1, 3, 5])),
+    "empty": dict(bs=2, nc=20, na=525, n_obj=0, seed=12, dtype="float32", kw=dict(conf_thres=0.25, iou_thres=0.45)),
+}
+
+
+def nms_case_input(name):
+    c = NMS_CASES[name]
+    return synth_pred(c["bs"], c["nc"], c["na"], c["n_obj"], c["seed"], np.dtype(c["dtype"]))
+
+
+def ties_input():
+    """Ties / touching boxes: IoU == thr must be kept (suppression is strict '>')."""
+    y = np.zeros((1, 4 + 2, 8), np.float32)
+    y[0, :4, 0] = [50, 50, 20, 20]
+    y[0, :4, 1] = [60, 50, 20, 20]  # IoU with box0 = 1/3
+    y[0, :4, 2] = [50, 50, 20, 20]  # exact duplicate of box0, same score -> index order decides
+    y[0, :4, 3] = [200, 200, 30, 30]
+    y[0, :4, 4] = [200, 200, 30, 30]  # duplicate but other class
+    y[0, 4, [0, 1, 2, 3]] = [0.5, 0.5, 0.5, 0.9]
+    y[0, 5, 4] = 0.9
+    return y
+
+
+def predict_inputs():
+    """Per-task y for the CerberusDetInference.predict post-processing fixture."""
+    ya = synth_pred(3, 20, 2100, 60, 21)
+    yb = synth_pred(3, 19, 2100, 60, 22)
+    for b in range(3):  # make some animals boxes coincide with voc boxes -> cross-task suppression triggers
+        ia = np.nonzero(ya[b, 4:].max(0) > 0.25)[0][:10]
+        ib = np.nonzero(yb[b, 4:].max(0) > 0.25)[0][:10]
+        k = min(len(ia), len(ib))
+        yb[b, :4, ib[:k]] = ya[b, :4, ia[:k]] + 0.5
+    names = {"voc": [f"v{i}" for i in range(20)], "objects365_animals": [f"a{i}" for i in range(19)]}
+    shapes = [(480, 640), (720, 1280), (640, 640)]
+    return ya, yb, names, shapes
+
+
+TINY_WIDTH, TINY_DEPTH = 0.125, 0.33
+HYP = dict(box=[7.5, 7.5, 7.5], cls=[0.5, 0.5, 0.5], dfl=[1.5, 1.5, 1.5], lr0=0.00309, lrf=0.0956, momentum=0.952,
+           weight_decay=0.00037, warmup_epochs=2.04, warmup_momentum=0.898, warmup_bias_lr=0.0502)
