@@ -1,0 +1,113 @@
+"""ctypes binding of libcerberus_hip.so (the C-ABI declared in include/cerberus_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcerberus_hip.so"
+
+BF16, F16, F32, U8 = 0, 1, 2, 3
+ACT_NONE, ACT_SILU = 0, 1
+CONV_FWD, CONV_DGRAD = 0, 1
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, i32) for n in (
+        "N", "Hs", "Ws", "Cs", "Hd", "Wd", "Cd", "kh", "kw", "stride", "pad", "mode", "dtype", "out_dtype", "act",
+        "src_ld", "src_coff", "dst_ld", "dst_coff", "res_ld", "res_coff", "accumulate")]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("N", i32), ("nc", i32), ("n_max", i32), ("hw", i32 * 6), ("stride", f32 * 3), ("gain_box", f32),
+                ("gain_cls", f32), ("gain_dfl", f32), ("grad_scale", f32), ("dtype", i32), ("grad_dtype", i32),
+                ("f_ld", i32), ("topk", i32), ("alpha", f32), ("beta", f32)]
+
+
+class NmsDesc(C.Structure):
+    _fields_ = [("N", i32), ("nc", i32), ("A", i32), ("dtype", i32), ("conf_thres", f32), ("iou_thres", f32),
+                ("agnostic", i32), ("multi_label", i32), ("max_det", i32), ("max_nms", i32), ("max_cand", i32),
+                ("classes", vp), ("n_classes", i32)]
+
+
+class ParamSlot(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("lr", f32), ("weight_decay", f32),
+                ("inv_div", f32), ("first_step", i32)]
+
+
+_SIGS = {
+    "cdet_version": (i32, []),
+    "cdet_last_error": (C.c_char_p, []),
+    "cdet_device_info": (i32, [C.POINTER(i32)]),
+    "cdet_conv2d_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "cdet_packed_weight_elems": (i64, [i32, i32, i32, i32, i32]),
+    "cdet_conv2d_wgrad_ws_elems": (i64, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
+    "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "cdet_stem_conv_stat_blocks": (i32, [i32, i32, i32]),
+    "cdet_stem_conv_wgrad": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "cdet_bn_finalize": (i32, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),
+    "cdet_bn_silu_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, i32, vp]),
+    "cdet_bn_bwd_blocks": (i32, [i64]),
+    "cdet_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "cdet_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32,
+                                     i64, i32, i32, vp]),
+    "cdet_copy_channels": (i32, [vp, i32, i32, vp, i32, i32, i64, i32, i32, i32, vp]),
+    "cdet_add_channels": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, i32, vp]),
+    "cdet_upsample2": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cdet_upsample2_bwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cdet_sppf_pool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cdet_sppf_pool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cdet_detect_decode": (i32, [vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i32, i32, vp, i32, vp]),
+    "cdet_det_loss_ws_bytes": (i64, [C.POINTER(LossDesc)]),
+    "cdet_det_loss": (i32, [C.POINTER(LossDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_nms_ws_bytes": (i64, [C.POINTER(NmsDesc)]),
+    "cdet_nms_batched": (i32, [C.POINTER(NmsDesc), vp, vp, vp, vp, vp]),
+    "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp]),
+    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, f32, f32, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+_lib = None
+
+
+class CdetError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises CdetError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise CdetError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {_HERE / 'csrc'}`). cerberusdet_amd has no CPU fallback by design.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cdet_version() != 1:
+        raise CdetError(f"ABI version mismatch: library {lib.cdet_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().cdet_last_error().decode(errors="replace")
+        raise CdetError(f"{what} failed ({code}): {msg}")
+
+
+def is_built() -> bool:
+    return LIB_PATH.exists()

@@ -1,0 +1,84 @@
+// Shared helpers for the gfx950 kernels of libcerberus_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cerberus_hip.h"
+
+namespace cdet {
+
+void set_error(const char* fmt, ...);
+
+#define CDET_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            cdet::set_error(__VA_ARGS__);         \
+            return -1001;                         \
+        }                                         \
+    } while (0)
+
+#define CDET_LAUNCH_CHECK()                                                             \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            cdet::set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return -(int)e__;                                                           \
+        }                                                                               \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- scalar conversions (round-to-nearest-even) -------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
+}
+
+template <int DT> struct Elem;  // 16-bit storage types
+template <> struct Elem<CDET_BF16> {
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return bf16_bits_to_f32(v); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return f32_to_bf16_bits(f); }
+};
+template <> struct Elem<CDET_F16> {
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return f16_bits_to_f32(v); }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return f32_to_f16_bits(f); }
+};
+
+__device__ __forceinline__ float load_elem(const void* p, int64_t i, int dtype) {
+    if (dtype == CDET_F32) return ((const float*)p)[i];
+    uint16_t v = ((const uint16_t*)p)[i];
+    return dtype == CDET_BF16 ? bf16_bits_to_f32(v) : f16_bits_to_f32(v);
+}
+__device__ __forceinline__ void store_elem(void* p, int64_t i, float f, int dtype) {
+    if (dtype == CDET_F32) ((float*)p)[i] = f;
+    else ((uint16_t*)p)[i] = dtype == CDET_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
+}
+
+__device__ __forceinline__ float silu_f(float a) { return a / (1.0f + __expf(-a)); }
+__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + __expf(-a)); }
+
+static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int elem_size(int dtype) { return dtype == CDET_F32 ? 4 : (dtype == CDET_U8 ? 1 : 2); }
+
+}  // namespace cdet

@@ -1,0 +1,390 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (bf16 / f16 in, fp32 accumulate).
+//
+// GEMM view (FWD):  D[co][p] = sum_k W[co][k] * X[p][k],  k = (kh, kw, ci) flattened, p = (n, oy, ox).
+// Both operands are K-contiguous: NHWC activations give 8-channel (16 B) vectors per (pixel, tap),
+// weights are pre-packed [Cout][Kpad]. The MFMA "A" operand is the weight tile and "B" the pixel
+// tile, so each lane's 4 accumulator registers are 4 CONSECUTIVE output channels of one pixel ->
+// 8-byte NHWC stores and lane-local per-channel BN statistics.
+//
+// Tiling: wave tile = 80 couts x 64 pixels (5 x 4 MFMA 16x16x32 tiles, 80 fp32 accumulators/lane);
+// YOLOv8x widths are multiples of 80 (80/160/320/640), so 80-wide wave tiles waste nothing.
+//   <2,2>: block = 160 couts x 128 pixels (Cout >= 160)      <4,1>: block = 80 couts x 256 pixels (Cout <= 80)
+// K step 64 (128-B LDS rows, XOR-swizzled 16-B slots -> conflict-free ds_read_b128 fragments),
+// single LDS stage + register prefetch of the next K step (global loads fly under the MFMAs).
+// Workgroup ids are remapped so that the cout-blocks of one pixel-block run back to back on ONE XCD
+// (their im2col tile is served by that XCD's L2 instead of HBM).
+#include "common.h"
+
+namespace cdet {
+
+struct ConvArgs {
+    const uint16_t* x;
+    const uint16_t* w;
+    const float* scale;
+    const float* bias;
+    const uint16_t* res;
+    void* y;
+    float* stats;
+    int N, Hs, Ws, Cs, Hd, Wd, Cd;
+    int KH, KW, stride, pad;
+    int src_ld, src_coff, dst_ld, dst_coff, res_ld, res_coff;
+    int Kpad, nk;       // packed K (multiple of 64), number of 64-wide K steps
+    int M;              // N*Hd*Wd
+    int n_pblk, n_cblk;
+    int act, out_dtype, accumulate;
+};
+
+constexpr int BK = 64;
+constexpr int ROW_BYTES = BK * 2;  // 128
+
+__device__ __forceinline__ int lds_slot(int row, int kvec) { return row * ROW_BYTES + ((kvec ^ ((row >> 1) & 7)) << 4); }
+
+template <int DT> struct Mfma;
+template <> struct Mfma<CDET_BF16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<CDET_F16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <int DT, int WAVES_M, int WAVES_N, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BP = 64 * WAVES_M;          // pixels per block
+    constexpr int BC = 80 * WAVES_N;          // couts per block
+    constexpr int XR = BP / 32;               // X rows per thread
+    constexpr int WR = (BC + 31) / 32;        // W rows per thread (last may be partial)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Xs = smem;
+    unsigned char* Wsm = smem + BP * ROW_BYTES;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+
+    // ---- XCD-aware block remap (bijective): logical id L walks cout-blocks fastest --------------
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int cblk = L % a.n_cblk;
+    const int pblk = L / a.n_cblk;
+    const int p0 = pblk * BP;
+    const int c0 = cblk * BC;
+
+    // ---- per-thread load bookkeeping --------------------------------------------------------------
+    const int kvec = t & 7;
+    const int lrow = t >> 3;  // 0..31
+    int ybase[XR], xbase[XR], nbase[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int p = p0 + lrow + 32 * i;
+        if (p < a.M) {
+            const int hw = a.Hd * a.Wd;
+            const int n = p / hw;
+            const int rem = p - n * hw;
+            const int py = rem / a.Wd;
+            const int px = rem - py * a.Wd;
+            nbase[i] = n * a.Hs;
+            if (DGRAD) {
+                ybase[i] = py + a.pad;
+                xbase[i] = px + a.pad;
+            } else {
+                ybase[i] = py * a.stride - a.pad;
+                xbase[i] = px * a.stride - a.pad;
+            }
+        } else {
+            nbase[i] = 0;
+            ybase[i] = -(1 << 20);  // every tap fails the bounds test
+            xbase[i] = -(1 << 20);
+        }
+    }
+    // position of this thread's 8-element K vector: channel c within tap (kh, kw)
+    int kc, kkh, kkw;
+    {
+        const int k = kvec * 8;
+        const int tap = k / a.Cs;
+        kc = k - tap * a.Cs;
+        kkh = tap / a.KW;
+        kkw = tap - kkh * a.KW;
+    }
+    const uint16_t* wrow[WR];
+    bool wok[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int r = lrow + 32 * i;
+        const int co = c0 + r;
+        wok[i] = (r < BC) && (co < a.Cd);
+        wrow[i] = a.w + (int64_t)(wok[i] ? co : 0) * a.Kpad + kvec * 8;
+    }
+
+    u32x4 xreg[XR], wreg[WR];
+    auto load_global = [&](int ks) {
+        const bool ktap_ok = kkh < a.KH;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            int sy, sx;
+            bool ok = ktap_ok;
+            if (DGRAD) {
+                const int ty = ybase[i] - kkh, tx = xbase[i] - kkw;
+                if (a.stride == 2) {
+                    ok = ok && (((ty | tx) & 1) == 0);
+                    sy = ty >> 1;
+                    sx = tx >> 1;
+                } else {
+                    sy = ty;
+                    sx = tx;
+                }
+            } else {
+                sy = ybase[i] + kkh;
+                sx = xbase[i] + kkw;
+            }
+            ok = ok && ((unsigned)sy < (unsigned)a.Hs) && ((unsigned)sx < (unsigned)a.Ws);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const int64_t off = ((int64_t)(nbase[i] + sy) * a.Ws + sx) * a.src_ld + a.src_coff + kc;
+                v = *reinterpret_cast<const u32x4*>(a.x + off);
+            }
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (wok[i]) v = *reinterpret_cast<const u32x4*>(wrow[i] + (int64_t)ks * BK);
+            wreg[i] = v;
+        }
+        // advance the K cursor by one step (64 elements)
+        kc += BK;
+        while (kc >= a.Cs) {
+            kc -= a.Cs;
+            if (++kkw == a.KW) {
+                kkw = 0;
+                ++kkh;
+            }
+        }
+    };
+
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fk = lane >> 4;  // 0..3
+
+    load_global(0);
+    for (int ks = 0; ks < a.nk; ++ks) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) *reinterpret_cast<u32x4*>(Xs + lds_slot(lrow + 32 * i, kvec)) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            if (lrow + 32 * i < BC) *reinterpret_cast<u32x4*>(Wsm + lds_slot(lrow + 32 * i, kvec)) = wreg[i];
+        __syncthreads();
+        if (ks + 1 < a.nk) load_global(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 af[5], bf[4];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) af[i] = *reinterpret_cast<const u32x4*>(Wsm + lds_slot(wn * 80 + i * 16 + frow, kk * 4 + fk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(Xs + lds_slot(wm * 64 + j * 16 + frow, kk * 4 + fk));
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<DT>::run(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- BN statistics of the raw convolution (train mode) --------------------------------------
+    if (a.stats != nullptr) {
+        float* st = reinterpret_cast<float*>(smem);  // [WAVES_M][2][BC]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s += acc[i][j];
+                q += acc[i][j] * acc[i][j];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sv = s[r], qv = q[r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    sv += __shfl_xor(sv, m);
+                    qv += __shfl_xor(qv, m);
+                }
+                if (frow == 0) {
+                    const int cl = wn * 80 + i * 16 + fk * 4 + r;
+                    st[(wm * 2 + 0) * BC + cl] = sv;
+                    st[(wm * 2 + 1) * BC + cl] = qv;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < BC && c0 + t < a.Cd) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int m = 0; m < WAVES_M; ++m) {
+                sv += st[(m * 2 + 0) * BC + t];
+                qv += st[(m * 2 + 1) * BC + t];
+            }
+            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+        }
+    }
+
+    // ---- epilogue: scale/bias, activation, residual, store -------------------------------------
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int co = c0 + wn * 80 + i * 16 + fk * 4;
+        if (co >= a.Cd) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+        if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + wm * 64 + j * 16 + frow;
+            if (p >= a.M) continue;
+            f32x4 v = acc[i][j] * sc + bi;
+            if (a.act == CDET_ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            if (a.res) {
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (int64_t)p * a.res_ld + a.res_coff + co);
+                v[0] += Elem<DT>::to_f32((uint16_t)(rv[0] & 0xffff));
+                v[1] += Elem<DT>::to_f32((uint16_t)(rv[0] >> 16));
+                v[2] += Elem<DT>::to_f32((uint16_t)(rv[1] & 0xffff));
+                v[3] += Elem<DT>::to_f32((uint16_t)(rv[1] >> 16));
+            }
+            const int64_t o = (int64_t)p * a.dst_ld + a.dst_coff + co;
+            if (a.out_dtype == CDET_F32) {
+                float* yp = reinterpret_cast<float*>(a.y) + o;
+                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
+                *reinterpret_cast<f32x4*>(yp) = v;
+            } else {
+                u32x2 pk;
+                if (a.out_dtype == CDET_BF16) {
+                    pk[0] = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+                    pk[1] = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+                } else {
+                    pk[0] = (uint32_t)f32_to_f16_bits(v[0]) | ((uint32_t)f32_to_f16_bits(v[1]) << 16);
+                    pk[1] = (uint32_t)f32_to_f16_bits(v[2]) | ((uint32_t)f32_to_f16_bits(v[3]) << 16);
+                }
+                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.y) + o) = pk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 -> [rows][Kpad] (bf16/f16), K = (kh, kw, c)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int O, int O_pad, int I, int KH, int KW,
+                                   int transpose, const float* __restrict__ row_scale, int dtype, int rows, int Kpad) {
+    const int64_t total = (int64_t)rows * Kpad;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / Kpad);
+        const int k = (int)(idx - (int64_t)row * Kpad);
+        const int C = transpose ? O_pad : I;  // reduction channels
+        float v = 0.f;
+        if (k < KH * KW * C) {
+            const int tap = k / C, c = k - tap * C;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int o = transpose ? c : row, i = transpose ? row : c;
+            if (o < O) {
+                v = w[(((int64_t)o * I + i) * KH + kh) * KW + kw];
+                if (row_scale) v *= row_scale[o];
+            }
+        }
+        out[idx] = dtype == CDET_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+    }
+}
+
+static inline int kpad_of(int K) { return (K + BK - 1) / BK * BK; }
+
+template <int DT, int WM, int WN>
+static int launch_conv(const ConvArgs& a, bool dgrad, hipStream_t s) {
+    constexpr int BP = 64 * WM, BC = 80 * WN;
+    const size_t lds = (size_t)(BP + BC) * ROW_BYTES;
+    dim3 grid(a.n_pblk * a.n_cblk), block(256);
+    if (dgrad)
+        hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, true>), grid, block, lds, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, false>), grid, block, lds, s, a);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline bool wide_tile(const cdet_conv_desc* d) { return d->Cd > 80; }
+
+}  // namespace cdet
+
+using namespace cdet;
+
+extern "C" int cdet_conv2d_stat_blocks(const cdet_conv_desc* d) {
+    const int64_t M = (int64_t)d->N * d->Hd * d->Wd;
+    return div_up(M, wide_tile(d) ? 128 : 256);
+}
+
+extern "C" int64_t cdet_packed_weight_elems(int32_t O, int32_t I, int32_t kh, int32_t kw, int32_t transpose) {
+    // O is the PADDED output-channel count here
+    const int rows = transpose ? I : O, C = transpose ? O : I;
+    return (int64_t)rows * kpad_of(kh * kw * C);
+}
+
+extern "C" int cdet_pack_weight(const float* w, void* out, int32_t O, int32_t O_pad, int32_t I, int32_t kh, int32_t kw, int32_t transpose,
+                                const float* row_scale, int32_t dtype, void* stream) {
+    CDET_CHECK_ARG(w && out && O > 0 && O_pad >= O && I > 0 && kh > 0 && kw > 0, "cdet_pack_weight: bad arguments");
+    CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "cdet_pack_weight: dtype must be bf16/f16");
+    const int rows = transpose ? I : O_pad, C = transpose ? O_pad : I;
+    const int Kpad = kpad_of(kh * kw * C);
+    const int64_t total = (int64_t)rows * Kpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)out, O, O_pad, I, kh, kw,
+                       transpose, row_scale, dtype, rows, Kpad);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w, const float* scale, const float* bias,
+                           const void* residual, void* y, float* stats, void* stream) {
+    CDET_CHECK_ARG(d && x && w && y, "cdet_conv2d: null pointer");
+    CDET_CHECK_ARG(d->dtype == CDET_BF16 || d->dtype == CDET_F16, "cdet_conv2d: dtype must be bf16/f16 (got %d)", d->dtype);
+    CDET_CHECK_ARG(d->Cs % 8 == 0 && d->src_ld % 8 == 0 && d->src_coff % 8 == 0,
+                   "cdet_conv2d: source channels/ld/coff must be multiples of 8 (Cs=%d ld=%d coff=%d)", d->Cs, d->src_ld, d->src_coff);
+    CDET_CHECK_ARG(d->Cd % 4 == 0 && d->dst_ld % 4 == 0 && d->dst_coff % 4 == 0,
+                   "cdet_conv2d: destination channels/ld/coff must be multiples of 4 (Cd=%d ld=%d coff=%d)", d->Cd, d->dst_ld, d->dst_coff);
+    CDET_CHECK_ARG(!residual || (d->res_ld % 4 == 0 && d->res_coff % 4 == 0), "cdet_conv2d: residual ld/coff must be multiples of 4");
+    CDET_CHECK_ARG(d->stride == 1 || d->stride == 2, "cdet_conv2d: stride must be 1 or 2");
+    CDET_CHECK_ARG(!d->accumulate || d->out_dtype == CDET_F32, "cdet_conv2d: accumulate needs an fp32 destination");
+    CDET_CHECK_ARG((int64_t)d->N * d->Hd * d->Wd < (1ll << 31) && (int64_t)d->N * d->Hs * d->Ws < (1ll << 31), "cdet_conv2d: too many pixels");
+    ConvArgs a;
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
+    a.y = y; a.stats = stats;
+    a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Cs = d->Cs; a.Hd = d->Hd; a.Wd = d->Wd; a.Cd = d->Cd;
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;
+    a.res_ld = d->res_ld; a.res_coff = d->res_coff;
+    a.Kpad = kpad_of(d->kh * d->kw * d->Cs); a.nk = a.Kpad / BK;
+    a.M = d->N * d->Hd * d->Wd;
+    a.act = d->act; a.out_dtype = d->out_dtype; a.accumulate = d->accumulate;
+    const bool wide = wide_tile(d);
+    a.n_pblk = div_up(a.M, wide ? 128 : 256);
+    a.n_cblk = div_up(d->Cd, wide ? 160 : 80);
+    const bool dg = d->mode == CDET_CONV_DGRAD;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == CDET_BF16) return wide ? launch_conv<CDET_BF16, 2, 2>(a, dg, s) : launch_conv<CDET_BF16, 4, 1>(a, dg, s);
+    return wide ? launch_conv<CDET_F16, 2, 2>(a, dg, s) : launch_conv<CDET_F16, 4, 1>(a, dg, s);
+}

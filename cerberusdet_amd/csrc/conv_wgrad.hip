@@ -1,0 +1,294 @@
+// Weight gradient of the NHWC convolution on MFMA (gfx950).
+//
+//   dW[co][k] = sum_p dY[p][co] * Xg[p][k],   k = (kh, kw, ci) flattened, p = (n, oy, ox), Xg = im2col gather of X.
+//
+// The reduction runs over PIXELS, but NHWC keeps channels contiguous, so both operand tiles arrive in LDS as
+// [pixel][channel] rows -- the transpose of what an MFMA fragment wants (8 consecutive reduction indices per lane).
+// gfx950's LDS transpose read (ds_read_b64_tr_b16) does that transposition for free on the way to the registers:
+// a 16-lane group reads a [4 pixels][16 channels] block and each lane receives one channel's 4 pixels.
+// Two such reads give a lane 8 reduction indices {4q..4q+3, 16+4q..16+4q+3} (q = lane>>4); A and B fragments use the
+// same index set, so the dot products are consistent.
+//
+// Tiling: A = X tile (rows = k columns, 64 per wave), B = dY tile (cols = couts, 80 per wave); block = 128 k-cols x
+// 160 couts (<2,2> waves) or 256 x 80 (<4,1>); 64 pixels per step; the pixel range is split over `S` blocks (split-K),
+// partials go to a workspace [S][Cout_pad][Kpad] and a second kernel reduces them in fixed order into fp32 OIHW.
+#include "common.h"
+
+namespace cdet {
+
+struct WgradArgs {
+    const uint16_t* x;
+    const uint16_t* dy;
+    float* ws;
+    int N, Hs, Ws, Cs, Hd, Wd, Cd;
+    int KH, KW, stride, pad;
+    int src_ld, src_coff, dy_ld, dy_coff;
+    int Ktot, Kp;         // taps*Cs and its padding to the k-tile
+    int Cd_pad;
+    int P;                // N*Hd*Wd
+    int chunk;            // pixels per split (multiple of 64)
+    int n_kblk, n_cblk, S;
+};
+
+constexpr int WKP = 64;  // pixels per step
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(u32x2, r);
+}
+
+template <int DT> struct Mfma2;
+template <> struct Mfma2<CDET_BF16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma2<CDET_F16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <int DT, int WAVES_K, int WAVES_C>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int BKC = 64 * WAVES_K;          // k columns per block
+    constexpr int BCO = 80 * WAVES_C;          // couts per block
+    constexpr int XROW = BKC * 2 + 32;         // LDS row bytes (+32 B: rows land on different banks)
+    constexpr int YROW = BCO * 2 + ((BCO * 2) % 256 == 0 ? 32 : 0);
+    constexpr int XV = BKC / 8;                // vectors per X row
+    constexpr int YV = BCO / 8;
+    constexpr int XR = WKP * XV / 256;         // X vectors per thread
+    constexpr int YTOT = WKP * YV;             // Y vectors per step
+    constexpr int YR = (YTOT + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Xs = smem;
+    unsigned char* Ys = smem + WKP * XROW;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave / WAVES_C, wc = wave % WAVES_C;
+    int bid = blockIdx.x;
+    const int s = bid % a.S;
+    bid /= a.S;
+    const int cblk = bid % a.n_cblk;
+    const int kblk = bid / a.n_cblk;
+    const int k0 = kblk * BKC, c0 = cblk * BCO;
+    const int p_begin = s * a.chunk;
+    const int p_end = min(p_begin + a.chunk, a.P);
+
+    // ---- X gather bookkeeping: this thread always loads k-vector `xkv` of rows xrow0 + 16*i (XV == 16 for BKC 128) ----
+    const int xkv = t % XV;
+    const int xrow0 = t / XV;
+    constexpr int XRSTEP = 256 / XV;
+    const int kcol = k0 + xkv * 8;
+    const bool k_ok = kcol < a.Ktot;
+    int tap = 0, ci = 0, kh = 0, kw = 0;
+    if (k_ok) {
+        tap = kcol / a.Cs;
+        ci = kcol - tap * a.Cs;
+        kh = tap / a.KW;
+        kw = tap - kh * a.KW;
+    }
+    // running (n, oy, ox) of each of this thread's rows; advanced by 64 pixels per step
+    int rn[XR], roy[XR], rox[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int p = p_begin + xrow0 + XRSTEP * i;
+        const int hw = a.Hd * a.Wd;
+        const int n = p / hw, rem = p - n * hw;
+        rn[i] = n;
+        roy[i] = rem / a.Wd;
+        rox[i] = rem - roy[i] * a.Wd;
+    }
+
+    u32x4 xreg[XR], yreg[YR];
+    auto load_global = [&](int pbase) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int p = pbase + xrow0 + XRSTEP * i;
+            const int sy = roy[i] * a.stride - a.pad + kh, sx = rox[i] * a.stride - a.pad + kw;
+            const bool ok = k_ok && p < p_end && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *reinterpret_cast<const u32x4*>(a.x + ((int64_t)(rn[i] * a.Hs + sy) * a.Ws + sx) * a.src_ld + a.src_coff + ci);
+            xreg[i] = v;
+            // advance by WKP pixels
+            rox[i] += WKP;
+            while (rox[i] >= a.Wd) {
+                rox[i] -= a.Wd;
+                if (++roy[i] == a.Hd) {
+                    roy[i] = 0;
+                    ++rn[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < YR; ++i) {
+            const int v = t + 256 * i;
+            const int row = v / YV, cv = v - row * YV;
+            const int p = pbase + row, co = c0 + cv * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (v < YTOT && p < p_end && co < a.Cd) val = *reinterpret_cast<const u32x4*>(a.dy + (int64_t)p * a.dy_ld + a.dy_coff + co);
+            yreg[i] = val;
+        }
+    };
+
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, li = lane & 15;
+    // byte offset of this lane's 8-byte chunk inside a [4 rows][16 ch] block: row (li>>2), channels (li&3)*4..+3
+    const int x_lane_off = (4 * q + (li >> 2)) * XROW + (wk * 64 + (li & 3) * 4) * 2;
+    const int y_lane_off = (4 * q + (li >> 2)) * YROW + (wc * 80 + (li & 3) * 4) * 2;
+
+    load_global(p_begin);
+    for (int pb = p_begin; pb < p_end; pb += WKP) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) *reinterpret_cast<u32x4*>(Xs + (xrow0 + XRSTEP * i) * XROW + xkv * 16) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < YR; ++i) {
+            const int v = t + 256 * i;
+            const int row = v / YV, cv = v - row * YV;
+            if (v < YTOT) *reinterpret_cast<u32x4*>(Ys + row * YROW + cv * 16) = yreg[i];
+        }
+        __syncthreads();
+        if (pb + WKP < p_end) load_global(pb + WKP);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {  // two 32-pixel MFMA steps
+            u32x4 af[4], bf[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* base = Xs + x_lane_off + kk * 32 * XROW + i * 32;  // 16 channels = 32 B per tile
+                const u32x2 lo = tr_read(base), hi = tr_read(base + 16 * XROW);
+                af[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const unsigned char* base = Ys + y_lane_off + kk * 32 * YROW + j * 32;
+                const u32x2 lo = tr_read(base), hi = tr_read(base + 16 * YROW);
+                bf[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[i][j] = Mfma2<DT>::run(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store partial tile: ws[s][co][k], lane holds 4 consecutive k for one co -------------------------------------
+    float* wsp = a.ws + (int64_t)s * a.Cd_pad * a.Kp;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int co = c0 + wc * 80 + j * 16 + li;
+        if (co >= a.Cd_pad) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + wk * 64 + i * 16 + q * 4;
+            if (k < a.Kp) *reinterpret_cast<f32x4*>(wsp + (int64_t)co * a.Kp + k) = acc[i][j];
+        }
+    }
+}
+
+// dw[o][i][kh][kw] (+)= sum_s ws[s][o][(kh,kw,i)]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int O, int Cd_pad, int I,
+                                                          int KH, int KW, int Kp, int accumulate) {
+    const int64_t total = (int64_t)O * I * KH * KW;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        // iterate in packed order (o, kh, kw, i) so that workspace reads are coalesced
+        const int i = (int)(idx % I);
+        int64_t r = idx / I;
+        const int kw = (int)(r % KW);
+        r /= KW;
+        const int kh = (int)(r % KH);
+        const int o = (int)(r / KH);
+        const int k = (kh * KW + kw) * I + i;
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum += ws[((int64_t)s * Cd_pad + o) * Kp + k];
+        float* d = dw + (((int64_t)o * I + i) * KH + kh) * KW + kw;
+        *d = accumulate ? *d + sum : sum;
+    }
+}
+
+struct WgradPlan {
+    bool wide;
+    int BKC, BCO, n_kblk, n_cblk, Kp, Cd_pad, S, chunk;
+};
+
+static WgradPlan plan_wgrad(const cdet_conv_desc* d) {
+    WgradPlan p;
+    p.wide = d->Cd > 80;
+    p.BKC = p.wide ? 128 : 256;
+    p.BCO = p.wide ? 160 : 80;
+    const int Ktot = d->kh * d->kw * d->Cs;
+    p.n_kblk = div_up(Ktot, p.BKC);
+    p.n_cblk = div_up(d->Cd, p.BCO);
+    p.Kp = p.n_kblk * p.BKC;
+    p.Cd_pad = p.n_cblk * p.BCO;
+    const int64_t P = (int64_t)d->N * d->Hd * d->Wd;
+    const int tiles = p.n_kblk * p.n_cblk;
+    // aim at ~4 workgroups per CU (1024 on MI355X) but keep >= 256 pixels per split
+    int S = (1024 + tiles - 1) / tiles;
+    const int maxS = (int)((P + 255) / 256);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    int chunk = (int)((P + S - 1) / S);
+    chunk = (chunk + WKP - 1) / WKP * WKP;
+    S = (int)((P + chunk - 1) / chunk);
+    p.S = S;
+    p.chunk = chunk;
+    return p;
+}
+
+template <int DT, int WK, int WC>
+static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    constexpr int BKC = 64 * WK, BCO = 80 * WC;
+    constexpr int XROW = BKC * 2 + 32;
+    constexpr int YROW = BCO * 2 + ((BCO * 2) % 256 == 0 ? 32 : 0);
+    const size_t lds = (size_t)WKP * (XROW + YROW);
+    hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC>), dim3(a.n_kblk * a.n_cblk * a.S), dim3(256), lds, s, a);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdet
+
+using namespace cdet;
+
+extern "C" int64_t cdet_conv2d_wgrad_ws_elems(const cdet_conv_desc* d) {
+    if (!d) return -1;
+    const WgradPlan p = plan_wgrad(d);
+    return (int64_t)p.S * p.Cd_pad * p.Kp;
+}
+
+extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const void* dy, float* dw, float* ws, int32_t accumulate, void* stream) {
+    CDET_CHECK_ARG(d && x && dy && dw && ws, "cdet_conv2d_wgrad: null pointer");
+    CDET_CHECK_ARG(d->dtype == CDET_BF16 || d->dtype == CDET_F16, "cdet_conv2d_wgrad: dtype must be bf16/f16");
+    CDET_CHECK_ARG(d->Cs % 8 == 0 && d->src_ld % 8 == 0 && d->src_coff % 8 == 0, "cdet_conv2d_wgrad: x channels/ld/coff must be multiples of 8");
+    CDET_CHECK_ARG(d->dst_ld % 8 == 0 && d->dst_coff % 8 == 0, "cdet_conv2d_wgrad: dy ld/coff must be multiples of 8");
+    CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_wgrad: descriptor must describe the forward convolution");
+    const WgradPlan p = plan_wgrad(d);
+    WgradArgs a;
+    a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.ws = ws;
+    a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Cs = d->Cs; a.Hd = d->Hd; a.Wd = d->Wd;
+    a.Cd = (d->Cd + 7) / 8 * 8;  // dy carries the padded channel count; pad channels hold zeros
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dy_ld = d->dst_ld; a.dy_coff = d->dst_coff;
+    a.Ktot = d->kh * d->kw * d->Cs; a.Kp = p.Kp; a.Cd_pad = p.Cd_pad;
+    a.P = d->N * d->Hd * d->Wd; a.chunk = p.chunk; a.n_kblk = p.n_kblk; a.n_cblk = p.n_cblk; a.S = p.S;
+    hipStream_t s = (hipStream_t)stream;
+    int e;
+    if (d->dtype == CDET_BF16) e = p.wide ? launch_wgrad<CDET_BF16, 2, 2>(a, s) : launch_wgrad<CDET_BF16, 4, 1>(a, s);
+    else e = p.wide ? launch_wgrad<CDET_F16, 2, 2>(a, s) : launch_wgrad<CDET_F16, 4, 1>(a, s);
+    if (e) return e;
+    const int64_t total = (int64_t)d->Cd * d->Cs * d->kh * d->kw;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, d->kh, d->kw, p.Kp, accumulate);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}

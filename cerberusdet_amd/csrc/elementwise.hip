@@ -1,0 +1,544 @@
+// HBM-bound NHWC kernels around the convolutions: train-mode BatchNorm+SiLU (fwd / bwd), channel-slice copies
+// (Concat), nearest 2x upsample (+bwd), SPPF max-pool chain (+bwd). All of them move 16-byte (8-channel)
+// vectors per lane; a thread keeps ONE channel vector for its whole life so that the per-channel parameters
+// (mean, invstd, gamma, beta) stay in registers while it walks down the pixel rows.
+#include "common.h"
+
+namespace cdet {
+
+struct Vec8 {
+    float v[8];
+};
+
+template <int DT>
+__device__ __forceinline__ Vec8 load8(const uint16_t* p) {
+    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    Vec8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o.v[2 * i] = Elem<DT>::to_f32((uint16_t)(r[i] & 0xffff));
+        o.v[2 * i + 1] = Elem<DT>::to_f32((uint16_t)(r[i] >> 16));
+    }
+    return o;
+}
+template <int DT>
+__device__ __forceinline__ void store8(uint16_t* p, const Vec8& x) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (uint32_t)Elem<DT>::from_f32(x.v[2 * i]) | ((uint32_t)Elem<DT>::from_f32(x.v[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = r;
+}
+__device__ __forceinline__ Vec8 loadf8(const float* p) {
+    Vec8 o;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o.v[i] = a[i];
+        o.v[4 + i] = b[i];
+    }
+    return o;
+}
+
+// thread -> (channel vector cv, row lane rl); rows advance by rows_per_pass
+struct ColMap {
+    int cv, rl, rows_per_pass;
+    bool active;
+};
+__device__ __forceinline__ ColMap col_map(int CV) {
+    ColMap m;
+    const int t = threadIdx.x;
+    m.rows_per_pass = blockDim.x / CV;
+    m.cv = t % CV;
+    m.rl = t / CV;
+    m.active = m.rl < m.rows_per_pass;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN finalize: partial sums [nblk][2][C] -> mean / invstd (+ running stats)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int C, double inv_count,
+                                                          double unbias, float eps, float momentum, float* running_mean,
+                                                          float* running_var, float* mean, float* invstd) {
+    __shared__ double sh[2][4][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int b = g; b < nblk; b += 4) {
+            s += (double)stats[((int64_t)b * 2 + 0) * C + c];
+            q += (double)stats[((int64_t)b * 2 + 1) * C + c];
+        }
+    }
+    sh[0][g][cx] = s;
+    sh[1][g][cx] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        s = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+        q = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+        const double m = s * inv_count;
+        double var = q * inv_count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = silu(gamma*(z-mean)*invstd + beta) (+ residual)
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const uint16_t* __restrict__ z, int z_ld, int z_coff,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const uint16_t* __restrict__ res, int res_ld, int res_coff,
+                                                          uint16_t* __restrict__ y, int y_ld, int y_coff, int64_t M, int CV) {
+    const ColMap cm = col_map(CV);
+    if (!cm.active) return;
+    const int c = cm.cv * 8;
+    const Vec8 mu = loadf8(mean + c), is = loadf8(invstd + c), ga = loadf8(gamma + c), be = loadf8(beta + c);
+    Vec8 sc, sh;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc.v[i] = ga.v[i] * is.v[i];
+        sh.v[i] = be.v[i] - mu.v[i] * sc.v[i];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+        Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x.v[i] = silu_f(x.v[i] * sc.v[i] + sh.v[i]);
+        if (res) {
+            const Vec8 rr = load8<DT>(res + r * res_ld + res_coff + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x.v[i] += rr.v[i];
+        }
+        store8<DT>(y + r * y_ld + y_coff + c, x);
+    }
+}
+
+// d silu(a)/da = s*(1 + a*(1-s)), s = sigmoid(a)
+__device__ __forceinline__ float dsilu_f(float a) {
+    const float s = sigmoid_f(a);
+    return s * (1.f + a * (1.f - s));
+}
+
+// pass 1: per-channel partial sums of dact and dact*xhat
+template <int DT>
+__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const uint16_t* __restrict__ dy, int dy_ld, int dy_coff,
+                                                                 const uint16_t* __restrict__ z, int z_ld, int z_coff,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ part, int64_t M, int C, int CV) {
+    extern __shared__ float shm[];  // [rows_per_pass][2][C]
+    const ColMap cm = col_map(CV);
+    const int c = cm.cv * 8;
+    Vec8 s1, s2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1.v[i] = s2.v[i] = 0.f;
+    if (cm.active) {
+        const Vec8 mu = loadf8(mean + c), is = loadf8(invstd + c), ga = loadf8(gamma + c), be = loadf8(beta + c);
+        for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+            const Vec8 g = load8<DT>(dy + r * dy_ld + dy_coff + c);
+            const Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (x.v[i] - mu.v[i]) * is.v[i];
+                const float da = g.v[i] * dsilu_f(ga.v[i] * xh + be.v[i]);
+                s1.v[i] += da;
+                s2.v[i] += da * xh;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            shm[(cm.rl * 2 + 0) * C + c + i] = s1.v[i];
+            shm[(cm.rl * 2 + 1) * C + c + i] = s2.v[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < cm.rows_per_pass; ++r) acc += shm[r * 2 * C + j];
+        part[(int64_t)blockIdx.x * 2 * C + j] = acc;
+    }
+}
+
+// pass 2a: reduce partials -> sums (and dgamma / dbeta)
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums,
+                                                          float* dgamma, float* dbeta, int accumulate) {
+    __shared__ double sh[2][4][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int b = g; b < nblk; b += 4) {
+            s += (double)part[((int64_t)b * 2 + 0) * C + c];
+            q += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+    }
+    sh[0][g][cx] = s;
+    sh[1][g][cx] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        s = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+        q = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+        sums[c] = (float)s;
+        sums[C + c] = (float)q;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+    }
+}
+
+// pass 2b: dz = gamma*invstd*(dact - mean(dact) - xhat*mean(dact*xhat))
+template <int DT>
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ dy, int dy_ld, int dy_coff,
+                                                                const uint16_t* __restrict__ z, int z_ld, int z_coff,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ sums, float inv_count,
+                                                                uint16_t* __restrict__ dz, int dz_ld, int dz_coff, int64_t M, int C, int CV) {
+    const ColMap cm = col_map(CV);
+    if (!cm.active) return;
+    const int c = cm.cv * 8;
+    const Vec8 mu = loadf8(mean + c), is = loadf8(invstd + c), ga = loadf8(gamma + c), be = loadf8(beta + c);
+    Vec8 m1 = loadf8(sums + c), m2 = loadf8(sums + C + c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        m1.v[i] *= inv_count;
+        m2.v[i] *= inv_count;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+        const Vec8 g = load8<DT>(dy + r * dy_ld + dy_coff + c);
+        const Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
+        Vec8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (x.v[i] - mu.v[i]) * is.v[i];
+            const float da = g.v[i] * dsilu_f(ga.v[i] * xh + be.v[i]);
+            o.v[i] = ga.v[i] * is.v[i] * (da - m1.v[i] - xh * m2.v[i]);
+        }
+        store8<DT>(dz + r * dz_ld + dz_coff + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// channel-slice copy / add, upsample, SPPF pools
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const uint16_t* __restrict__ src, int s_ld, int s_coff, uint16_t* __restrict__ dst,
+                                                            int d_ld, int d_coff, int64_t M, int CV, int accumulate) {
+    const int64_t total = M * CV;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = v / CV;
+        const int c = (int)(v - r * CV) * 8;
+        if (accumulate) {
+            Vec8 a = load8<DT>(src + r * s_ld + s_coff + c);
+            const Vec8 b = load8<DT>(dst + r * d_ld + d_coff + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.v[i] += b.v[i];
+            store8<DT>(dst + r * d_ld + d_coff + c, a);
+        } else {
+            *reinterpret_cast<u32x4*>(dst + r * d_ld + d_coff + c) = *reinterpret_cast<const u32x4*>(src + r * s_ld + s_coff + c);
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void add_channels_kernel(const uint16_t* __restrict__ a, int a_ld, int a_coff, const uint16_t* __restrict__ b,
+                                                           int b_ld, int b_coff, uint16_t* __restrict__ y, int y_ld, int y_coff, int64_t M, int CV) {
+    const int64_t total = M * CV;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = v / CV;
+        const int c = (int)(v - r * CV) * 8;
+        Vec8 x = load8<DT>(a + r * a_ld + a_coff + c);
+        const Vec8 z = load8<DT>(b + r * b_ld + b_coff + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x.v[i] += z.v[i];
+        store8<DT>(y + r * y_ld + y_coff + c, x);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void upsample2_kernel(const uint16_t* __restrict__ src, int s_ld, int s_coff, uint16_t* __restrict__ dst,
+                                                        int d_ld, int d_coff, int N, int H, int W, int CV) {
+    const int64_t total = (int64_t)N * 2 * H * 2 * W * CV;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = v / CV;
+        const int c = (int)(v - p * CV) * 8;
+        const int x = (int)(p % (2 * W));
+        const int64_t t = p / (2 * W);
+        const int y = (int)(t % (2 * H));
+        const int n = (int)(t / (2 * H));
+        const int64_t sp = ((int64_t)n * H + (y >> 1)) * W + (x >> 1);
+        *reinterpret_cast<u32x4*>(dst + p * d_ld + d_coff + c) = *reinterpret_cast<const u32x4*>(src + sp * s_ld + s_coff + c);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const uint16_t* __restrict__ dd, int dd_ld, int dd_coff, uint16_t* __restrict__ ds,
+                                                            int ds_ld, int ds_coff, int N, int H, int W, int CV, int accumulate) {
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = v / CV;
+        const int c = (int)(v - p * CV) * 8;
+        const int x = (int)(p % W);
+        const int64_t t = p / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        Vec8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.v[i] = 0.f;
+        if (accumulate) acc = load8<DT>(ds + p * ds_ld + ds_coff + c);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int64_t q = ((int64_t)n * 2 * H + 2 * y + dy) * (2 * W) + 2 * x + dx;
+                const Vec8 g = load8<DT>(dd + q * dd_ld + dd_coff + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc.v[i] += g.v[i];
+            }
+        store8<DT>(ds + p * ds_ld + ds_coff + c, acc);
+    }
+}
+
+// 5x5 stride-1 pad-2 max pool from channel slice `coff` into slice `coff + C`; first maximum in (ky, kx) scan order wins
+// (what torch's max_pool2d backward routes to).
+template <int DT>
+__global__ __launch_bounds__(256) void pool5_kernel(uint16_t* __restrict__ buf, int ld, int coff_in, int coff_out, int N, int H, int W, int CV) {
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = v / CV;
+        const int c = (int)(v - p * CV) * 8;
+        const int x = (int)(p % W);
+        const int64_t t = p / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        Vec8 best;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) best.v[i] = -INFINITY;
+        for (int ky = -2; ky <= 2; ++ky) {
+            const int yy = y + ky;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int kx = -2; kx <= 2; ++kx) {
+                const int xx = x + kx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const Vec8 s = load8<DT>(buf + (((int64_t)n * H + yy) * W + xx) * ld + coff_in + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) best.v[i] = fmaxf(best.v[i], s.v[i]);
+            }
+        }
+        store8<DT>(buf + p * ld + coff_out + c, best);
+    }
+}
+
+// backward of one pool stage (gather form): din[q] += sum over windows p containing q of dout[p] * [argmax_p == q],
+// argmax_p = first maximum of window p in (ky, kx) scan order, recomputed from the saved forward slices.
+template <int DT>
+__global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restrict__ buf, uint16_t* __restrict__ dbuf, int ld, int coff_in,
+                                                        int coff_out, int N, int H, int W, int CV) {
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = v / CV;
+        const int c = (int)(v - q * CV) * 8;
+        const int x = (int)(q % W);
+        const int64_t t = q / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Vec8 mine = load8<DT>(buf + q * ld + coff_in + c);
+        Vec8 acc = load8<DT>(dbuf + q * ld + coff_in + c);
+        for (int wy = -2; wy <= 2; ++wy) {
+            const int py = y + wy;
+            if ((unsigned)py >= (unsigned)H) continue;
+            for (int wx = -2; wx <= 2; ++wx) {
+                const int px = x + wx;
+                if ((unsigned)px >= (unsigned)W) continue;
+                const int64_t p = ((int64_t)n * H + py) * W + px;
+                const Vec8 mx = load8<DT>(buf + p * ld + coff_out + c);
+                const Vec8 g = load8<DT>(dbuf + p * ld + coff_out + c);
+                // q wins window p for channel i iff mine == max AND no EARLIER element of the window equals the max
+                bool cand[8];
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    cand[i] = mine.v[i] == mx.v[i];
+                    any |= cand[i];
+                }
+                if (!any) continue;
+                // scan elements of window p that come before q in (ky,kx) order
+                for (int ky = -2; ky <= 2; ++ky) {
+                    const int yy = py + ky;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    if (yy > y) break;
+                    for (int kx = -2; kx <= 2; ++kx) {
+                        const int xx = px + kx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        if (yy == y && xx >= x) break;
+                        const Vec8 e = load8<DT>(buf + (((int64_t)n * H + yy) * W + xx) * ld + coff_in + c);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) cand[i] = cand[i] && !(e.v[i] == mx.v[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (cand[i]) acc.v[i] += g.v[i];
+            }
+        }
+        store8<DT>(dbuf + q * ld + coff_in + c, acc);
+    }
+}
+
+static inline int grid_for(int64_t work_items, int per_block) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > 8192 ? 8192 : b);
+}
+
+}  // namespace cdet
+
+using namespace cdet;
+
+#define DISPATCH16(dtype, CALL)                                        \
+    do {                                                               \
+        if ((dtype) == CDET_BF16) { constexpr int DT = CDET_BF16; CALL; } \
+        else { constexpr int DT = CDET_F16; CALL; }                    \
+    } while (0)
+
+static int check16(const char* fn, int dtype, int C, int a, int b, int c, int d) {
+    CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "%s: dtype must be bf16/f16", fn);
+    CDET_CHECK_ARG(C > 0 && C % 8 == 0 && a % 8 == 0 && b % 8 == 0 && c % 8 == 0 && d % 8 == 0,
+                   "%s: channels / ld / coff must be multiples of 8 (C=%d)", fn, C);
+    return 0;
+}
+
+extern "C" int cdet_bn_finalize(const float* stats, int32_t nblk, int32_t C, int64_t count, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* invstd, void* stream) {
+    CDET_CHECK_ARG(stats && mean && invstd && nblk > 0 && C > 0 && count > 0, "cdet_bn_finalize: bad arguments");
+    const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, stats, nblk, C, 1.0 / (double)count,
+                       unbias, eps, momentum, running_mean, running_var, mean, invstd);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, const void* residual, int32_t res_ld, int32_t res_coff, void* y, int32_t y_ld,
+                                int32_t y_coff, int64_t M, int32_t C, int32_t dtype, void* stream) {
+    if (int e = check16("cdet_bn_silu_fwd", dtype, C, z_ld, z_coff, y_ld, y_coff)) return e;
+    CDET_CHECK_ARG(C / 8 <= 256, "cdet_bn_silu_fwd: C too large");
+    const int CV = C / 8, rpp = 256 / CV;
+    const int grid = grid_for(M, rpp * 8);
+    DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_fwd_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)z, z_ld,
+                                         z_coff, mean, invstd, gamma, beta, (const uint16_t*)residual, res_ld, res_coff, (uint16_t*)y, y_ld,
+                                         y_coff, M, CV));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_bn_bwd_blocks(int64_t M) {
+    int64_t b = (M + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                       const float* mean, const float* invstd, const float* gamma, const float* beta, float* part, int64_t M,
+                                       int32_t C, int32_t dtype, void* stream) {
+    if (int e = check16("cdet_bn_silu_bwd_reduce", dtype, C, dy_ld, dy_coff, z_ld, z_coff)) return e;
+    CDET_CHECK_ARG(C / 8 <= 256, "cdet_bn_silu_bwd_reduce: C too large");
+    const int CV = C / 8, rpp = 256 / CV;
+    const size_t shm = (size_t)rpp * 2 * C * sizeof(float);
+    CDET_CHECK_ARG(shm <= 64 * 1024, "cdet_bn_silu_bwd_reduce: LDS budget exceeded");
+    DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<DT>), dim3(cdet_bn_bwd_blocks(M)), dim3(256), shm, (hipStream_t)stream,
+                                         (const uint16_t*)dy, dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, part,
+                                         M, C, CV));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta, const float* part,
+                                      int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate, void* dz, int32_t dz_ld, int32_t dz_coff,
+                                      int64_t M, int32_t C, int32_t dtype, void* stream) {
+    if (int e = check16("cdet_bn_silu_bwd_apply", dtype, C, dy_ld, dy_coff, z_ld, z_coff)) return e;
+    CDET_CHECK_ARG(dz_ld % 8 == 0 && dz_coff % 8 == 0 && part && nblk > 0, "cdet_bn_silu_bwd_apply: bad arguments");
+    // the reduced sums live behind the partials: part[nblk*2*C .. nblk*2*C + 2*C)
+    float* sums = const_cast<float*>(part) + (int64_t)nblk * 2 * C;
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, dgamma, dbeta, accumulate);
+    CDET_LAUNCH_CHECK();
+    const int CV = C / 8, rpp = 256 / CV;
+    const int grid = grid_for(M, rpp * 8);
+    DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, dy_ld,
+                                         dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)M,
+                                         (uint16_t*)dz, dz_ld, dz_coff, M, C, CV));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_copy_channels(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff, int64_t M,
+                                  int32_t C, int32_t dtype, int32_t accumulate, void* stream) {
+    if (int e = check16("cdet_copy_channels", dtype, C, src_ld, src_coff, dst_ld, dst_coff)) return e;
+    const int CV = C / 8;
+    DISPATCH16(dtype, hipLaunchKernelGGL((copy_channels_kernel<DT>), dim3(grid_for(M * CV, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                                         (const uint16_t*)src, src_ld, src_coff, (uint16_t*)dst, dst_ld, dst_coff, M, CV, accumulate));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_add_channels(const void* a, int32_t a_ld, int32_t a_coff, const void* b, int32_t b_ld, int32_t b_coff, void* y, int32_t y_ld,
+                                 int32_t y_coff, int64_t M, int32_t C, int32_t dtype, void* stream) {
+    if (int e = check16("cdet_add_channels", dtype, C, a_ld, a_coff, b_ld, b_coff)) return e;
+    CDET_CHECK_ARG(y_ld % 8 == 0 && y_coff % 8 == 0, "cdet_add_channels: y ld/coff must be multiples of 8");
+    const int CV = C / 8;
+    DISPATCH16(dtype, hipLaunchKernelGGL((add_channels_kernel<DT>), dim3(grid_for(M * CV, 256 * 4)), dim3(256), 0, (hipStream_t)stream,
+                                         (const uint16_t*)a, a_ld, a_coff, (const uint16_t*)b, b_ld, b_coff, (uint16_t*)y, y_ld, y_coff, M, CV));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_upsample2(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff, int32_t N,
+                              int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (int e = check16("cdet_upsample2", dtype, C, src_ld, src_coff, dst_ld, dst_coff)) return e;
+    const int CV = C / 8;
+    DISPATCH16(dtype, hipLaunchKernelGGL((upsample2_kernel<DT>), dim3(grid_for((int64_t)N * 4 * H * W * CV, 256 * 4)), dim3(256), 0,
+                                         (hipStream_t)stream, (const uint16_t*)src, src_ld, src_coff, (uint16_t*)dst, dst_ld, dst_coff, N, H, W, CV));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_upsample2_bwd(const void* ddst, int32_t ddst_ld, int32_t ddst_coff, void* dsrc, int32_t dsrc_ld, int32_t dsrc_coff,
+                                  int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate, void* stream) {
+    if (int e = check16("cdet_upsample2_bwd", dtype, C, ddst_ld, ddst_coff, dsrc_ld, dsrc_coff)) return e;
+    const int CV = C / 8;
+    DISPATCH16(dtype, hipLaunchKernelGGL((upsample2_bwd_kernel<DT>), dim3(grid_for((int64_t)N * H * W * CV, 256 * 2)), dim3(256), 0,
+                                         (hipStream_t)stream, (const uint16_t*)ddst, ddst_ld, ddst_coff, (uint16_t*)dsrc, dsrc_ld, dsrc_coff, N, H,
+                                         W, CV, accumulate));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    if (int e = check16("cdet_sppf_pool", dtype, C, ld, coff, 0, 0)) return e;
+    const int CV = C / 8;
+    for (int i = 0; i < 3; ++i) {
+        DISPATCH16(dtype, hipLaunchKernelGGL((pool5_kernel<DT>), dim3(grid_for((int64_t)N * H * W * CV, 256)), dim3(256), 0, (hipStream_t)stream,
+                                             (uint16_t*)buf, ld, coff + i * C, coff + (i + 1) * C, N, H, W, CV));
+        CDET_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  int32_t dtype, void* stream) {
+    if (int e = check16("cdet_sppf_pool_bwd", dtype, C, ld, coff, 0, 0)) return e;
+    const int CV = C / 8;
+    for (int i = 2; i >= 0; --i) {
+        DISPATCH16(dtype, hipLaunchKernelGGL((pool5_bwd_kernel<DT>), dim3(grid_for((int64_t)N * H * W * CV, 256)), dim3(256), 0,
+                                             (hipStream_t)stream, (const uint16_t*)buf, (uint16_t*)dbuf, ld, coff + i * C, coff + (i + 1) * C, N, H,
+                                             W, CV));
+        CDET_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,293 @@
+// Batched NMS for gfx950: all images of the batch in ONE call, no host round trips.
+// Replaces the per-image python loop of utils/general.py:411-474 (amax filter, boolean compaction, best-class /
+// multi-label expansion, argsort, class offsets) and torchvision.ops.nms (general.py:464).
+//
+//   1. filter+compact (one workgroup per image): order-preserving compaction (block prefix sums) of the candidates in
+//      ORIGINAL index order -- anchor order, or (anchor, class) row-major order for multi_label -- so that the sort
+//      key (score desc, original position asc) reproduces a stable descending argsort. Scores are compared in the INPUT
+//      dtype (fp16 stays fp16) and xywh->xyxy is evaluated with the input dtype's rounding, as the reference does;
+//      everything after that is fp32 (general.py:446-449 promotes through `j.float()`).
+//   2. sort (one workgroup per image): bitonic sort of 64-bit keys; in LDS when the image has <= 4096 candidates,
+//      through the L2-resident workspace otherwise.
+//   3. greedy suppression (one wavefront per image): candidates are visited in tiles of 64 (one per lane); a tile is first
+//      tested against the list of already-kept boxes (LDS), then resolved internally with a 64x64 bit matrix held one
+//      row per lane. Kept boxes are in descending score order, so the scan STOPS after max_det keeps -- the result equals
+//      torchvision.ops.nms(...)[:max_det] without ever building the O(n^2) matrix.
+// IoU arithmetic is torchvision's: inter/(area_a+area_b-inter) > thr, fp32, IEEE division, no eps, no +1.
+#include "common.h"
+
+namespace cdet {
+
+constexpr float MAX_WH = 7680.0f;  // general.py:413
+
+struct Cand {        // 32 bytes
+    float x1, y1, x2, y2, conf, cls;
+    uint32_t pos, pad;
+};
+
+__device__ __forceinline__ float round_to(float v, int dtype) {
+    if (dtype == CDET_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
+    if (dtype == CDET_BF16) return bf16_bits_to_f32(f32_to_bf16_bits(v));
+    return v;
+}
+
+// monotone map float -> uint32 (ascending)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* sh_wave, int& total) {
+    // 256 threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) sh_wave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += sh_wave[w];
+    total = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+    return base + inc - v;
+}
+
+struct NmsArgs {
+    const void* pred;
+    int N, nc, A, dtype;
+    float conf_thres, iou_thres;
+    int agnostic, multi_label, max_det, max_nms, max_cand;
+    const int* classes;
+    int n_classes;
+    Cand* cand;             // [N][max_cand]
+    unsigned long long* keys;  // [N][cap2]
+    int cap2;
+    int* count;             // [N]
+    float* out_rows;
+    int* out_count;
+};
+
+__device__ __forceinline__ bool class_allowed(const NmsArgs& a, int c) {
+    if (a.n_classes <= 0) return true;
+    for (int i = 0; i < a.n_classes; ++i)
+        if (a.classes[i] == c) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs a) {
+    __shared__ int sh_wave[4];
+    __shared__ int sh_base;
+    const int n = blockIdx.x;
+    const int A = a.A, nc = a.nc;
+    const float thr = round_to(a.conf_thres, a.dtype);
+    const int64_t img = (int64_t)n * (4 + nc) * A;
+    Cand* out = a.cand + (int64_t)n * a.max_cand;
+    if (threadIdx.x == 0) sh_base = 0;
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += 256) {
+        const int an = a0 + threadIdx.x;
+        int cnt = 0;
+        float best = -INFINITY;
+        int bestc = 0;
+        if (an < A) {
+            for (int c = 0; c < nc; ++c) {
+                const float s = load_elem(a.pred, img + (int64_t)(4 + c) * A + an, a.dtype);
+                if (s > best) {  // first maximum wins, like torch.max(1)
+                    best = s;
+                    bestc = c;
+                }
+                if (a.multi_label && s > thr && class_allowed(a, c)) ++cnt;
+            }
+            if (!a.multi_label) cnt = (best > thr && class_allowed(a, bestc)) ? 1 : 0;
+        }
+        int total;
+        const int excl = block_exclusive_scan(cnt, sh_wave, total);
+        const int base = sh_base;
+        if (cnt > 0) {
+            const float cx = load_elem(a.pred, img + 0 * (int64_t)A + an, a.dtype), cy = load_elem(a.pred, img + 1 * (int64_t)A + an, a.dtype);
+            const float w = load_elem(a.pred, img + 2 * (int64_t)A + an, a.dtype), h = load_elem(a.pred, img + 3 * (int64_t)A + an, a.dtype);
+            const float hw = round_to(w / 2.f, a.dtype), hh = round_to(h / 2.f, a.dtype);
+            Cand cd;
+            cd.x1 = round_to(cx - hw, a.dtype);
+            cd.y1 = round_to(cy - hh, a.dtype);
+            cd.x2 = round_to(cx + hw, a.dtype);
+            cd.y2 = round_to(cy + hh, a.dtype);
+            cd.pad = 0;
+            int slot = base + excl;
+            if (a.multi_label) {
+                for (int c = 0; c < nc; ++c) {
+                    const float s = load_elem(a.pred, img + (int64_t)(4 + c) * A + an, a.dtype);
+                    if (s > thr && class_allowed(a, c)) {
+                        if (slot < a.max_cand) {
+                            cd.conf = s;
+                            cd.cls = (float)c;
+                            cd.pos = (uint32_t)slot;
+                            out[slot] = cd;
+                        }
+                        ++slot;
+                    }
+                }
+            } else if (slot < a.max_cand) {
+                cd.conf = best;
+                cd.cls = (float)bestc;
+                cd.pos = (uint32_t)slot;
+                out[slot] = cd;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh_base = base + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.count[n] = sh_base < a.max_cand ? sh_base : a.max_cand;
+}
+
+// key = (~ord(conf) << 32) | pos : ascending sort == conf descending, original position ascending
+constexpr int SORT_LDS_MAX = 4096;
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
+    __shared__ unsigned long long sk[SORT_LDS_MAX];
+    const int n = blockIdx.x;
+    const int cnt = a.count[n];
+    const Cand* cand = a.cand + (int64_t)n * a.max_cand;
+    unsigned long long* keys = a.keys + (int64_t)n * a.cap2;
+    int p2 = 1;
+    while (p2 < cnt) p2 <<= 1;
+    if (cnt <= 1) {
+        if (threadIdx.x == 0 && cnt == 1) keys[0] = 0ull;
+        return;
+    }
+    const bool in_lds = p2 <= SORT_LDS_MAX;
+    unsigned long long* k = in_lds ? sk : keys;
+    for (int i = threadIdx.x; i < p2; i += blockDim.x)
+        k[i] = i < cnt ? (((unsigned long long)(~f2ord(cand[i].conf))) << 32) | (unsigned long long)i : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= p2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < (p2 >> 1); i += blockDim.x) {
+                const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long x = k[lo], y = k[hi];
+                if ((x > y) == up) {
+                    k[lo] = y;
+                    k[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (in_lds)
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[i] = sk[i];
+}
+
+__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2, float by2,
+                                       float barea, float thr) {
+    const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1), xx2 = fminf(ax2, bx2), yy2 = fminf(ay2, by2);
+    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    const float inter = w * h;
+    const float iou = inter / (aarea + barea - inter);
+    return iou > thr;
+}
+
+constexpr int KEPT_MAX = 2048;  // LDS list of kept boxes (max_det is clamped to this)
+__global__ __launch_bounds__(64) void nms_greedy_kernel(const NmsArgs a) {
+    __shared__ float kx1[KEPT_MAX], ky1[KEPT_MAX], kx2[KEPT_MAX], ky2[KEPT_MAX], kar[KEPT_MAX];
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    int cnt = a.count[n];
+    if (cnt > a.max_nms) cnt = a.max_nms;  // general.py:459
+    const Cand* cand = a.cand + (int64_t)n * a.max_cand;
+    const unsigned long long* keys = a.keys + (int64_t)n * a.cap2;
+    float* rows = a.out_rows + (int64_t)n * a.max_det * 6;
+    const float thr = a.iou_thres;
+    int nkept = 0;
+    for (int t0 = 0; t0 < cnt && nkept < a.max_det; t0 += 64) {
+        const int i = t0 + lane;
+        const bool have = i < cnt;
+        Cand c;
+        c.x1 = c.y1 = c.x2 = c.y2 = c.conf = c.cls = 0.f;
+        if (have) c = cand[(uint32_t)(keys[i] & 0xffffffffull)];
+        const float off = a.agnostic ? 0.f : c.cls * MAX_WH;
+        const float bx1 = c.x1 + off, by1 = c.y1 + off, bx2 = c.x2 + off, by2 = c.y2 + off;
+        const float area = (bx2 - bx1) * (by2 - by1);
+        bool alive = have;
+        for (int k = 0; k < nkept && alive; ++k)
+            if (iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], bx1, by1, bx2, by2, area, thr)) alive = false;
+        // intra-tile: row `lane` of the suppression matrix = later lanes this box would suppress
+        unsigned long long row = 0ull;
+        for (int j = 0; j < 64; ++j) {
+            const float ox1 = __shfl(bx1, j), oy1 = __shfl(by1, j), ox2 = __shfl(bx2, j), oy2 = __shfl(by2, j), oar = __shfl(area, j);
+            if (j > lane && iou_gt(bx1, by1, bx2, by2, area, ox1, oy1, ox2, oy2, oar, thr)) row |= (1ull << j);
+        }
+        unsigned long long alive_mask = __ballot(alive);
+        unsigned long long keep_mask = 0ull;
+        int kept_here = 0;
+        for (int j = 0; j < 64; ++j) {
+            if (!((alive_mask >> j) & 1ull)) continue;
+            if (nkept + kept_here >= a.max_det) break;
+            keep_mask |= (1ull << j);
+            ++kept_here;
+            const unsigned long long rj = __shfl(row, j);  // uniform j: broadcast lane j's row
+            alive_mask &= ~rj;
+        }
+        if ((keep_mask >> lane) & 1ull) {
+            const int slot = nkept + __popcll(keep_mask & ((1ull << lane) - 1ull));
+            if (slot < KEPT_MAX) {
+                kx1[slot] = bx1; ky1[slot] = by1; kx2[slot] = bx2; ky2[slot] = by2; kar[slot] = area;
+            }
+            float* r = rows + (int64_t)slot * 6;
+            r[0] = c.x1; r[1] = c.y1; r[2] = c.x2; r[3] = c.y2; r[4] = c.conf; r[5] = c.cls;
+        }
+        nkept += kept_here;
+        __syncthreads();
+    }
+    if (lane == 0) a.out_count[n] = nkept;
+}
+
+static inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace cdet
+
+using namespace cdet;
+
+static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d) {
+    if (!d) return -1;
+    const int cap2 = next_pow2(d->max_cand);
+    return align256((int64_t)d->N * d->max_cand * sizeof(Cand)) + align256((int64_t)d->N * cap2 * 8) + align256((int64_t)d->N * 4);
+}
+
+extern "C" int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, void* ws, void* stream) {
+    CDET_CHECK_ARG(d && pred && out_rows && out_count && ws, "cdet_nms_batched: null pointer");
+    CDET_CHECK_ARG(d->conf_thres >= 0.f && d->conf_thres <= 1.f, "Invalid Confidence threshold %f, valid values are between 0.0 and 1.0", d->conf_thres);
+    CDET_CHECK_ARG(d->iou_thres >= 0.f && d->iou_thres <= 1.f, "Invalid IoU %f, valid values are between 0.0 and 1.0", d->iou_thres);
+    CDET_CHECK_ARG(d->max_det > 0 && d->max_det <= KEPT_MAX, "cdet_nms_batched: max_det must be in [1, %d]", KEPT_MAX);
+    CDET_CHECK_ARG(d->max_cand > 0 && d->N > 0 && d->nc > 0 && d->A > 0, "cdet_nms_batched: bad sizes");
+    NmsArgs a;
+    a.pred = pred; a.N = d->N; a.nc = d->nc; a.A = d->A; a.dtype = d->dtype;
+    a.conf_thres = d->conf_thres; a.iou_thres = d->iou_thres; a.agnostic = d->agnostic;
+    a.multi_label = (d->multi_label && d->nc > 1) ? 1 : 0;  // general.py:419
+    a.max_det = d->max_det; a.max_nms = d->max_nms > 0 ? d->max_nms : 30000; a.max_cand = d->max_cand;
+    a.classes = d->classes; a.n_classes = d->classes ? d->n_classes : 0;
+    a.cap2 = next_pow2(d->max_cand);
+    char* p = (char*)ws;
+    a.cand = (Cand*)p; p += align256((int64_t)d->N * d->max_cand * sizeof(Cand));
+    a.keys = (unsigned long long*)p; p += align256((int64_t)d->N * a.cap2 * 8);
+    a.count = (int*)p;
+    a.out_rows = out_rows; a.out_count = out_count;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_filter_kernel, dim3(d->N), dim3(256), 0, s, a);
+    CDET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(d->N), dim3(1024), 0, s, a);
+    CDET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(d->N), dim3(64), 0, s, a);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}

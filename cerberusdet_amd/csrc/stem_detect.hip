@@ -1,0 +1,291 @@
+// Stem convolution (Cin = 3: K = 27, HBM-bound, direct VALU kernel reading the reference's NCHW image) and the
+// Detect head's eval-mode decode (DFL softmax-expectation + dist2bbox + sigmoid, writes the reference's [N,4+nc,A]).
+#include "common.h"
+
+namespace cdet {
+
+constexpr int STEM_TPB = 256;
+constexpr int STEM_MAX_COUT = 128;
+
+__device__ __forceinline__ float load_img(const void* img, int64_t i, int dtype) {
+    if (dtype == CDET_U8) return (float)((const uint8_t*)img)[i] * (1.0f / 255.0f);
+    return load_elem(img, i, dtype);
+}
+
+// One thread = one output pixel, all Cout channels (8 at a time). Weights live in LDS as [27][Cout] fp32 (broadcast reads).
+__global__ __launch_bounds__(STEM_TPB) void stem_conv_kernel(const void* __restrict__ img, int img_dtype, const float* __restrict__ w,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            void* __restrict__ y, int N, int H, int W, int Cout, int out_dtype, int act,
+                                                            float* __restrict__ stats) {
+    __shared__ float ws[27 * STEM_MAX_COUT];
+    __shared__ float red[2][4][STEM_MAX_COUT];
+    for (int i = threadIdx.x; i < 27 * Cout; i += STEM_TPB) {
+        const int k = i / Cout, co = i - k * Cout;  // k = (c*3 + kh)*3 + kw  (OIHW inner order)
+        ws[i] = w[co * 27 + k];
+    }
+    __syncthreads();
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t M = (int64_t)N * Ho * Wo;
+    const int64_t p = (int64_t)blockIdx.x * STEM_TPB + threadIdx.x;
+    const bool valid = p < M;
+    float in[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) in[k] = 0.f;
+    if (valid) {
+        const int ox = (int)(p % Wo);
+        const int64_t t = p / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iy = oy * 2 - 1 + kh, ix = ox * 2 - 1 + kw;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                        in[(c * 3 + kh) * 3 + kw] = load_img(img, (((int64_t)n * 3 + c) * H + iy) * W + ix, img_dtype);
+                }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int cb = 0; cb < Cout; cb += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(in[k], ws[k * Cout + cb + j], acc[j]);
+        }
+        if (stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = acc[j], q = acc[j] * acc[j];  // invalid threads hold zeros
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    s += __shfl_xor(s, m);
+                    q += __shfl_xor(q, m);
+                }
+                if (lane == 0) {
+                    red[0][wave][cb + j] = s;
+                    red[1][wave][cb + j] = q;
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = acc[j];
+                if (scale) v *= scale[cb + j];
+                if (bias) v += bias[cb + j];
+                if (act == CDET_ACT_SILU) v = silu_f(v);
+                acc[j] = v;
+            }
+            const int64_t o = p * Cout + cb;
+            if (out_dtype == CDET_F32) {
+                float* yp = (float*)y + o;
+                *reinterpret_cast<f32x4*>(yp) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4*>(yp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            } else {
+                u32x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint16_t lo = out_dtype == CDET_BF16 ? f32_to_bf16_bits(acc[2 * j]) : f32_to_f16_bits(acc[2 * j]);
+                    const uint16_t hi = out_dtype == CDET_BF16 ? f32_to_bf16_bits(acc[2 * j + 1]) : f32_to_f16_bits(acc[2 * j + 1]);
+                    pk[j] = (uint32_t)lo | ((uint32_t)hi << 16);
+                }
+                *reinterpret_cast<u32x4*>((uint16_t*)y + o) = pk;
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < Cout; c += STEM_TPB) {
+            stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+            stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        }
+    }
+}
+
+// dW[co][c][kh][kw] += sum_p dy[p][co] * in[p][c,kh,kw]; thread (co, c) owns the 9 taps of one input channel.
+// Pixels are staged through LDS in tiles of 64; one fp32 atomicAdd per output per block at the end.
+constexpr int SW_TILE = 64;
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const void* __restrict__ img, int img_dtype, const void* __restrict__ dy, int dtype,
+                                                        float* __restrict__ dw, int N, int H, int W, int Cout, int pix_per_block) {
+    __shared__ float s_in[SW_TILE][28];
+    __shared__ float s_dy[SW_TILE][STEM_MAX_COUT + 1];
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t M = (int64_t)N * Ho * Wo;
+    const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p_end = p_begin + pix_per_block < M ? p_begin + pix_per_block : M;
+    const int t = threadIdx.x;
+    float acc[3][9];  // a thread may own up to 3 (co, c) pairs when 3*Cout > 256
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[s][k] = 0.f;
+    const int n_pairs = 3 * Cout;
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += SW_TILE) {
+        __syncthreads();
+        for (int i = t; i < SW_TILE * 27; i += 256) {
+            const int lp = i / 27, k = i - lp * 27;
+            const int64_t p = p0 + lp;
+            float v = 0.f;
+            if (p < p_end) {
+                const int ox = (int)(p % Wo);
+                const int64_t tt = p / Wo;
+                const int oy = (int)(tt % Ho);
+                const int n = (int)(tt / Ho);
+                const int c = k / 9, kh = (k % 9) / 3, kw = k % 3;
+                const int iy = oy * 2 - 1 + kh, ix = ox * 2 - 1 + kw;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = load_img(img, (((int64_t)n * 3 + c) * H + iy) * W + ix, img_dtype);
+            }
+            s_in[lp][k] = v;
+        }
+        for (int i = t; i < SW_TILE * Cout; i += 256) {
+            const int lp = i / Cout, co = i - lp * Cout;
+            const int64_t p = p0 + lp;
+            s_dy[lp][co] = p < p_end ? load_elem(dy, p * Cout + co, dtype) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int pair = t + s * 256;
+            if (pair < n_pairs) {
+                const int c = pair / Cout, co = pair - c * Cout;
+                for (int lp = 0; lp < SW_TILE; ++lp) {
+                    const float g = s_dy[lp][co];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc[s][k] = fmaf(g, s_in[lp][c * 9 + k], acc[s][k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int pair = t + s * 256;
+        if (pair < n_pairs) {
+            const int c = pair / Cout, co = pair - c * Cout;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicAdd(dw + (co * 3 + c) * 9 + k, acc[s][k]);
+        }
+    }
+}
+
+__global__ void zero_f32_kernel(float* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Detect decode: one thread per (image, anchor)
+// ------------------------------------------------------------------------------------------------
+struct DecodeArgs {
+    const void* f[3];
+    int h[3], w[3];
+    float stride[3];
+    int a_off[4];  // anchor offsets of the levels, a_off[3] = A
+};
+
+__global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N, int nc, int dtype, void* __restrict__ y, int out_dtype) {
+    const int A = d.a_off[3];
+    const int64_t total = (int64_t)N * A;
+    const int no = 64 + nc;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / A);
+        const int a = (int)(idx - (int64_t)n * A);
+        const int lvl = a >= d.a_off[2] ? 2 : (a >= d.a_off[1] ? 1 : 0);
+        const int la = a - d.a_off[lvl];
+        const int gx = la % d.w[lvl], gy = la / d.w[lvl];
+        const void* f = d.f[lvl];
+        const int64_t base = ((int64_t)n * d.h[lvl] * d.w[lvl] + la) * no;
+        float dist[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                v[b] = load_elem(f, base + s * 16 + b, dtype);
+                mx = fmaxf(mx, v[b]);
+            }
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const float e = expf(v[b] - mx);
+                den += e;
+                num += e * (float)b;
+            }
+            dist[s] = num / den;
+        }
+        const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f, st = d.stride[lvl];
+        const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+        const int64_t yo = (int64_t)n * (4 + nc) * A + a;
+        store_elem(y, yo + 0 * (int64_t)A, (x1 + x2) * 0.5f * st, out_dtype);
+        store_elem(y, yo + 1 * (int64_t)A, (y1 + y2) * 0.5f * st, out_dtype);
+        store_elem(y, yo + 2 * (int64_t)A, (x2 - x1) * st, out_dtype);
+        store_elem(y, yo + 3 * (int64_t)A, (y2 - y1) * st, out_dtype);
+        for (int c = 0; c < nc; ++c) {
+            const float z = load_elem(f, base + 64 + c, dtype);
+            store_elem(y, yo + (int64_t)(4 + c) * A, 1.0f / (1.0f + expf(-z)), out_dtype);
+        }
+    }
+}
+
+}  // namespace cdet
+
+using namespace cdet;
+
+extern "C" int cdet_stem_conv_stat_blocks(int32_t N, int32_t H, int32_t W) { return div_up((int64_t)N * (H / 2) * (W / 2), STEM_TPB); }
+
+extern "C" int cdet_stem_conv(const void* img, int32_t img_dtype, const float* w, const float* scale, const float* bias, void* y, int32_t N,
+                              int32_t H, int32_t W, int32_t Cout, int32_t out_dtype, int32_t act, float* stats, void* stream) {
+    CDET_CHECK_ARG(img && w && y, "cdet_stem_conv: null pointer");
+    CDET_CHECK_ARG(Cout % 8 == 0 && Cout <= STEM_MAX_COUT, "cdet_stem_conv: Cout must be a multiple of 8 and <= %d (got %d)", STEM_MAX_COUT, Cout);
+    CDET_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "cdet_stem_conv: H and W must be even");
+    const int blocks = cdet_stem_conv_stat_blocks(N, H, W);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(STEM_TPB), 0, (hipStream_t)stream, img, img_dtype, w, scale, bias, y, N, H, W, Cout,
+                       out_dtype, act, stats);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_stem_conv_wgrad(const void* img, int32_t img_dtype, const void* dy, int32_t dtype, float* dw, int32_t N, int32_t H, int32_t W,
+                                    int32_t Cout, int32_t accumulate, void* stream) {
+    CDET_CHECK_ARG(img && dy && dw, "cdet_stem_conv_wgrad: null pointer");
+    CDET_CHECK_ARG(Cout <= STEM_MAX_COUT && 3 * Cout <= 768, "cdet_stem_conv_wgrad: Cout too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(4), dim3(256), 0, s, dw, (int64_t)Cout * 27);
+        CDET_LAUNCH_CHECK();
+    }
+    const int64_t M = (int64_t)N * (H / 2) * (W / 2);
+    int blocks = (int)((M + 2047) / 2048);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    int ppb = (int)((M + blocks - 1) / blocks);
+    ppb = (ppb + SW_TILE - 1) / SW_TILE * SW_TILE;
+    blocks = (int)((M + ppb - 1) / ppb);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, s, img, img_dtype, dy, dtype, dw, N, H, W, Cout, ppb);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_detect_decode(const void* f0, const void* f1, const void* f2, const int32_t* hw6, const float* strides3, int32_t N, int32_t nc,
+                                  int32_t dtype, void* y, int32_t out_dtype, void* stream) {
+    CDET_CHECK_ARG(f0 && f1 && f2 && hw6 && strides3 && y, "cdet_detect_decode: null pointer");
+    DecodeArgs d;
+    d.f[0] = f0; d.f[1] = f1; d.f[2] = f2;
+    int off = 0;
+    for (int i = 0; i < 3; ++i) {
+        d.h[i] = hw6[2 * i]; d.w[i] = hw6[2 * i + 1]; d.stride[i] = strides3[i];
+        d.a_off[i] = off;
+        off += d.h[i] * d.w[i];
+    }
+    d.a_off[3] = off;
+    const int64_t total = (int64_t)N * off;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(detect_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d, N, nc, dtype, y, out_dtype);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,283 @@
+"""Thin host wrappers: torch tensors own the memory, libcerberus_hip.so does the work.
+
+NHWC activations are described by `View` = (buffer [N,H,W,LD], channel offset, channel count) so that producers
+can write straight into channel slices of concat buffers (models/common.py:191,245,295 never materialise a cat).
+Every wrapper launches asynchronously on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.bfloat16: L.BF16, torch.float16: L.F16, torch.float32: L.F32, torch.uint8: L.U8}
+
+
+def dt(t) -> int:
+    return _DT[t if isinstance(t, torch.dtype) else t.dtype]
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> Optional[int]:
+    if t is None:
+        return None
+    if isinstance(t, View):
+        return t.buf.data_ptr()
+    return t.data_ptr()
+
+
+class View:
+    """Channel slice [coff, coff+C) of a contiguous NHWC buffer."""
+
+    __slots__ = ("buf", "coff", "C")
+
+    def __init__(self, buf: torch.Tensor, coff: int = 0, C: Optional[int] = None):
+        assert buf.dim() == 4 and buf.is_contiguous()
+        self.buf, self.coff = buf, coff
+        self.C = buf.shape[3] - coff if C is None else C
+
+    N = property(lambda s: s.buf.shape[0])
+    H = property(lambda s: s.buf.shape[1])
+    W = property(lambda s: s.buf.shape[2])
+    ld = property(lambda s: s.buf.shape[3])
+    M = property(lambda s: s.buf.shape[0] * s.buf.shape[1] * s.buf.shape[2])
+    dtype = property(lambda s: s.buf.dtype)
+
+    def slice(self, c0, c):
+        return View(self.buf, self.coff + c0, c)
+
+    def torch(self):
+        return self.buf[..., self.coff:self.coff + self.C]
+
+    def nchw(self):
+        return self.torch().permute(0, 3, 1, 2)
+
+
+def new_act(N, H, W, C, dtype, device="cuda", zero=False):
+    f = torch.zeros if zero else torch.empty
+    return View(f((N, H, W, C), dtype=dtype, device=device))
+
+
+def from_nchw(x: torch.Tensor, dtype=None) -> View:
+    x = x.permute(0, 2, 3, 1).contiguous()
+    return View(x.to(dtype) if dtype is not None else x)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def conv_desc(src: View, dst: View, k, s, mode=L.CONV_FWD, act=L.ACT_NONE, res: Optional[View] = None, accumulate=False,
+              pad=None) -> L.ConvDesc:
+    d = L.ConvDesc()
+    d.N, d.Hs, d.Ws, d.Cs = src.N, src.H, src.W, src.C
+    d.Hd, d.Wd, d.Cd = dst.H, dst.W, dst.C
+    d.kh = d.kw = k
+    d.stride, d.pad, d.mode = s, (k // 2 if pad is None else pad), mode
+    d.dtype, d.out_dtype, d.act = dt(src.dtype), dt(dst.dtype), act
+    d.src_ld, d.src_coff, d.dst_ld, d.dst_coff = src.ld, src.coff, dst.ld, dst.coff
+    d.res_ld, d.res_coff = (res.ld, res.coff) if res is not None else (0, 0)
+    d.accumulate = 1 if accumulate else 0
+    return d
+
+
+def pack_weight(w_oihw: torch.Tensor, dtype, transpose=False, row_scale=None, o_pad=None) -> torch.Tensor:
+    lib = L.load()
+    O, I, kh, kw = w_oihw.shape
+    o_pad = O if o_pad is None else o_pad
+    w32 = w_oihw.detach().float().contiguous()
+    n = lib.cdet_packed_weight_elems(o_pad, I, kh, kw, int(transpose))
+    out = torch.empty(n, dtype=dtype, device=w_oihw.device)
+    L.check(lib.cdet_pack_weight(ptr(w32), ptr(out), O, o_pad, I, kh, kw, int(transpose), ptr(row_scale), dt(dtype), stream()),
+            "cdet_pack_weight")
+    return out
+
+
+def conv2d(src: View, w_packed, dst: View, k, s, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None,
+           stats=None, mode=L.CONV_FWD, accumulate=False, desc=None):
+    lib = L.load()
+    d = desc or conv_desc(src, dst, k, s, mode, act, res, accumulate)
+    L.check(lib.cdet_conv2d(C.byref(d), ptr(src), ptr(w_packed), ptr(scale), ptr(bias), ptr(res), ptr(dst), ptr(stats), stream()),
+            "cdet_conv2d")
+    return dst
+
+
+def conv_stat_blocks(src: View, dst: View, k, s) -> int:
+    d = conv_desc(src, dst, k, s)
+    return L.load().cdet_conv2d_stat_blocks(C.byref(d))
+
+
+def conv2d_wgrad(src: View, dy: View, dw: torch.Tensor, k, s, accumulate=False, ws=None):
+    """dw: fp32 OIHW [Cd_real, Cs, k, k]; dy may carry channel padding (dy.C >= dw.shape[0])."""
+    lib = L.load()
+    d = conv_desc(src, dy, k, s)
+    d.Cd = dw.shape[0]
+    n = lib.cdet_conv2d_wgrad_ws_elems(C.byref(d))
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=dw.device)
+    L.check(lib.cdet_conv2d_wgrad(C.byref(d), ptr(src), ptr(dy), ptr(dw), ptr(ws), int(accumulate), stream()), "cdet_conv2d_wgrad")
+    return dw
+
+
+def stem_conv(img: torch.Tensor, w: torch.Tensor, dst: View, scale=None, bias=None, act=L.ACT_NONE, stats=None):
+    lib = L.load()
+    N, c, H, W = img.shape
+    assert c == 3 and img.is_contiguous() and dst.coff == 0 and dst.ld == dst.C
+    L.check(lib.cdet_stem_conv(ptr(img), dt(img.dtype), ptr(w), ptr(scale), ptr(bias), ptr(dst), N, H, W, dst.C, dt(dst.dtype), act,
+                               ptr(stats), stream()), "cdet_stem_conv")
+    return dst
+
+
+def stem_stat_blocks(N, H, W) -> int:
+    return L.load().cdet_stem_conv_stat_blocks(N, H, W)
+
+
+def stem_conv_wgrad(img, dy: View, dw, accumulate=False):
+    lib = L.load()
+    N, c, H, W = img.shape
+    assert dy.coff == 0 and dy.ld == dy.C
+    L.check(lib.cdet_stem_conv_wgrad(ptr(img), dt(img.dtype), ptr(dy), dt(dy.dtype), ptr(dw), N, H, W, dy.C, int(accumulate), stream()),
+            "cdet_stem_conv_wgrad")
+    return dw
+
+
+def bn_finalize(stats, nblk, Cn, count, eps, momentum, running_mean, running_var, mean, invstd):
+    L.check(L.load().cdet_bn_finalize(ptr(stats), nblk, Cn, count, eps, momentum, ptr(running_mean), ptr(running_var), ptr(mean),
+                                      ptr(invstd), stream()), "cdet_bn_finalize")
+
+
+def bn_silu_fwd(z: View, mean, invstd, gamma, beta, y: View, res: Optional[View] = None):
+    L.check(L.load().cdet_bn_silu_fwd(ptr(z), z.ld, z.coff, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(res),
+                                      res.ld if res else 0, res.coff if res else 0, ptr(y), y.ld, y.coff, z.M, z.C, dt(z.dtype), stream()),
+            "cdet_bn_silu_fwd")
+    return y
+
+
+def bn_bwd_blocks(M) -> int:
+    return L.load().cdet_bn_bwd_blocks(M)
+
+
+def bn_silu_bwd(dy: View, z: View, mean, invstd, gamma, beta, dz: View, dgamma, dbeta, accumulate=False, part=None):
+    lib = L.load()
+    nblk = lib.cdet_bn_bwd_blocks(z.M)
+    need = nblk * 2 * z.C + 2 * z.C
+    if part is None or part.numel() < need:
+        part = torch.empty(need, dtype=torch.float32, device=z.buf.device)
+    L.check(lib.cdet_bn_silu_bwd_reduce(ptr(dy), dy.ld, dy.coff, ptr(z), z.ld, z.coff, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                                        ptr(part), z.M, z.C, dt(z.dtype), stream()), "cdet_bn_silu_bwd_reduce")
+    L.check(lib.cdet_bn_silu_bwd_apply(ptr(dy), dy.ld, dy.coff, ptr(z), z.ld, z.coff, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                                       ptr(part), nblk, ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dz), dz.ld, dz.coff, z.M, z.C,
+                                       dt(z.dtype), stream()), "cdet_bn_silu_bwd_apply")
+    return dz
+
+
+def copy_channels(src: View, dst: View, accumulate=False):
+    assert src.C == dst.C and src.M == dst.M
+    L.check(L.load().cdet_copy_channels(ptr(src), src.ld, src.coff, ptr(dst), dst.ld, dst.coff, src.M, src.C, dt(src.dtype),
+                                        int(accumulate), stream()), "cdet_copy_channels")
+    return dst
+
+
+def add_channels(a: View, b: View, y: View):
+    L.check(L.load().cdet_add_channels(ptr(a), a.ld, a.coff, ptr(b), b.ld, b.coff, ptr(y), y.ld, y.coff, a.M, a.C, dt(a.dtype), stream()),
+            "cdet_add_channels")
+    return y
+
+
+def upsample2(src: View, dst: View):
+    assert dst.H == 2 * src.H and dst.W == 2 * src.W and dst.C == src.C
+    L.check(L.load().cdet_upsample2(ptr(src), src.ld, src.coff, ptr(dst), dst.ld, dst.coff, src.N, src.H, src.W, src.C, dt(src.dtype),
+                                    stream()), "cdet_upsample2")
+    return dst
+
+
+def upsample2_bwd(ddst: View, dsrc: View, accumulate=False):
+    L.check(L.load().cdet_upsample2_bwd(ptr(ddst), ddst.ld, ddst.coff, ptr(dsrc), dsrc.ld, dsrc.coff, dsrc.N, dsrc.H, dsrc.W, dsrc.C,
+                                        dt(dsrc.dtype), int(accumulate), stream()), "cdet_upsample2_bwd")
+    return dsrc
+
+
+def sppf_pool(buf: View, Cn):
+    """buf: concat buffer; slice [coff, coff+Cn) holds x, slices 1..3 receive the chained 5x5 max pools."""
+    L.check(L.load().cdet_sppf_pool(ptr(buf), buf.ld, buf.coff, buf.N, buf.H, buf.W, Cn, dt(buf.dtype), stream()), "cdet_sppf_pool")
+    return buf
+
+
+def sppf_pool_bwd(buf: View, dbuf: View, Cn):
+    L.check(L.load().cdet_sppf_pool_bwd(ptr(buf), ptr(dbuf), buf.ld, buf.coff, buf.N, buf.H, buf.W, Cn, dt(buf.dtype), stream()),
+            "cdet_sppf_pool_bwd")
+    return dbuf
+
+
+def detect_decode(feats, nc, strides, out_dtype=torch.float32):
+    """feats: 3 NHWC tensors [N,h,w,ld>=64+nc] -> y [N, 4+nc, A] (reference layout)."""
+    lib = L.load()
+    N = feats[0].shape[0]
+    ld = feats[0].shape[3]
+    assert all(f.is_contiguous() and f.shape[3] == ld for f in feats)
+    assert ld == 64 + nc, "detect_decode expects unpadded maps; use the engine's decode for padded layouts"
+    A = sum(f.shape[1] * f.shape[2] for f in feats)
+    y = torch.empty((N, 4 + nc, A), dtype=out_dtype, device=feats[0].device)
+    hw = (C.c_int32 * 6)(*[v for f in feats for v in (f.shape[1], f.shape[2])])
+    st = (C.c_float * 3)(*[float(s) for s in strides])
+    L.check(lib.cdet_detect_decode(ptr(feats[0]), ptr(feats[1]), ptr(feats[2]), hw, st, N, nc, dt(feats[0].dtype), ptr(y), dt(out_dtype),
+                                   stream()), "cdet_detect_decode")
+    return y
+
+
+def det_loss(feats, gt, nc, gains, strides, grad_scale=1.0, grad_dtype=None, want_assign=False, topk=10, alpha=0.5, beta=6.0):
+    """feats: 3 NHWC tensors [N,h,w,ld]; gt [N,n_max,5] fp32 (cls,x1,y1,x2,y2 px). Returns (loss5, dfeats, assign)."""
+    lib = L.load()
+    dev = feats[0].device
+    N, ld = feats[0].shape[0], feats[0].shape[3]
+    d = L.LossDesc()
+    d.N, d.nc, d.n_max = N, nc, gt.shape[1]
+    for i, f in enumerate(feats):
+        d.hw[2 * i], d.hw[2 * i + 1] = f.shape[1], f.shape[2]
+        d.stride[i] = float(strides[i])
+    d.gain_box, d.gain_cls, d.gain_dfl = gains["box"], gains["cls"], gains["dfl"]
+    d.grad_scale = grad_scale
+    d.dtype = dt(feats[0].dtype)
+    grad_dtype = grad_dtype or feats[0].dtype
+    d.grad_dtype = dt(grad_dtype)
+    d.f_ld, d.topk, d.alpha, d.beta = ld, topk, alpha, beta
+    A = sum(f.shape[1] * f.shape[2] for f in feats)
+    ws = torch.empty(lib.cdet_det_loss_ws_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    out = torch.empty(5, dtype=torch.float32, device=dev)
+    dfe = [torch.empty(f.shape, dtype=grad_dtype, device=dev) for f in feats]
+    asg = None
+    if want_assign:
+        asg = dict(fg_mask=torch.empty((N, A), dtype=torch.uint8, device=dev), target_gt_idx=torch.empty((N, A), dtype=torch.int32, device=dev),
+                   target_labels=torch.empty((N, A), dtype=torch.int32, device=dev), target_bboxes=torch.empty((N, A, 4), device=dev),
+                   target_scores=torch.empty((N, A, nc), device=dev))
+    g = asg or {}
+    L.check(lib.cdet_det_loss(C.byref(d), ptr(feats[0]), ptr(feats[1]), ptr(feats[2]), ptr(gt), ptr(dfe[0]), ptr(dfe[1]), ptr(dfe[2]), ptr(out),
+                              ptr(g.get("fg_mask")), ptr(g.get("target_gt_idx")), ptr(g.get("target_labels")), ptr(g.get("target_bboxes")),
+                              ptr(g.get("target_scores")), ptr(ws), stream()), "cdet_det_loss")
+    return out, dfe, asg
+
+
+def nms_batched(pred: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
+                max_nms=30000):
+    """pred [N, 4+nc, A] -> (rows [N,max_det,6] fp32, counts [N] i32)."""
+    lib = L.load()
+    assert pred.is_contiguous()
+    N, no, A = pred.shape
+    nc = no - 4
+    d = L.NmsDesc()
+    d.N, d.nc, d.A, d.dtype = N, nc, A, dt(pred.dtype)
+    d.conf_thres, d.iou_thres = conf_thres, iou_thres
+    d.agnostic, d.multi_label, d.max_det, d.max_nms = int(agnostic), int(multi_label), max_det, max_nms
+    d.max_cand = A * nc if (multi_label and nc > 1) else A
+    cls_t = None
+    if classes is not None:
+        cls_t = torch.tensor(list(classes), dtype=torch.int32, device=pred.device)
+        d.classes, d.n_classes = cls_t.data_ptr(), cls_t.numel()
+    ws = torch.empty(lib.cdet_nms_ws_bytes(C.byref(d)), dtype=torch.uint8, device=pred.device)
+    rows = torch.zeros((N, max_det, 6), dtype=torch.float32, device=pred.device)
+    cnt = torch.zeros(N, dtype=torch.int32, device=pred.device)
+    L.check(lib.cdet_nms_batched(C.byref(d), ptr(pred), ptr(rows), ptr(cnt), ptr(ws), stream()), "cdet_nms_batched")
+    return rows, cnt

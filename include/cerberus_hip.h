@@ -1,0 +1,223 @@
+/*
+ * cerberus_hip.h -- C-ABI of libcerberus_hip.so: hand-written CDNA4 (gfx950) kernels for the
+ * CerberusDet hot path (shared backbone -> per-task neck -> Detect head -> {loss | NMS}).
+ *
+ * The reference (ai-forever/CerberusDet) has NO native/FFI interface: every op on its hot path is a
+ * stock torch op reached from Python. Each entry point below therefore cites
+ * the reference Python call site(s) it replaces (paths relative to cerberusdet/ in the reference).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes + POD descriptors, no torch / C++ types;
+ *   - the CALLER owns every buffer (device pointers of tensors allocated by the host framework);
+ *     the library never allocates or frees device memory and keeps no pointer past return;
+ *   - every launch is asynchronous on the hipStream_t passed last (void* here so that the header
+ *     needs no HIP include); no entry point synchronises;
+ *   - return 0 on success, <0 on failure (-1000-x = argument validation, otherwise -hipError_t);
+ *     cdet_last_error() returns a thread-local message;
+ *   - thread-safe: no global mutable state besides the thread-local error string;
+ *   - activations are NHWC ("channels last"); a tensor is described by (ptr, ld, coff): pixel p,
+ *     channel c lives at ptr[p*ld + coff + c] -- this lets producers write straight into channel
+ *     slices of a concat buffer, so torch.cat (common.py:191,245,295) never materialises.
+ */
+#ifndef CERBERUS_HIP_H
+#define CERBERUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDET_ABI_VERSION 1
+
+/* element types */
+enum { CDET_BF16 = 0, CDET_F16 = 1, CDET_F32 = 2, CDET_U8 = 3 };
+/* activations */
+enum { CDET_ACT_NONE = 0, CDET_ACT_SILU = 1 };
+/* conv gather modes */
+enum { CDET_CONV_FWD = 0, CDET_CONV_DGRAD = 1 };
+
+int cdet_version(void);
+const char* cdet_last_error(void);
+/* device properties the host needs to size workspaces: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=gfx arch number */
+int cdet_device_info(int32_t* out3);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (bf16/f16 in, fp32 accumulate).
+ * Replaces nn.Conv2d inside Conv.forward / fuseforward (models/common.py:57-68), the biased 1x1 head
+ * projections (models/yolo.py:82-84) and -- in DGRAD mode -- autograd's convolution_backward(input).
+ *
+ *   FWD  : y[n,oy,ox,co] = sum_{kh,kw,ci} x[n, oy*s-pad+kh, ox*s-pad+kw, ci] * w[co][kh][kw][ci]
+ *   DGRAD: y[n,iy,ix,ci] = sum_{kh,kw,co} x[n,(iy+pad-kh)/s,(ix+pad-kw)/s, co] * w[ci][kh][kw][co]
+ *          (terms with non-integer or out-of-range source coordinates are zero)
+ * then    y = act(y * scale[c] + bias[c]) (+ residual), each optional.
+ * `w` is the PACKED weight produced by cdet_pack_weight: [Crows][Kpad] of the activation dtype,
+ * K = kh*kw*Csrc contiguous, zero-padded to a multiple of 64.
+ * If stats != NULL the kernel also writes per-(pixel-block, channel) partial sums of the RAW fp32
+ * convolution result: stats[(blk*2+0)*Cout + c] = sum, stats[(blk*2+1)*Cout + c] = sum of squares
+ * (blk < cdet_conv2d_stat_blocks(desc)); this feeds train-mode BatchNorm (common.py:61).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, Hs, Ws, Cs;     /* source tensor: batch, height, width, channels (reduction channels)      */
+    int32_t Hd, Wd, Cd;        /* destination tensor: height, width, channels (GEMM rows of `w`)          */
+    int32_t kh, kw, stride, pad;
+    int32_t mode;              /* CDET_CONV_FWD / CDET_CONV_DGRAD                                         */
+    int32_t dtype;             /* element type of x, w, residual (CDET_BF16 / CDET_F16)                  */
+    int32_t out_dtype;         /* CDET_BF16 / CDET_F16 / CDET_F32                                        */
+    int32_t act;               /* CDET_ACT_*                                                             */
+    int32_t src_ld, src_coff;  /* source pixel stride / channel offset (elements)                        */
+    int32_t dst_ld, dst_coff;
+    int32_t res_ld, res_coff;  /* residual (same dtype as x), used when residual != NULL                 */
+    int32_t accumulate;        /* !=0: y += result (out_dtype must be F32); used for gradient fan-in     */
+} cdet_conv_desc;
+
+int cdet_conv2d_stat_blocks(const cdet_conv_desc* d);
+int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* bias,
+                const void* residual, void* y, float* stats, void* stream);
+
+/* OIHW fp32 master weight -> packed GEMM operand.
+ *   transpose == 0: rows = O, K order (kh, kw, i)   [forward operand]
+ *   transpose == 1: rows = I, K order (kh, kw, o)   [DGRAD operand]
+ * row_scale (optional, length O): multiplies output channel o (BN folding, utils/torch_utils.py:191-217).
+ * Replaces the implicit fp32->half cast of autocast (trainers/averaging.py:158) and fuse_conv_and_bn. */
+int cdet_pack_weight(const float* w_oihw, void* w_packed, int32_t O, int32_t O_pad, int32_t I, int32_t kh, int32_t kw,
+                     int32_t transpose, const float* row_scale, int32_t dtype, void* stream);
+/* O_pad >= O: output channels O..O_pad-1 are zero (head maps are padded to a multiple of 8 channels). */
+int64_t cdet_packed_weight_elems(int32_t O_pad, int32_t I, int32_t kh, int32_t kw, int32_t transpose);
+
+/* Weight gradient: dw[o][i][kh][kw] (+)= sum_{n,oy,ox} dy[n,oy,ox,o] * x[n,oy*s-pad+kh,ox*s-pad+kw,i]
+ * (autograd's convolution_backward(weight) for models/common.py:57). dw is fp32 OIHW; `ws` is a caller-provided
+ * fp32 workspace of cdet_conv2d_wgrad_ws_elems(d) elements (split-K partials), may be NULL when that is 0. */
+int64_t cdet_conv2d_wgrad_ws_elems(const cdet_conv_desc* d);
+int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const void* dy, float* dw_oihw, float* ws,
+                      int32_t accumulate, void* stream);
+
+/* Stem convolution (models/common.py:57 for the first backbone row, Cin = 3): reads the image in the
+ * reference's NCHW layout (uint8 scaled by 1/255 -- trainers/base_trainer.py:61-63 -- or float), 3x3 stride 2 pad 1,
+ * writes NHWC. Direct (non-MFMA) kernel: K = 27, HBM-bound. Same epilogue/stat semantics as cdet_conv2d. */
+int cdet_stem_conv(const void* img_nchw, int32_t img_dtype, const float* w_oihw, const float* scale, const float* bias,
+                   void* y, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t out_dtype, int32_t act,
+                   float* stats, void* stream);
+int cdet_stem_conv_stat_blocks(int32_t N, int32_t H, int32_t W);
+/* d(stem weight) from dy (NHWC, dtype) and the image; accumulates into fp32 OIHW [Cout,3,3,3]. */
+int cdet_stem_conv_wgrad(const void* img_nchw, int32_t img_dtype, const void* dy, int32_t dtype, float* dw_oihw,
+                         int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU around the conv (common.py:61, torch_utils.py:184-186)
+ * ---------------------------------------------------------------------------------------------- */
+/* Reduce the conv kernel's partial sums -> mean, invstd (biased var), update running stats (unbiased var). */
+int cdet_bn_finalize(const float* stats, int32_t nblk, int32_t C, int64_t count, float eps, float momentum,
+                     float* running_mean, float* running_var, float* mean, float* invstd, void* stream);
+/* y = silu(gamma*(z-mean)*invstd + beta) (+ residual); z,y [M, C] with strides. */
+int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, const void* residual, int32_t res_ld, int32_t res_coff,
+                     void* y, int32_t y_ld, int32_t y_coff, int64_t M, int32_t C, int32_t dtype, void* stream);
+/* Backward, pass 1: dact = dy * silu'(a), a = gamma*xhat+beta; partial sums of dact and dact*xhat per channel
+ * -> part[(blk*2+{0,1})*C + c], blk < cdet_bn_bwd_blocks(M). */
+int cdet_bn_bwd_blocks(int64_t M);
+int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            float* part, int64_t M, int32_t C, int32_t dtype, void* stream);
+/* pass 2: reduce partials -> dgamma(+)=, dbeta(+)=; dz = gamma*invstd*(dact - mean(dact) - xhat*mean(dact*xhat)).
+ * `part` must hold (nblk*2*C + 2*C) floats: the reduced sums are stored behind the partials. */
+int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* part, int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate,
+                           void* dz, int32_t dz_ld, int32_t dz_coff, int64_t M, int32_t C, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-movement ops of the graph
+ * ---------------------------------------------------------------------------------------------- */
+/* dst[:, coff:coff+C] (=|+=) src[:, :C]  -- Concat (common.py:288-295) / chunk views / gradient fan-in. */
+int cdet_copy_channels(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff,
+                       int64_t M, int32_t C, int32_t dtype, int32_t accumulate, void* stream);
+/* nn.Upsample(None, 2, 'nearest') (model YAML neck rows) fused with the Concat that always follows it. */
+int cdet_upsample2(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff,
+                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* backward of the above: dsrc[n,y,x,c] (=|+=) sum of the 4 children */
+int cdet_upsample2_bwd(const void* ddst, int32_t ddst_ld, int32_t ddst_coff, void* dsrc, int32_t dsrc_ld,
+                       int32_t dsrc_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, int32_t accumulate,
+                       void* stream);
+/* SPPF pooling (common.py:237,243-245): buf[:, coff + (i+1)*C : ...] = maxpool5x5s1p2^(i+1)(buf[:, coff : coff+C]), i=0..2 */
+int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                   void* stream);
+/* backward through the three chained pools: dbuf[:, coff:coff+C] += routed gradients of slices 1..3 */
+int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C,
+                       int32_t dtype, void* stream);
+/* y (=|+=) a + b elementwise on [M,C] slices (Bottleneck residual backward fan-in, common.py:117) */
+int cdet_add_channels(const void* a, int32_t a_ld, int32_t a_coff, const void* b, int32_t b_ld, int32_t b_coff,
+                      void* y, int32_t y_ld, int32_t y_coff, int64_t M, int32_t C, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Detect head eval branch (models/yolo.py:93-100 + DFL 57-59 + utils/tal.py:181-205)
+ * feats: 3 NHWC maps with channels [64 box-bin logits | nc class logits], fp32/bf16/f16.
+ * y: [N, 4+nc, A] (reference layout, A = sum H_i*W_i), out_dtype.
+ * ---------------------------------------------------------------------------------------------- */
+int cdet_detect_decode(const void* f0, const void* f1, const void* f2, const int32_t* hw6, const float* strides3,
+                       int32_t N, int32_t nc, int32_t dtype, void* y, int32_t out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss: TAL assignment + BCE + CIoU + DFL, forward AND gradient w.r.t. the raw head maps in one pass
+ * (utils/loss.py:133-181, utils/tal.py:56-178, utils/metrics.py:373-412).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, nc, n_max;          /* batch, classes, padded GT count per image                      */
+    int32_t hw[6];                 /* h0,w0,h1,w1,h2,w2                                              */
+    float stride[3];
+    float gain_box, gain_cls, gain_dfl;
+    float grad_scale;              /* d(scalar)/d(feat) is multiplied by this (loss weight * world)  */
+    int32_t dtype;                 /* dtype of the head maps (CDET_F32 / BF16 / F16)                 */
+    int32_t grad_dtype;            /* dtype of the gradient maps df*                                 */
+    int32_t f_ld;                  /* channel stride of a map pixel: >= 64+nc (layout padding, the   */
+                                   /* pad channels get zero gradient)                                */
+    int32_t topk;                  /* 10                                                             */
+    float alpha, beta;             /* 0.5, 6.0                                                       */
+} cdet_loss_desc;
+int64_t cdet_det_loss_ws_bytes(const cdet_loss_desc* d);
+/* gt: [N, n_max, 5] fp32 (cls, x1, y1, x2, y2 in pixels; rows with box sum <= 0 are padding, loss.py:155);
+ * n_max >= 1 (pass one all-zero row per image when the batch has no labels).
+ * out_loss[0..3] = (box, cls, dfl, box+cls+dfl) with gains applied; out_loss[4] = 2*N*total (loss.py:179-181).
+ * assign outputs (optional, may be NULL): fg_mask u8 [N,A], target_gt_idx i32 [N,A], target_labels i32 [N,A],
+ * target_bboxes f32 [N,A,4] (pixels), target_scores f32 [N,A,nc]. dfeat*: same shape/dtype as feats (may be NULL). */
+int cdet_det_loss(const cdet_loss_desc* d, const void* f0, const void* f1, const void* f2, const float* gt,
+                  void* df0, void* df1, void* df2, float* out_loss5, uint8_t* fg_mask, int32_t* target_gt_idx,
+                  int32_t* target_labels, float* target_bboxes, float* target_scores, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched NMS (utils/general.py:360-481 incl. torchvision.ops.nms at :464) for ALL images in one call.
+ * pred: [N, 4+nc, A] (xywh + class scores), dtype. out_rows: [N, max_det, 6] fp32, out_count: [N] i32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, nc, A;
+    int32_t dtype;
+    float conf_thres, iou_thres;
+    int32_t agnostic, multi_label, max_det;
+    int32_t max_nms;               /* 30000 (general.py:414)                                         */
+    int32_t max_cand;              /* capacity of the candidate buffers per image (<= A or A*nc)     */
+    const int32_t* classes;        /* optional device pointer to class filter list                   */
+    int32_t n_classes;
+} cdet_nms_desc;
+int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d);
+int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor optimizer step (trainers/averaging.py:205-223, utils/torch_utils.py:302-312)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* p; float* g; float* mom; float* ema;   /* ema may be NULL */
+    int64_t n;
+    float lr, weight_decay, inv_div;              /* inv_div = 1 / #tasks served by the block */
+    int32_t first_step;                           /* momentum buffer uninitialised            */
+} cdet_param_slot;
+/* sum of squares of all gradients -> out[0]; `out` must hold 1 + 32*n_slots floats (block partials, fixed-order reduce).
+ * A slot with g == NULL takes part in the EMA only (BatchNorm running statistics). */
+int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, void* stream);
+/* clip by global norm (coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))), per-block division, SGD-nesterov, EMA, zero grad */
+int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm,
+                      float momentum, float ema_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CERBERUS_HIP_H */
