@@ -61,12 +61,13 @@ _SIGS = {
     "cdet_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32,
                                      i64, i32, i32, vp]),
     "cdet_copy_channels": (i32, [vp, i32, i32, vp, i32, i32, i64, i32, i32, i32, vp]),
+    "cdet_colsum": (i32, [vp, i32, i32, i64, i32, i32, i32, vp, i32, vp, vp]),
     "cdet_add_channels": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i64, i32, i32, vp]),
     "cdet_upsample2": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_upsample2_bwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_sppf_pool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_sppf_pool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "cdet_detect_decode": (i32, [vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i32, i32, vp, i32, vp]),
+    "cdet_detect_decode": (i32, [vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i32, i32, i32, vp, i32, vp]),
     "cdet_det_loss_ws_bytes": (i64, [C.POINTER(LossDesc)]),
     "cdet_det_loss": (i32, [C.POINTER(LossDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_nms_ws_bytes": (i64, [C.POINTER(NmsDesc)]),

@@ -1,0 +1,47 @@
+"""torch.autograd bridge: lets reference-style code (`out = model(img, task); loss(out).backward()`) drive the compiled
+plan. Forward returns the three raw head maps (views of the plan's fp32 buffers, NCHW-shaped); backward copies the
+incoming gradients into the plan's head-gradient buffers and replays the backward launch list. Parameter gradients are
+accumulated IN PLACE into the model-owned fp32 `.grad` buffers (the reference accumulates over the per-task passes of an
+iteration too, trainers/averaging.py:142-168), so the Function returns None for them."""
+from __future__ import annotations
+
+import torch
+
+
+class _PlanFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x, anchor):
+        plan.run_forward(x)
+        ctx.plan = plan
+        outs = []
+        for t in plan.tasks:
+            nc = plan.model.get_head(t).nc
+            outs += [f[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        i = 0
+        for t in plan.tasks:
+            nc = plan.model.get_head(t).nc
+            for d in plan.dfeats[t]:
+                g = grads[i]
+                i += 1
+                if g is None:
+                    d.zero_()
+                else:
+                    d[..., :64 + nc].copy_(g.permute(0, 2, 3, 1))
+        plan.run_backward()
+        return None, None, None
+
+
+def run_with_autograd(plan, x):
+    # `anchor` is a leaf that requires grad so that autograd records the node even though the image does not need gradients
+    anchor = plan.model._autograd_anchor()
+    outs = _PlanFunction.apply(plan, x, anchor)
+    res, i = {}, 0
+    for t in plan.tasks:
+        res[t] = list(outs[i:i + 3])
+        i += 3
+    return res

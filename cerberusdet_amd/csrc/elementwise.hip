@@ -391,6 +391,43 @@ __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restri
     }
 }
 
+
+// per-channel sum over rows of a [M, C] slice (bias gradient of the head's 1x1 projections): block partials, then
+// bn_bwd_sums_kernel-style fixed-order finish.
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __restrict__ src, int ld, int coff, float* __restrict__ part, int64_t M,
+                                                             int C, int CV) {
+    extern __shared__ float shm[];  // [rows_per_pass][C]
+    const ColMap cm = col_map(CV);
+    const int c = cm.cv * 8;
+    Vec8 s1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1.v[i] = 0.f;
+    if (cm.active) {
+        for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+            const Vec8 g = load8<DT>(src + r * ld + coff + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1.v[i] += g.v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) shm[cm.rl * C + c + i] = s1.v[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < C; j += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < cm.rows_per_pass; ++r) acc += shm[r * C + j];
+        part[(int64_t)blockIdx.x * C + j] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, int C, int C_out, float* out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C_out) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * C + c];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
 static inline int grid_for(int64_t work_items, int per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -540,5 +577,20 @@ extern "C" int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32
                                              W, CV));
         CDET_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int cdet_colsum(const void* src, int32_t ld, int32_t coff, int64_t M, int32_t C, int32_t C_out, int32_t dtype, float* out,
+                           int32_t accumulate, float* part, void* stream) {
+    if (int e = check16("cdet_colsum", dtype, C, ld, coff, 0, 0)) return e;
+    CDET_CHECK_ARG(out && part && C_out <= C && C / 8 <= 256, "cdet_colsum: bad arguments");
+    const int CV = C / 8, rpp = 256 / CV;
+    const int nblk = cdet_bn_bwd_blocks(M);
+    const size_t shm = (size_t)rpp * C * sizeof(float);
+    DISPATCH16(dtype, hipLaunchKernelGGL((colsum_partial_kernel<DT>), dim3(nblk), dim3(256), shm, (hipStream_t)stream, (const uint16_t*)src, ld, coff,
+                                         part, M, C, CV));
+    CDET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(div_up(C_out, 256)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, C_out, out, accumulate);
+    CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -186,10 +186,10 @@ struct DecodeArgs {
     int a_off[4];  // anchor offsets of the levels, a_off[3] = A
 };
 
-__global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N, int nc, int dtype, void* __restrict__ y, int out_dtype) {
+__global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N, int nc, int f_ld, int dtype, void* __restrict__ y, int out_dtype) {
     const int A = d.a_off[3];
     const int64_t total = (int64_t)N * A;
-    const int no = 64 + nc;
+    const int no = f_ld;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / A);
         const int a = (int)(idx - (int64_t)n * A);
@@ -271,8 +271,9 @@ extern "C" int cdet_stem_conv_wgrad(const void* img, int32_t img_dtype, const vo
 }
 
 extern "C" int cdet_detect_decode(const void* f0, const void* f1, const void* f2, const int32_t* hw6, const float* strides3, int32_t N, int32_t nc,
-                                  int32_t dtype, void* y, int32_t out_dtype, void* stream) {
+                                  int32_t f_ld, int32_t dtype, void* y, int32_t out_dtype, void* stream) {
     CDET_CHECK_ARG(f0 && f1 && f2 && hw6 && strides3 && y, "cdet_detect_decode: null pointer");
+    CDET_CHECK_ARG(f_ld >= 64 + nc, "cdet_detect_decode: f_ld (%d) < 64 + nc (%d)", f_ld, 64 + nc);
     DecodeArgs d;
     d.f[0] = f0; d.f[1] = f1; d.f[2] = f2;
     int off = 0;
@@ -285,7 +286,7 @@ extern "C" int cdet_detect_decode(const void* f0, const void* f1, const void* f2
     const int64_t total = (int64_t)N * off;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(detect_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d, N, nc, dtype, y, out_dtype);
+    hipLaunchKernelGGL(detect_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d, N, nc, f_ld, dtype, y, out_dtype);
     CDET_LAUNCH_CHECK();
     return 0;
 }

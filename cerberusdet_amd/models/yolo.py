@@ -1,0 +1,169 @@
+"""YAML -> layers, the backbone container `Model`, and the `Detect` head -- same schema, names and state-dict keys as the
+reference (ai-forever/CerberusDet cerberusdet/models/yolo.py:48-60 DFL, 64-110 Detect, 113-231 Model, 234-339 parsing).
+
+Modules are resolved BY NAME from the YAML through an explicit table (the reference `eval()`s the strings, yolo.py:254).
+"""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from pathlib import Path
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .common import BN_EPS, BN_MOMENTUM, C2f, Concat, Conv, SPPF, Upsample, _NoEager
+
+REG_MAX = 16
+
+MODULES = {"Conv": Conv, "C2f": C2f, "SPPF": SPPF, "Concat": Concat, "nn.Upsample": Upsample, "Upsample": Upsample}
+
+
+def make_divisible(x, divisor):
+    """reference utils/general.py:206-208"""
+    return math.ceil(x / divisor) * divisor
+
+
+class DFL(_NoEager):
+    """Frozen 1x1 conv holding arange(16): expectation over the softmaxed distance bins (reference yolo.py:48-60)."""
+
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+
+class Detect(_NoEager):
+    """YOLOv8 detection head: per level cv2 = Conv3x3 -> Conv3x3 -> Conv2d1x1(64), cv3 = ... -> Conv2d1x1(nc)."""
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = REG_MAX
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], self.nc)
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
+        self.dfl = DFL(self.reg_max)
+        self.ch = tuple(ch)
+
+    def bias_init(self):
+        """reference yolo.py:102-110 (requires self.stride)"""
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
+
+
+def initialize_weights(model):
+    """reference utils/torch_utils.py:179-188: BN eps / momentum (conv init stays torch's default)."""
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps = BN_EPS
+            m.momentum = BN_MOMENTUM
+
+
+def get_next_layer_from_cfg(gd, ch, gw, nc, m, n, f, args, max_channels):
+    """One YAML row -> module instance (reference yolo.py:283-339). `nc` is the list of per-task class counts;
+    a Detect row pops the first entry. Returns (args, nc, n, c2, module)."""
+    args = list(args)
+    for j, a in enumerate(args):
+        if isinstance(a, str):
+            if a == "None":
+                args[j] = None
+            elif a in ("True", "False"):
+                args[j] = a == "True"
+    if isinstance(m, str):
+        if m == "Detect":
+            m = Detect
+        elif m in MODULES:
+            m = MODULES[m]
+        else:
+            raise NotImplementedError(f"module '{m}' is not part of the CerberusDet hot path (Conv, C2f, SPPF, Concat, nn.Upsample, Detect)")
+    c2 = None
+    n = n_ = max(round(n * gd), 1) if n > 1 else n
+    if m in (Conv, SPPF, C2f):
+        c1, c2 = ch[f], args[0]
+        if all(c2 != nc_ for nc_ in nc):  # reference quirk (yolo.py:311): widths that equal a class count are not scaled
+            c2 = make_divisible(min(c2, max_channels) * gw, 8)
+        args = [c1, c2, *args[1:]]
+        if m is C2f:
+            args.insert(2, n)
+            n = 1
+    elif m is Concat:
+        c2 = sum(ch[x] for x in f)
+    elif m is Detect:
+        if len(args) == 0:
+            args.append(nc.pop(0))
+        elif isinstance(args[0], list):
+            args[0] = args[0][0]
+        args.append([ch[x] for x in f])
+    else:
+        c2 = ch[f]
+    module = nn.Sequential(*[m(*args) for _ in range(n)]) if n > 1 else m(*args)
+    return args, nc, n_, c2, module
+
+
+def parse_model(yaml_config, ch, without_head=False, verbose=False):
+    """backbone (+ neck + head unless without_head) rows -> nn.Sequential, save list, channel list (yolo.py:234-280)."""
+    gd, gw = yaml_config["depth_multiple"], yaml_config["width_multiple"]
+    max_channels = yaml_config.get("max_channels", 1024)
+    nc = yaml_config["nc"]
+    rows = list(yaml_config["backbone"])
+    if not without_head:
+        rows += list(yaml_config.get("neck") or []) + list(yaml_config["head"])
+    layers, save = [], []
+    for i, (f, n, m, args) in enumerate(rows):
+        args, _, n_, c2, m_ = get_next_layer_from_cfg(gd, ch, gw, nc, m, n, f, args, max_channels)
+        m_.i, m_.f, m_.type = i, f, (m if isinstance(m, str) else m.__name__)
+        m_.np = sum(x.numel() for x in m_.parameters())
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+    if without_head:
+        i = len(layers)
+        for h_layer in list(yaml_config["neck"]) + list(yaml_config["head"]):
+            f = h_layer[0]
+            f = [f] if isinstance(f, int) else f
+            save.extend(x % i for x in f if x != -1 and x < len(layers))
+            i += 1
+    return nn.Sequential(*layers), sorted(set(save)), ch
+
+
+class Model(_NoEager):
+    """Sequential backbone runner; with `without_head=True` it is block 0 of a CerberusDet and yields the saved
+    outputs (reference yolo.py:113-231)."""
+
+    def __init__(self, cfg="v8x.yaml", ch=3, nc=None, without_head=False, _=None, verbose=False, **kwargs):
+        super().__init__()
+        if isinstance(cfg, dict):
+            self.yaml = cfg
+        else:
+            import yaml
+
+            self.yaml_file = Path(cfg).name
+            with open(cfg) as f:
+                self.yaml = yaml.safe_load(f)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if isinstance(nc, list) and self.yaml.get("nc", None) is not None:
+            self.yaml["nc"] = nc
+        elif nc and (self.yaml.get("nc") is None or nc != self.yaml["nc"]):
+            self.yaml["nc"] = nc
+        if not isinstance(self.yaml["nc"], list):
+            self.yaml["nc"] = [self.yaml["nc"]]
+        if not without_head:
+            raise NotImplementedError("cerberusdet_amd builds single-task models as a one-head CerberusDet (without_head=True)")
+        self.model, self.save, self.saved_ch = parse_model(deepcopy(self.yaml), ch=[ch], without_head=True, verbose=verbose)
+        self.without_head = True
+        self.inplace = self.yaml.get("inplace", True)
+
+    def fuse(self):
+        for m in self.model.modules():
+            if type(m) is Conv:
+                m.fuse_()
+        return self

@@ -218,12 +218,11 @@ def detect_decode(feats, nc, strides, out_dtype=torch.float32):
     N = feats[0].shape[0]
     ld = feats[0].shape[3]
     assert all(f.is_contiguous() and f.shape[3] == ld for f in feats)
-    assert ld == 64 + nc, "detect_decode expects unpadded maps; use the engine's decode for padded layouts"
     A = sum(f.shape[1] * f.shape[2] for f in feats)
     y = torch.empty((N, 4 + nc, A), dtype=out_dtype, device=feats[0].device)
     hw = (C.c_int32 * 6)(*[v for f in feats for v in (f.shape[1], f.shape[2])])
     st = (C.c_float * 3)(*[float(s) for s in strides])
-    L.check(lib.cdet_detect_decode(ptr(feats[0]), ptr(feats[1]), ptr(feats[2]), hw, st, N, nc, dt(feats[0].dtype), ptr(y), dt(out_dtype),
+    L.check(lib.cdet_detect_decode(ptr(feats[0]), ptr(feats[1]), ptr(feats[2]), hw, st, N, nc, ld, dt(feats[0].dtype), ptr(y), dt(out_dtype),
                                    stream()), "cdet_detect_decode")
     return y
 

@@ -1,0 +1,126 @@
+"""Box utilities and NMS with the reference's signatures (ai-forever/CerberusDet cerberusdet/utils/general.py:
+206-208 make_divisible, 122-127 check_img_size, 211-213 one_cycle, 272-288 xywh2xyxy, 313-357 scale/clip_boxes,
+360-481 non_max_suppression, 484-554 nms_between_tasks). NMS runs as ONE batched gfx950 launch sequence for the whole
+batch (csrc/nms.hip) with a single device->host sync for the per-image counts."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def check_img_size(img_size, s=32):
+    new_size = make_divisible(img_size, int(s))
+    return new_size
+
+
+def one_cycle(y1=0.0, y2=1.0, steps=100):
+    return lambda x: ((1 - math.cos(x * math.pi / steps)) / 2) * (y2 - y1) + y1
+
+
+def xywh2xyxy(x):
+    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
+    y[..., 0] = x[..., 0] - x[..., 2] / 2
+    y[..., 1] = x[..., 1] - x[..., 3] / 2
+    y[..., 2] = x[..., 0] + x[..., 2] / 2
+    y[..., 3] = x[..., 1] + x[..., 3] / 2
+    return y
+
+
+def clip_boxes(boxes, shape):
+    if isinstance(boxes, torch.Tensor):
+        boxes[..., 0].clamp_(0, shape[1])
+        boxes[..., 1].clamp_(0, shape[0])
+        boxes[..., 2].clamp_(0, shape[1])
+        boxes[..., 3].clamp_(0, shape[0])
+    else:
+        boxes[..., [0, 2]] = boxes[..., [0, 2]].clip(0, shape[1])
+        boxes[..., [1, 3]] = boxes[..., [1, 3]].clip(0, shape[0])
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain = ratio_pad[0][0]
+        pad = ratio_pad[1]
+    boxes[..., [0, 2]] -= pad[0]
+    boxes[..., [1, 3]] -= pad[1]
+    boxes[..., :4] /= gain
+    clip_boxes(boxes, img0_shape)
+    return boxes
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),
+                        max_det=300, nm=0) -> List[torch.Tensor]:
+    """Same contract as the reference: prediction [bs, 4+nc, A] (or the eval tuple (y, feats)) -> list of [k,6] fp32
+    tensors (x1,y1,x2,y2,conf,cls) on the prediction's device. Not reproduced on purpose: the wall-clock `time_limit`
+    bail-out (general.py:417,477-479) and a-priori `labels` / mask channels (`nm`), which the hot path never uses."""
+    from .. import ops
+
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    if nm != 0 or (labels and any(len(lb) for lb in labels)):
+        raise NotImplementedError("cerberusdet_amd NMS: nm and a-priori labels are not part of the detection hot path")
+    if not prediction.is_cuda:
+        raise RuntimeError("cerberusdet_amd.non_max_suppression needs a tensor on the MI355X (no CPU path)")
+    rows, cnt = ops.nms_batched(prediction.contiguous(), conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
+    counts = cnt.tolist()  # the only host sync of the call
+    return [rows[i, :k] for i, k in enumerate(counts)]
+
+
+def box_iou(box1, box2, eps=1e-7):
+    (a1, a2), (b1, b2) = box1.unsqueeze(1).chunk(2, 2), box2.unsqueeze(0).chunk(2, 2)
+    inter = (torch.min(a2, b2) - torch.max(a1, b1)).clamp(0).prod(2)
+    return inter / ((a2 - a1).prod(2) + (b2 - b1).prod(2) - inter + eps)
+
+
+def nms_between_tasks(bboxes: torch.Tensor, categories_map_per_task: Dict[str, Dict[int, int]], iou_thres: float) -> torch.Tensor:
+    """Cross-task suppression on the (few hundred) rows that survive per-task NMS (reference general.py:484-554): rows are
+    regrouped by task, IoU is evaluated between boxes of DIFFERENT tasks only (upper triangle), then a greedy row scan
+    deletes, for each row with hits, everything but the best-scoring box of {row} U hits. Vectorised on the host."""
+    b = bboxes.detach().cpu()
+    n = b.shape[0]
+    if n == 0:
+        return bboxes
+    cls = b[:, 5].to(torch.int64)
+    tasks = list(categories_map_per_task.keys())
+    task_of = torch.full((n,), -1, dtype=torch.int64)
+    for ti, t in enumerate(tasks):
+        ids = torch.tensor(sorted(categories_map_per_task[t].values()), dtype=torch.int64)
+        task_of[torch.isin(cls, ids)] = ti
+    order = torch.cat([torch.nonzero(task_of == ti).flatten() for ti in range(len(tasks))])
+    b = b[order]
+    tk = task_of[order]
+    iou = torch.zeros((n, n))
+    m = b.shape[0]
+    if m:
+        full = box_iou(b[:, :4], b[:, :4])
+        upper = tk.view(-1, 1) < tk.view(1, -1)
+        iou[:m, :m] = torch.where(upper, full, torch.zeros_like(full))
+    if not torch.any(iou > iou_thres):
+        return b.to(bboxes.device)
+    hit = (iou > iou_thres).numpy()
+    scores = b[:, 4].numpy()
+    deleted = np.zeros(m, bool)
+    for r in range(m):
+        if deleted[r]:
+            continue
+        idxs = np.nonzero(hit[r])[0]
+        if len(idxs) == 0:
+            continue
+        idxs = np.concatenate((idxs, [r]))
+        best = int(np.argmax(scores[idxs]))
+        deleted[np.delete(idxs, best)] = True
+    if deleted.all():
+        return b.to(bboxes.device)
+    return b[torch.from_numpy(~deleted)].to(bboxes.device)

@@ -145,17 +145,22 @@ int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, int32_t H, in
 /* backward through the three chained pools: dbuf[:, coff:coff+C] += routed gradients of slices 1..3 */
 int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C,
                        int32_t dtype, void* stream);
+/* out[c] (=|+=) sum_r src[r, coff + c], c < C_out <= C: bias gradient of the head's biased 1x1 projections (yolo.py:82-84).
+ * `part`: fp32 scratch of cdet_bn_bwd_blocks(M) * C elements. */
+int cdet_colsum(const void* src, int32_t ld, int32_t coff, int64_t M, int32_t C, int32_t C_out, int32_t dtype, float* out,
+                int32_t accumulate, float* part, void* stream);
 /* y (=|+=) a + b elementwise on [M,C] slices (Bottleneck residual backward fan-in, common.py:117) */
 int cdet_add_channels(const void* a, int32_t a_ld, int32_t a_coff, const void* b, int32_t b_ld, int32_t b_coff,
                       void* y, int32_t y_ld, int32_t y_coff, int64_t M, int32_t C, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Detect head eval branch (models/yolo.py:93-100 + DFL 57-59 + utils/tal.py:181-205)
- * feats: 3 NHWC maps with channels [64 box-bin logits | nc class logits], fp32/bf16/f16.
+ * feats: 3 NHWC maps with channels [64 box-bin logits | nc class logits | layout padding], pixel stride f_ld, fp32/bf16/f16.
+ * hw6 / strides3 are HOST arrays.
  * y: [N, 4+nc, A] (reference layout, A = sum H_i*W_i), out_dtype.
  * ---------------------------------------------------------------------------------------------- */
 int cdet_detect_decode(const void* f0, const void* f1, const void* f2, const int32_t* hw6, const float* strides3,
-                       int32_t N, int32_t nc, int32_t dtype, void* y, int32_t out_dtype, void* stream);
+                       int32_t N, int32_t nc, int32_t f_ld, int32_t dtype, void* y, int32_t out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss: TAL assignment + BCE + CIoU + DFL, forward AND gradient w.r.t. the raw head maps in one pass

@@ -1,0 +1,152 @@
+"""Model-level parity on the MI355X: the compiled gfx950 launch list vs the REAL reference's golden outputs
+(tests/golden/model_tiny*.npz) and vs the CPU oracle run with the same bf16 storage roundings.
+
+Tolerances: activations and packed weights are stored in bf16 (8 mantissa bits, 2^-8 = 3.9e-3 relative per rounding) while
+the golden vectors are fp32, so the comparison against the fp32 reference is statistical (relative L2 error of a tensor);
+the comparison against the oracle that emulates the same storage roundings is tight.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import graph as og
+from util import load_golden, oracle_model_from_meta
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))
+
+
+def _build(meta):
+    from cerberusdet_amd.models import CerberusDet
+
+    m = CerberusDet(meta["tasks"], meta["nc"], cfg=copy.deepcopy(meta["cfg"]), verbose=False)
+    m.sequential_split(meta["cfg"]["cerber"], "cpu")
+    sd = m.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["state_shapes"]
+    m.load_state_dict({k: torch.from_numpy(synth.det_tensor(meta["seed"], k, v.shape)) for k, v in sd.items()})
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_eval_forward_vs_reference_golden(name):
+    arrays, meta = load_golden(name)
+    m = _build(meta).eval()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    with torch.no_grad():
+        out = m(x)
+    torch.cuda.synchronize()
+    for t in meta["tasks"]:
+        y, feats = out[t]
+        assert y.shape == arrays[f"eval/{t}/y"].shape
+        for i, f in enumerate(feats):
+            assert _rel_l2(f.float().cpu().numpy(), arrays[f"eval/{t}/feat{i}"]) < 2e-2, (t, i)
+        assert _rel_l2(y.cpu().numpy()[:, :4], arrays[f"eval/{t}/y"][:, :4]) < 1e-2
+        assert np.abs(y.cpu().numpy()[:, 4:] - arrays[f"eval/{t}/y"][:, 4:]).max() < 2e-2
+    # single-task call returns that task's tuple, like the reference
+    with torch.no_grad():
+        y0, _ = m(x, meta["tasks"][0])
+    assert torch.equal(y0, out[meta["tasks"][0]][0])
+    # fused model gives the same result
+    mf = copy.deepcopy(m).fuse().eval()
+    with torch.no_grad():
+        outf = mf(x)
+    for t in meta["tasks"]:
+        assert _rel_l2(outf[t][0].cpu().numpy(), arrays[f"fused/{t}/y"]) < 1e-2
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_train_forward_backward_all_gradients_vs_oracle(name):
+    """Wiring test of the compiled train-mode forward + backward launch lists: EVERY parameter gradient, the BN running
+    statistics and the head maps against the fp32 CPU oracle (autograd) on a well-conditioned input (bs 4 @128: BatchNorm
+    sees >= 64 samples per channel). Random-weight nets are chaotic: emulating bf16 storage inside the fp32 CPU oracle
+    (weights + activations rounded at the same points) moves the maps by 5/8/11 % and the worst gradient to cos 0.80
+    (median 0.978) -- measured, see DESIGN.md "numerics". A wiring / accumulation error instead shows up as O(1) error, a
+    wrong direction or a wrong norm, so gradients are checked by cosine similarity (worst, median) and norm ratio."""
+    _, meta = load_golden(name)
+    m = _build(meta).train()
+    g, w = oracle_model_from_meta(meta)
+    bs, imgsz = 4, 128
+    x_cpu = torch.from_numpy(synth.det_image(77, bs, imgsz))
+    x = x_cpu.to(DEV)
+    for t in meta["tasks"]:
+        sd0 = copy.deepcopy(m.state_dict())
+        for p in m.parameters():
+            p.grad = None
+        feats = m(x, t)
+        cot = [torch.from_numpy(synth.det_array(77, f"cot/{t}/{i}", f.shape)).to(DEV) for i, f in enumerate(feats)]
+        sum((f * c).sum() for f, c in zip(feats, cot)).backward()
+        torch.cuda.synchronize()
+        wt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in w.items()}
+        upd = {}
+        of = og.forward(g, wt, x_cpu, t, training=True, bn_updates=upd)
+        sum((f * c.cpu()).sum() for f, c in zip(of, cot)).backward()
+        worst = []
+        for i, f in enumerate(feats):
+            e = _rel_l2(f.detach().cpu().numpy(), of[i].detach().numpy())
+            print(f"[{name}/{t}] feat{i}: rel-L2 vs fp32 oracle {e:.4f}")
+            assert e < 0.16, (t, i, e)
+        named = dict(m.named_parameters())
+        n_checked = 0
+        for k, v in wt.items():
+            if not (isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None):
+                continue
+            got = named[k].grad
+            assert got is not None, k
+            got = got.cpu().numpy()
+            c, ratio = _cos(got, v.grad.numpy()), np.linalg.norm(got) / (np.linalg.norm(v.grad.numpy()) + 1e-30)
+            worst.append((c, ratio, k))
+            n_checked += 1
+        worst.sort()
+        for c, ratio, k in worst[:6]:
+            print(f"[{name}/{t}] worst grads: cos {c:.4f} norm-ratio {ratio:.3f} {k}")
+        assert n_checked == len(meta["grad_keys_with_grad"][t])
+        cs = [c for c, _, _ in worst]
+        print(f"[{name}/{t}] gradient cosine: worst {cs[0]:.4f} median {cs[len(cs) // 2]:.4f} ({n_checked} tensors)")
+        assert cs[0] > 0.6 and cs[len(cs) // 2] > 0.95 and sum(c < 0.9 for c in cs) <= 0.1 * len(cs), worst[:8]
+        assert all(0.6 < r < 1.6 for _, r, _ in worst), [w_ for w_ in worst if not 0.6 < w_[1] < 1.6][:5]
+        # parameters off this task's path must not receive gradients
+        for k, p in named.items():
+            if k not in meta["grad_keys_with_grad"][t] and p.grad is not None:
+                assert float(p.grad.abs().sum()) == 0.0, k
+        sd1 = m.state_dict()
+        for k, v in upd.items():
+            assert _rel_l2(sd1[k].cpu().numpy(), v.numpy()) < 2e-2, k
+        assert int(sd1["blocks.0.model.0.bn.num_batches_tracked"]) == int(sd0["blocks.0.model.0.bn.num_batches_tracked"]) + 1
+        m.load_state_dict(sd0)
+
+
+@pytest.mark.parametrize("name", ["model_tiny2"])
+def test_train_golden_noise_regime(name):
+    """The reference's own train-mode golden (bs 2 @64: BatchNorm over 8..128 samples, random weights) is chaotic under ANY
+    16-bit storage: the fp32 oracle with merely bf16-ROUNDED WEIGHTS already deviates from it by 5-10 % on the head maps
+    (tests/test_oracle_golden.py::test_train_fixture_sensitivity). The HIP path must land in that same noise band."""
+    arrays, meta = load_golden(name)
+    m = _build(meta).train()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    for t in meta["tasks"]:
+        sd0 = copy.deepcopy(m.state_dict())
+        with torch.no_grad():
+            feats = m(x, t)
+        torch.cuda.synchronize()
+        for i, f in enumerate(feats):
+            e = _rel_l2(f.cpu().numpy(), arrays[f"train/{t}/feat{i}"])
+            print(f"[{name}/{t}] feat{i} vs fp32 reference golden: rel-L2 {e:.4f}")
+            assert e < 0.25, (t, i, e)
+        m.load_state_dict(sd0)

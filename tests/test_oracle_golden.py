@@ -248,3 +248,16 @@ def test_trainer_two_iterations():
         for k in meta["watch"]:
             assert rel_err(w[k].numpy(), arrays[f"it{it}/w/{k}"]) < 1e-4, (it, k)
             assert rel_err(ema[k].numpy(), arrays[f"it{it}/ema/{k}"]) < 1e-4, (it, k)
+
+
+def test_train_fixture_sensitivity():
+    """Documents why train-mode parity of 16-bit paths against model_tiny2's fp32 golden is statistical: rounding ONLY THE
+    WEIGHTS to bf16 in the fp32 oracle moves the head maps by several percent (BatchNorm over 8..128 samples)."""
+    arrays, meta = load_golden("model_tiny2")
+    g, w = oracle_model_from_meta(meta)
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"]))
+    wq = {k: (v.to(torch.bfloat16).float() if k.endswith(("conv.weight", ".2.weight")) and "dfl" not in k else v) for k, v in w.items()}
+    with torch.no_grad():
+        of = og.forward(g, wq, x, "voc", training=True)
+    errs = [np.linalg.norm(of[i].numpy() - arrays[f"train/voc/feat{i}"]) / np.linalg.norm(arrays[f"train/voc/feat{i}"]) for i in range(3)]
+    assert 0.02 < errs[0] < 0.2 and 0.02 < errs[2] < 0.3, errs
