@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the YOLOv8x 2-task TRAINING step @640 (BASELINE.json configs[1]) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one iteration of the reference's trainer (trainers/averaging.py:132-223): for each of the 2 tasks a batch of 32
+synthetic 640x640 images -> forward -> TAL/CIoU/DFL/BCE loss -> backward (gradients accumulate) ; then gradient all-reduce
+(N > 1), global-norm clip, per-block division, SGD-Nesterov, EMA. bf16 storage, fp32 accumulation and master weights.
+Inputs are resident in HBM before the timed region (synthetic data). Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TASKS = ["voc", "objects365_animals"]
+NC = [20, 19]
+HYP = dict(box=[7.5, 7.5], cls=[0.5, 0.5], dfl=[1.5, 1.5], lr0=0.00309, lrf=0.0956, momentum=0.952, weight_decay=0.00037,
+           warmup_epochs=2.04, warmup_momentum=0.898, warmup_bias_lr=0.0502)
+GFLOP_FWD_PER_IMG_TASK = 257.48  # conv FLOPs of one task's path @640 (README.md:237)
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
+
+
+def synth_batch(rank, t, i, bs, nc, imgsz, device, boxes_per_img=8):
+    """uint8 images from seed 1000+97r+13t+i; 8 boxes/img, cls~U, cxcy~U(.2,.8), wh~U(.05,.35)."""
+    g = torch.Generator().manual_seed(1000 + 97 * rank + 13 * t + i)
+    img = torch.randint(0, 256, (bs, 3, imgsz, imgsz), dtype=torch.uint8, generator=g)
+    n = bs * boxes_per_img
+    cls = torch.randint(0, nc, (n, 1), generator=g).float()
+    cxy = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(n, 2, generator=g) * 0.3 + 0.05
+    bi = torch.arange(bs).repeat_interleave(boxes_per_img).float()
+    return dict(img=img.to(device), cls=cls.to(device), bboxes=torch.cat((cxy, wh), 1).to(device), batch_idx=bi.to(device), prob=torch.ones(n, 1, device=device))
+
+
+def build_model(cfg_name, device, seed=0):
+    import yaml
+
+    from cerberusdet_amd.models import CerberusDet
+
+    cfg = yaml.safe_load(open(ROOT / "cerberusdet_amd" / "models" / "cfg" / cfg_name))
+    torch.manual_seed(seed)
+    model = CerberusDet(TASKS, NC, cfg=cfg, verbose=False)
+    model.sequential_split(cfg["cerber"], "cpu")
+    model.hyp = HYP
+    return model.to(device).train(), cfg
+
+
+def _cpu_baseline_worker(cfg, q):
+    """Child process (never touches the GPU): one task pass fwd+loss+bwd of the CPU oracle at bs 1 @640."""
+    from oracle import graph as og
+    from oracle import loss as ol
+
+    n_thr = max(1, min(len(os.sched_getaffinity(0)), 64))
+    torch.set_num_threads(n_thr)
+    g = og.build_graph(cfg, TASKS, NC)
+    og.apply_cerber_schedule(g, cfg["cerber"])
+    w = og.init_weights(g, seed=0)
+    t0 = time.perf_counter()
+    n_img = 0
+    for ti, t in enumerate(TASKS[:1]):
+        wt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in w.items()}
+        b = synth_batch(0, ti, 0, 1, NC[ti], 640, "cpu")
+        x = b["img"].float() / 255
+        feats = og.forward(g, wt, x, t, training=True)
+        scalar, _ = ol.detection_loss(feats, b, NC[ti], dict(box=7.5, cls=0.5, dfl=1.5))
+        scalar.backward()
+        n_img += 1
+    dt = time.perf_counter() - t0
+    q.put(dict(value=round(n_img / dt, 4), unit="images/sec", cores=n_thr, kind="port",
+               sample=f"one task pass (fwd + loss + bwd, no optimizer) of the YOLOv8x 2-task model @640, batch 1, CPU oracle (torch fp32), {dt:.1f} s"))
+
+
+def cpu_baseline(cfg, timeout_s=300):
+    """The reference's device='cpu' path cannot travel; time the parity-pinned CPU oracle (oracle/) on the host cores on a
+    bounded sample of the same workload, in a child process with a hard time limit."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_cpu_baseline_worker, args=(cfg, q))
+    p.start()
+    try:
+        res = q.get(timeout=timeout_s)
+    except Exception:
+        res = dict(value=None, unit="images/sec", cores=len(os.sched_getaffinity(0)), kind="port",
+                   sample=f"CPU oracle did not finish one bs-1 task pass within {timeout_s} s")
+    p.join(5)
+    if p.is_alive():
+        p.kill()
+    return res
+
+
+def kernel_breakdown(trainer, batches, n_max):
+    """Replay one iteration with a HIP event pair around every C-ABI call (on the launch stream = torch's current stream) and
+    attribute time + algorithmic conv FLOPs per entry point."""
+    import ctypes as C
+
+    from cerberusdet_amd import _lib as L
+
+    lib = L.load()
+    rec = []
+
+    def instrument(calls):
+        out = []
+        for fn, args in calls:
+            def wrapped(*a, _fn=fn, _args=args):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                rec.append((_fn.__name__ if hasattr(_fn, "__name__") else str(_fn), _args, e0, e1))
+                return rc
+            wrapped.__name__ = getattr(fn, "__name__", "fn")
+            out.append((wrapped, args))
+        return out
+
+    plans = [trainer.model.get_plan(t, batches[t]["img"].shape, batches[t]["img"].dtype, training=True) for t in TASKS]
+    saved = [(p.fwd, p.bwd_groups) for p in plans]
+    for p in plans:
+        p.fwd = instrument(p.fwd)
+        p.bwd_groups = [(i, instrument(c)) for i, c in p.bwd_groups]
+    trainer.train_step(batches, n_max=n_max)
+    torch.cuda.synchronize()
+    for p, (f, b) in zip(plans, saved):
+        p.fwd, p.bwd_groups = f, b
+    agg = {}
+    for name, args, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        flops = 0.0
+        key = name
+        if name in ("cdet_conv2d", "cdet_conv2d_wgrad"):
+            d = args[0]._obj  # ctypes.byref(desc) keeps the descriptor
+            if name == "cdet_conv2d":
+                M = d.N * d.Hd * d.Wd
+                if d.mode == L.CONV_DGRAD:
+                    key = "cdet_conv2d[dgrad]"
+                    # algorithmic FLOPs of dgrad = those of the forward conv it differentiates
+                    flops = 2.0 * d.N * d.Hs * d.Ws * d.Cs * d.Cd * d.kh * d.kw
+                else:
+                    key = "cdet_conv2d[fwd]"
+                    flops = 2.0 * M * d.Cd * d.Cs * d.kh * d.kw
+            else:
+                flops = 2.0 * d.N * d.Hd * d.Wd * d.Cd * d.Cs * d.kh * d.kw
+        a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0))
+        a["ms"] += ms
+        a["n"] += 1
+        a["flops"] += flops
+    return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per task per GPU")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--cfg", default="v8x_2task.yaml")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs the launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from cerberusdet_amd.trainers import Averaging
+
+    model, cfg = build_model(args.cfg, device)
+    if world > 1:  # every rank starts from rank 0's weights (what DDP's constructor broadcast does in the reference, train.py:184)
+        for t in list(model.state_dict().values()):
+            dist.broadcast(t, src=0)
+    trainer = Averaging(device, model, HYP, TASKS, epochs=100, nb=1000, rank=rank if world > 1 else -1, world_size=world)
+    n_iter = args.warmup + args.steps
+    n_distinct = min(n_iter, 4)  # a few distinct synthetic batches, resident in HBM, cycled
+    data = [{t: synth_batch(rank, ti, i, args.batch, NC[ti], args.imgsz, device) for ti, t in enumerate(TASKS)} for i in range(n_distinct)]
+    n_max = 8
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    items = None
+    for i in range(args.warmup):
+        items = trainer.train_step(data[i % n_distinct], n_max=n_max)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss_items = {t: [round(float(v), 5) for v in items[t].tolist()] for t in TASKS}
+    finite = all(np.isfinite(v).all() for v in loss_items.values())
+
+    if rank == 0:
+        imgs_per_step = args.batch * len(TASKS) * world
+        value = imgs_per_step * args.steps / dt
+        ms_per_step = dt / args.steps * 1e3
+        step_tflop = 3 * GFLOP_FWD_PER_IMG_TASK * args.batch * len(TASKS) / 1e3 * (args.imgsz / 640) ** 2  # per GPU, fwd+bwd = 3x fwd
+        out = {
+            "metric": "images/sec train @640 YOLOv8x 2-task", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"YOLOv8x 2-task (VOC nc20 + O365-animals nc19) training iteration, batch {args.batch}/task/GPU @{args.imgsz}, "
+                                   "fwd+loss+bwd per task, clip+SGD-nesterov+EMA, bf16 storage / fp32 accumulate",
+                       "cfg": args.cfg, "global_batch": imgs_per_step, "parallelism": f"dp{world}"},
+            "step_tflop_per_gpu": round(step_tflop, 2), "achieved_tflops_per_gpu": round(step_tflop / (ms_per_step / 1e3), 1),
+            "loss_items": loss_items, "loss_finite": bool(finite),
+        }
+        if not args.no_breakdown:
+            agg = kernel_breakdown(trainer, data[0], n_max)
+            tot = sum(a["ms"] for a in agg.values())
+            out["kernel_ms"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+            out["kernel_ms_total"] = round(tot, 3)
+            dom = max((k for k in agg if agg[k]["flops"] > 0), key=lambda k: agg[k]["ms"])
+            a = agg[dom]
+            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": a["n"],
+                               "avg_launch_ms": round(a["ms"] / a["n"], 4), "algorithmic_gflop_per_launch": round(a["flops"] / a["n"] / 1e9, 3)}
+            out["mfma_kernels"] = {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "ms": round(v["ms"], 2), "launches": v["n"]}
+                                   for k, v in agg.items() if v["flops"] > 0}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

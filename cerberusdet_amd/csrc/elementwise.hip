@@ -57,25 +57,47 @@ __device__ __forceinline__ ColMap col_map(int CV) {
 // ------------------------------------------------------------------------------------------------
 // BN finalize: partial sums [nblk][2][C] -> mean / invstd (+ running stats)
 // ------------------------------------------------------------------------------------------------
+// 16 channels x 16 partial-row groups per workgroup: the [nblk][2][C] partials are read in 64-byte runs, 16 groups stride over
+// the blocks with 4 independent accumulators each (the first version walked nblk serially with 4 groups: 19 ms per step).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int C, double inv_count,
                                                           double unbias, float eps, float momentum, float* running_mean,
                                                           float* running_var, float* mean, float* invstd) {
-    __shared__ double sh[2][4][64];
-    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double sh[2][16][16];
+    const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int b = g; b < nblk; b += 4) {
-            s += (double)stats[((int64_t)b * 2 + 0) * C + c];
-            q += (double)stats[((int64_t)b * 2 + 1) * C + c];
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+        int b = g;
+        for (; b + 16 < nblk; b += 32) {
+            s0 += stats[((int64_t)b * 2 + 0) * C + c];
+            q0 += stats[((int64_t)b * 2 + 1) * C + c];
+            s1 += stats[((int64_t)(b + 16) * 2 + 0) * C + c];
+            q1 += stats[((int64_t)(b + 16) * 2 + 1) * C + c];
+            if ((b & 1023) == g) {  // spill the fp32 runs into the double accumulators every 32 iterations
+                s += (double)s0 + (double)s1;
+                q += (double)q0 + (double)q1;
+                s0 = s1 = q0 = q1 = 0.f;
+            }
         }
+        for (; b < nblk; b += 16) {
+            s0 += stats[((int64_t)b * 2 + 0) * C + c];
+            q0 += stats[((int64_t)b * 2 + 1) * C + c];
+        }
+        s += (double)s0 + (double)s1;
+        q += (double)q0 + (double)q1;
     }
     sh[0][g][cx] = s;
     sh[1][g][cx] = q;
     __syncthreads();
     if (g == 0 && c < C) {
-        s = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-        q = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+        s = 0.0;
+        q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s += sh[0][k][cx];
+            q += sh[1][k][cx];
+        }
         const double m = s * inv_count;
         double var = q * inv_count - m * m;
         if (var < 0.0) var = 0.0;
@@ -455,7 +477,7 @@ extern "C" int cdet_bn_finalize(const float* stats, int32_t nblk, int32_t C, int
                                 float* running_mean, float* running_var, float* mean, float* invstd, void* stream) {
     CDET_CHECK_ARG(stats && mean && invstd && nblk > 0 && C > 0 && count > 0, "cdet_bn_finalize: bad arguments");
     const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, stats, nblk, C, 1.0 / (double)count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(div_up(C, 16)), dim3(256), 0, (hipStream_t)stream, stats, nblk, C, 1.0 / (double)count,
                        unbias, eps, momentum, running_mean, running_var, mean, invstd);
     CDET_LAUNCH_CHECK();
     return 0;

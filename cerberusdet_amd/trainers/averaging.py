@@ -1,0 +1,224 @@
+"""Multi-task "gradient averaging" trainer with the reference's step semantics
+(ai-forever/CerberusDet cerberusdet/trainers/averaging.py:97-223, base_trainer.py:100-112, utils/torch_utils.py:282-316):
+
+  per iteration: for every task -> next batch -> forward -> loss -> backward (gradients ACCUMULATE across tasks);
+  then: clip the global gradient norm over ALL parameters to 10, divide each block's gradients by the number of tasks it
+  serves, SGD-Nesterov step (3 parameter groups), zero the gradients, EMA update.
+
+MI355X-native differences (same algebra):
+  * forward/backward are the compiled launch lists of engine.Plan, the criterion is the fused HIP loss;
+  * clip + divide + SGD + zero + EMA are TWO kernel launches over a slot table (csrc/optim.hip);
+  * data parallelism is explicit: every rank sums its local gradients, `GradReducer` all-reduces (SUM) one flat fp32 bucket
+    per block over RCCL as soon as the LAST task that touches the block has finished its backward, overlapped with the rest
+    of the backward / the next task's forward. The reference gets the same sum through DDP(avg) * world_size
+    (averaging.py:162-163) but reduces every shared parameter once per task pass and all 105 M registered parameters
+    (find_unused_parameters) instead of only those on the executed path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from copy import deepcopy
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import _lib as L
+from ..utils.general import one_cycle
+from ..utils.loss import pad_targets
+from ..utils.torch_utils import ema_decay, get_hyperparameter
+
+
+def get_param_groups(model):
+    """g0 = weights with decay, g1 = BatchNorm weights, g2 = biases (reference averaging.py:249-262)."""
+    g0, g1, g2 = [], [], []
+    for _, v in model.named_modules():
+        if hasattr(v, "bias") and isinstance(v.bias, nn.Parameter):
+            g2.append(v.bias)
+        if isinstance(v, nn.BatchNorm2d):
+            g1.append(v.weight)
+        elif hasattr(v, "weight") and isinstance(v.weight, nn.Parameter):
+            g0.append(v.weight)
+    return g0, g1, g2
+
+
+class ModelEMA:
+    """EMA of every floating-point state-dict entry (reference torch_utils.py:282-316). The lerp itself runs inside the fused
+    optimizer kernel; this class owns the shadow model and the update counter."""
+
+    def __init__(self, model, decay=0.9999, updates=0):
+        self.ema = deepcopy(model).eval()
+        self.updates = updates
+        self.decay_base = decay
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+
+    def decay(self, x):
+        return ema_decay(x, self.decay_base)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce keyed on the block DAG. One flat fp32 bucket per block; a bucket is reduced (SUM, async)
+    when the last task of the iteration that serves the block has produced its gradients. Device-agnostic (works with gloo
+    on CPU tensors for tests, with RCCL on the GPU)."""
+
+    def __init__(self, buckets: Dict[int, torch.Tensor], serving: Dict[int, Sequence[str]], task_order: Sequence[str], group=None):
+        self.buckets, self.serving, self.task_order, self.group = buckets, serving, list(task_order), group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.handles: List = []
+        self.reduced_bytes = 0
+
+    def last_task(self, block_idx: int, active_tasks: Optional[Sequence[str]] = None) -> Optional[str]:
+        tasks = [t for t in (active_tasks or self.task_order) if t in self.serving.get(block_idx, ())]
+        return tasks[-1] if tasks else None
+
+    def on_block_backward(self, block_idx: int, task: str, active_tasks: Optional[Sequence[str]] = None):
+        if not self.enabled or block_idx not in self.buckets:
+            return
+        if self.last_task(block_idx, active_tasks) != task:
+            return  # a later task of this iteration still adds to the bucket: reduce once, after local summation
+        b = self.buckets[block_idx]
+        self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.reduced_bytes += b.numel() * b.element_size()
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+class Averaging:
+    def __init__(self, device, model, hyp: dict, task_ids: Sequence[str], epochs: int = 100, nb: int = 1000, loss_weights=None,
+                 linear_lr=False, use_ema=True, rank=-1, world_size=1):
+        self.device, self.model, self.hyp, self.task_ids = device, model, hyp, list(task_ids)
+        self.rank, self.world_size = rank, world_size
+        self.epochs, self.nb = epochs, nb
+        self.nw = max(round(get_hyperparameter(hyp, "warmup_epochs") * nb), 1000)  # averaging.py:58
+        self.lr0, self.lrf = get_hyperparameter(hyp, "lr0"), get_hyperparameter(hyp, "lrf")
+        self.momentum, self.weight_decay = get_hyperparameter(hyp, "momentum"), get_hyperparameter(hyp, "weight_decay")
+        self.lf = (lambda x: (1 - x / (epochs - 1)) * (1.0 - self.lrf) + self.lrf) if linear_lr else one_cycle(1, self.lrf, epochs)
+        self.loss_weights = dict(zip(self.task_ids, [1.0] * len(self.task_ids))) if loss_weights is None else dict(loss_weights)
+        self.gains = {t: dict(box=get_hyperparameter(hyp, "box", i, t), cls=get_hyperparameter(hyp, "cls", i, t),
+                              dfl=get_hyperparameter(hyp, "dfl", i, t)) for i, t in enumerate(self.task_ids)}
+        self.ema = ModelEMA(model) if (use_ema and rank in (-1, 0)) else None
+        self.epoch = 0
+        self.steps = 0
+        self.lib = L.load()
+        # ---- slot table: one slot per trainable parameter (+ EMA-only slots for BN running statistics)
+        g0, g1, g2 = get_param_groups(model)
+        group_of = {id(p): 0 for p in g0}
+        group_of.update({id(p): 1 for p in g1})
+        group_of.update({id(p): 2 for p in g2})
+        self.serving = {c.index: list(c.serving_tasks.keys()) for c in model.controllers}
+        names = dict(model.named_parameters())
+        ema_sd = self.ema.ema.state_dict() if self.ema else {}
+        self.slots_meta = []
+        model._plans = {}  # plans pre-bind gradient pointers: compile them after the buckets below exist
+        buckets: Dict[int, torch.Tensor] = {}
+        for bi, block in enumerate(model.blocks):
+            ps = [p for p in block.parameters() if p.requires_grad]
+            if not ps:
+                continue
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=device)
+            buckets[bi] = flat
+            off = 0
+            for p in ps:
+                g = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                model._pgrad[id(p)] = g
+                p.grad = g
+        for k, p in names.items():
+            if not p.requires_grad:
+                continue
+            bi = int(k.split(".")[1])
+            self.slots_meta.append(dict(p=p, g=model._pgrad[id(p)], mom=torch.zeros_like(p), ema=ema_sd.get(k), group=group_of[id(p)],
+                                        div=max(len(self.serving[bi]), 1), key=k))
+        if self.ema:
+            msd = dict(model.named_buffers())
+            for k, v in msd.items():
+                if v.dtype.is_floating_point and k in ema_sd:
+                    self.slots_meta.append(dict(p=v, g=None, mom=None, ema=ema_sd[k], group=-1, div=1, key=k))
+        self.n_slots = len(self.slots_meta)
+        self._slots_host = (L.ParamSlot * self.n_slots)()
+        self._slots_dev = torch.empty(C.sizeof(self._slots_host), dtype=torch.uint8, device=device)
+        self._norm_buf = torch.zeros(1 + 32 * self.n_slots, dtype=torch.float32, device=device)
+        self._slot_key = None
+        self.reducer = GradReducer(buckets, self.serving, self.task_ids)
+        self.group_sizes = [len(g2), len(g0), len(g1)]  # optimizer.param_groups order of the reference: bias, decay, bn
+
+    # ---------------------------------------------------------------------------------------------------- schedule
+    def lrs(self, ni: int, epoch: int):
+        """Per-group learning rates [g0, g1, g2] and momentum incl. warm-up (reference base_trainer.py:100-112, with its
+        quirk: the optimizer's group index 2 -- the BN-weight group -- is the one treated as "bias")."""
+        base = self.lr0 * self.lf(epoch)
+        if ni <= self.nw:
+            xi = [0, self.nw]
+            wb = get_hyperparameter(self.hyp, "warmup_bias_lr")
+            by_opt_index = [float(np.interp(ni, xi, [wb if j == 2 else 0.0, base])) for j in range(3)]
+            mom = float(np.interp(ni, xi, [get_hyperparameter(self.hyp, "warmup_momentum"), self.momentum]))
+            return [by_opt_index[1], by_opt_index[2], by_opt_index[0]], mom  # opt index 0 = g2, 1 = g0, 2 = g1
+        return [base, base, base], self.momentum
+
+    # ---------------------------------------------------------------------------------------------------- step pieces
+    def forward_backward(self, task: str, batch: dict, n_max: Optional[int] = None, active_tasks=None):
+        """One task pass: fused forward + criterion + backward; gradients accumulate. Returns loss items (device tensor[5])."""
+        img = batch["img"]
+        plan = self.model.get_plan(task, img.shape, img.dtype, training=True)
+        if not plan.hooks:
+            for idx in {i for i, _ in plan.bwd_groups}:
+                plan.hooks[idx] = (lambda i, t=task: self.reducer.on_block_backward(i, t, self._active))
+        self._active = active_tasks
+        plan.run_forward(img)
+        head = self.model.get_head(task)
+        gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max)
+        loss5 = plan.loss(task, gt, self.gains[task], grad_scale=float(self.loss_weights[task]))
+        plan.run_backward()
+        return loss5
+
+    def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None):
+        self.reducer.wait()
+        first = self.steps == 0
+        key = (tuple(lrs), first, tuple(sorted(n_serving.items())) if n_serving else None)
+        if key != self._slot_key:
+            for i, m in enumerate(self.slots_meta):
+                s = self._slots_host[i]
+                s.p, s.n = m["p"].data_ptr(), m["p"].numel()
+                s.g = m["g"].data_ptr() if m["g"] is not None else None
+                s.mom = m["mom"].data_ptr() if m["mom"] is not None else None
+                s.ema = m["ema"].data_ptr() if m["ema"] is not None else None
+                if m["group"] >= 0:
+                    s.lr = lrs[m["group"]]
+                    s.weight_decay = self.weight_decay if m["group"] == 0 else 0.0
+                    div = m["div"] if n_serving is None else max(n_serving.get(int(m["key"].split(".")[1]), 1), 1)
+                    s.inv_div = 1.0 / div
+                s.first_step = int(first)
+            self._slots_dev.copy_(torch.frombuffer(bytearray(bytes(self._slots_host)), dtype=torch.uint8), non_blocking=False)
+            self._slot_key = key
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(self.lib.cdet_grad_sqnorm(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), st), "cdet_grad_sqnorm")
+        d = 0.0
+        if self.ema:
+            self.ema.updates += 1
+            d = self.ema.decay(self.ema.updates)
+        L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), 10.0, float(momentum), float(d), st),
+                "cdet_sgd_ema_step")
+        self.model.mark_weights_changed()
+        self.steps += 1
+
+    def train_step(self, batches: Dict[str, dict], ni: Optional[int] = None, n_max: Optional[int] = None):
+        """batches: {task: {"img": [N,3,H,W] uint8|float on device, "batch_idx", "cls", "bboxes"}}; tasks missing from the dict
+        are skipped this iteration (the reference's --skip-batches). Returns {task: loss items tensor[5]}."""
+        ni = self.steps if ni is None else ni
+        lrs, mom = self.lrs(ni, self.epoch)
+        active = [t for t in self.task_ids if t in batches]
+        out = {}
+        for t in active:
+            out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
+        n_serving = None
+        if len(active) != len(self.task_ids):
+            n_serving = {i: max(len([t for t in ts if t in active]), 1) for i, ts in self.serving.items()}
+        self.optimizer_step(lrs, mom, n_serving)
+        return out

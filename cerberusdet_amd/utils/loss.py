@@ -20,7 +20,8 @@ def pad_targets(batch, batch_size, imgsz_hw, device, n_max=None):
     box = batch["bboxes"].to(device).float()
     order = torch.argsort(bi, stable=True)
     bi, cls, box = bi[order], cls[order], box[order]
-    counts = torch.bincount(bi, minlength=batch_size)
+    counts = torch.zeros(batch_size, dtype=torch.int64, device=device).index_add_(0, bi, torch.ones_like(bi))
+    sync_free = n_max is not None  # caller guarantees n_max >= labels per image: no device->host sync at all
     if n_max is None:
         n_max = int(counts.max())  # one host sync (the reference has `counts.max()` as well, loss.py:117)
     start = torch.cumsum(counts, 0) - counts
@@ -30,8 +31,11 @@ def pad_targets(batch, batch_size, imgsz_hw, device, n_max=None):
     xywh = box * scale
     xyxy = torch.stack((xywh[:, 0] - xywh[:, 2] / 2, xywh[:, 1] - xywh[:, 3] / 2, xywh[:, 0] + xywh[:, 2] / 2, xywh[:, 1] + xywh[:, 3] / 2), 1)
     out = torch.zeros(batch_size, max(n_max, 1), 5, device=device)
-    keep = pos < n_max
-    out[bi[keep], pos[keep]] = torch.cat((cls[keep, None], xyxy[keep]), 1)
+    vals = torch.cat((cls[:, None], xyxy), 1)
+    if sync_free:
+        out.index_put_((bi, pos.clamp(max=max(n_max, 1) - 1)), vals)
+    else:
+        out[bi, pos] = vals
     return out
 
 

@@ -1,0 +1,158 @@
+"""CPU-only checks of the host side: structure parity with the reference (block numbering, plans, state-dict schema), the
+C-ABI library loads and exports every symbol declared in include/cerberus_hip.h, host helpers."""
+import copy
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from util import GOLDEN
+
+ROOT = Path(__file__).resolve().parents[1]
+KA = json.load(open(GOLDEN / "graph_known_answers.json"))
+CFGS = {
+    "yolov8x_voc_obj365.yaml": ("v8x_2task.yaml", ["voc", "objects365_animals"], [20, 19]),
+    "yolov8x_voc_obj365_animals_tableware.yaml": ("v8x_3task.yaml", ["voc", "objects365_animals", "objects365_tableware"], [20, 19, 12]),
+    "yolov8x.yaml": ("v8x.yaml", ["voc"], [20]),
+}
+
+
+def test_library_exports_every_declared_symbol():
+    from cerberusdet_amd import _lib as L
+
+    hdr = (ROOT / "include" / "cerberus_hip.h").read_text()
+    declared = set(re.findall(r"\b(cdet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = L.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/cerberus_hip.h but not exported"
+    assert declared == set(L.EXPORTED_SYMBOLS), declared ^ set(L.EXPORTED_SYMBOLS)
+    assert lib.cdet_version() == 1
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without the GPU instead of silently computing elsewhere."""
+    import yaml
+
+    from cerberusdet_amd.models import CerberusDet
+    from cerberusdet_amd.utils.general import non_max_suppression
+
+    cfg = yaml.safe_load(open(ROOT / "cerberusdet_amd/models/cfg/v8n_2task.yaml"))
+    m = CerberusDet(["a", "b"], [3, 4], cfg=cfg, verbose=False)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(1, 3, 64, 64))
+        with pytest.raises(RuntimeError):
+            non_max_suppression(torch.zeros(1, 8, 10))
+    with pytest.raises(RuntimeError):
+        m.blocks[0].model[0](torch.zeros(1, 3, 64, 64))  # structural modules have no eager path
+
+
+@pytest.mark.parametrize("ref_name", list(CFGS))
+def test_structure_matches_reference(ref_name):
+    import yaml
+
+    from cerberusdet_amd.models import CerberusDet
+
+    ours, tasks, nc = CFGS[ref_name]
+    cfg = yaml.safe_load(open(ROOT / "cerberusdet_amd/models/cfg" / ours))
+    ka = KA[ref_name]
+    m = CerberusDet(tasks, nc, cfg=copy.deepcopy(cfg), verbose=False)
+    if cfg.get("cerber"):
+        m.sequential_split(cfg["cerber"], "cpu")
+    assert len(m.blocks) == ka["n_blocks"] and m.heads == ka["heads"]
+    for t in tasks:
+        assert m.execution_plan(t)[0] == ka["plans"][t]
+    assert m.execution_plan(tasks)[0] == ka["plan_all"]
+    assert sorted(m.branching_points) == ka["branching_points"]
+    assert [float(s) for s in m.stride] == ka["stride"]
+    assert sum(p.numel() for p in m.parameters()) == ka["n_params"]
+    assert len(m.state_dict()) == ka["n_state_keys"]
+    assert {str(c.index): list(c.serving_tasks.keys()) for c in m.controllers} == ka["serving"]
+    assert [type(b).__name__ for b in m.blocks] == ka["block_types"]
+    h = m.get_head(tasks[0])
+    assert all(abs(float(h.cv3[i][-1].bias[0].detach()) - ka["cls_bias_init"][i]) < 1e-5 for i in range(3))
+    # task-filtered parameters(): only blocks on that task's path
+    n_task = sum(p.numel() for p in m.parameters(task_ids=tasks[0]))
+    assert n_task == sum(p.numel() for i in ka["plans"][tasks[0]] for p in m.blocks[i].parameters())
+    copy.deepcopy(m)
+
+
+@pytest.mark.parametrize("which", ["2task", "3task"])
+def test_split_clones_weights_and_rewires(which):
+    from cerberusdet_amd.models import CerberusDet
+
+    meta = json.load(open(GOLDEN / ("model_tiny2.json" if which == "2task" else "model_tiny3.json")))
+    m = CerberusDet(meta["tasks"], meta["nc"], cfg=copy.deepcopy(meta["cfg"]), verbose=False)
+    n0 = len(m.blocks)
+    for i, b in enumerate(m.blocks):
+        for p in b.parameters():
+            p.data.fill_(float(i))
+    m.sequential_split(meta["cfg"]["cerber"], "cpu")
+    ka = KA["clones"][which]
+    assert len(m.blocks) == ka["n_blocks"]
+    for i in range(n0, len(m.blocks)):
+        ps = list(m.blocks[i].parameters())
+        src = int(ps[0].flatten()[0]) if ps else None
+        assert src == ka["clone_source"][str(i)]
+    for i, b in enumerate(m.blocks):
+        if i > 0:
+            got = [list(x) if isinstance(x, tuple) else int(x) for x in b.f]
+            assert got == ka["block_f"][str(i)], (i, got, ka["block_f"][str(i)])
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["state_shapes"]
+
+
+def test_pad_targets_matches_oracle():
+    from cerberusdet_amd.utils.loss import pad_targets
+    from oracle import loss as ol
+
+    b = synth.make_batch(4, 3, 20, 5, empty_images=(2,))
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    got = pad_targets(tb, 4, (96, 128), "cpu")
+    want = ol.pad_targets(tb["batch_idx"], tb["cls"], tb["prob"], tb["bboxes"], 4, torch.tensor([128.0, 96.0, 128.0, 96.0]))
+    assert torch.allclose(got, torch.cat((want[..., :1], want[..., 2:]), -1))
+    assert torch.equal(pad_targets(tb, 4, (96, 128), "cpu", n_max=3), got)
+    assert pad_targets({k: v[:0] for k, v in tb.items()}, 4, (96, 128), "cpu").shape == (4, 1, 5)
+
+
+def test_lr_schedule_and_param_groups_match_oracle():
+    import yaml
+
+    from cerberusdet_amd.models import CerberusDet
+    from cerberusdet_amd.trainers.averaging import get_param_groups
+    from oracle import optim as oo
+
+    meta = json.load(open(GOLDEN / "trainer.json"))
+    mmeta = json.load(open(GOLDEN / "model_tiny2.json"))
+    m = CerberusDet(mmeta["tasks"], mmeta["nc"], cfg=copy.deepcopy(mmeta["cfg"]), verbose=False)
+    m.sequential_split(mmeta["cfg"]["cerber"], "cpu")
+    g0, g1, g2 = get_param_groups(m)
+    assert [len(g2), len(g0), len(g1)] == meta["param_group_sizes"]
+    names = {id(p): k for k, p in m.named_parameters()}
+    for grp, ps in enumerate((g0, g1, g2)):
+        assert all(oo.param_group(names[id(p)]) == grp for p in ps)
+    # warm-up / schedule (reference base_trainer.py:100-112) -- check the host formula against the oracle's restatement
+    from cerberusdet_amd.trainers.averaging import Averaging
+
+    tr = Averaging.__new__(Averaging)
+    tr.hyp, tr.nw, tr.lr0, tr.momentum, tr.lf = meta["hyp"], 1000, meta["hyp"]["lr0"], meta["hyp"]["momentum"], (lambda e: 0.9)
+    for ni in (0, 1, 500, 1000):
+        lrs, mom = tr.lrs(ni, 0)
+        wl, wm = oo.warmup_lr(ni, 1000, meta["hyp"]["lr0"], 0.9)
+        assert np.allclose(lrs, wl) and abs(mom - wm) < 1e-12
+    assert tr.lrs(1001, 0)[0] == [meta["hyp"]["lr0"] * 0.9] * 3
+
+
+def test_nms_between_tasks_host_matches_golden():
+    from cerberusdet_amd.utils.general import nms_between_tasks
+    from oracle import nms as on
+
+    arrays = dict(np.load(GOLDEN / "nms.npz"))
+    _, _, names, _ = synth.predict_inputs()
+    cmap, _ = on.categories_map(names)
+    out = nms_between_tasks(torch.from_numpy(arrays["between/in"]), cmap, 0.8)
+    assert np.array_equal(out.numpy(), arrays["between/out"])
