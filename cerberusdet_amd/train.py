@@ -1,0 +1,170 @@
+"""Training entry point with the reference's flags and process model (ai-forever/CerberusDet cerberusdet/train.py:279-419):
+one process per GPU (`python -m torch.distributed.run --nproc-per-node N cerberusdet_amd/train.py ...`), env LOCAL_RANK /
+RANK / WORLD_SIZE, `train(hyp, opt, device, train_dataset=None, val_dataset=None)`, `run(**kwargs)`.
+
+Scope: the hot path -- model, loss, backward, gradient all-reduce, optimizer -- is native here. The
+reference's CPU data pipeline (cv2 mosaic/augmentations, label caches), validation harness, plotting and MLflow/TensorBoard
+logging are out of scope; `train_dataset` therefore is any iterable per task that yields the reference's batch dicts
+({"img": uint8 [N,3,H,W], "cls", "bboxes" (xywh in [0,1]), "batch_idx"}), and `--data synthetic` provides the benchmark's
+generator.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import yaml
+
+FILE = Path(__file__).resolve()
+ROOT = FILE.parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+LOCAL_RANK = int(os.getenv("LOCAL_RANK", -1))
+RANK = int(os.getenv("RANK", -1))
+WORLD_SIZE = int(os.getenv("WORLD_SIZE", 1))
+
+
+def parse_opt(known=False):
+    p = argparse.ArgumentParser()
+    p.add_argument("--weights", type=str, default="", help="initial cerberusdet_amd checkpoint")
+    p.add_argument("--cfg", type=str, default=str(ROOT / "cerberusdet_amd/models/cfg/v8x_2task.yaml"), help="model.yaml path")
+    p.add_argument("--data", type=str, default="synthetic", help="dataset.yaml path or 'synthetic'")
+    p.add_argument("--hyp", type=str, default="", help="hyperparameters path")
+    p.add_argument("--epochs", type=int, default=1)
+    p.add_argument("--batch-size", type=str, default="32", help="batch size PER GPU, one value or 'a,b,c' per task")
+    p.add_argument("--imgsz", "--img", "--img-size", type=int, default=640)
+    p.add_argument("--resume", nargs="?", const=True, default=False)
+    p.add_argument("--nosave", action="store_true")
+    p.add_argument("--noval", action="store_true")
+    p.add_argument("--device", default="")
+    p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (not implemented yet: statistics are per GPU)")
+    p.add_argument("--workers", type=int, default=8)
+    p.add_argument("--project", default="runs/train")
+    p.add_argument("--name", default="exp")
+    p.add_argument("--exist-ok", action="store_true")
+    p.add_argument("--linear-lr", action="store_true")
+    p.add_argument("--patience", type=int, default=30)
+    p.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    p.add_argument("--single-cls", action="store_true")
+    p.add_argument("--freeze-shared-till-epoch", type=int, default=0)
+    p.add_argument("--skip-batches", action="store_true")
+    p.add_argument("--iters-per-epoch", type=int, default=20, help="synthetic data: iterations per epoch")
+    p.add_argument("--tasks", type=str, default="voc,objects365_animals")
+    p.add_argument("--nc", type=str, default="20,19")
+    return p.parse_known_args()[0] if known else p.parse_args()
+
+
+DEFAULT_HYP = dict(lr0=0.00309, lrf=0.0956, momentum=0.952, weight_decay=0.00037, warmup_epochs=2.04, warmup_momentum=0.898,
+                   warmup_bias_lr=0.0502, box=7.5, cls=0.5, dfl=1.5)
+
+
+def fill_tasks_parameters(model, hyp, imgsz, names=None):
+    """hyp scaling + attribute contract of the reference (utils/models_manager.py:122-153): box *= 3/nl, cls *= (imgsz/640)^2*3/nl."""
+    nl = 3
+    hyp = dict(hyp)
+    for k, f in (("box", 3.0 / nl), ("cls", (imgsz / 640) ** 2 * 3.0 / nl)):
+        hyp[k] = [v * f for v in hyp[k]] if isinstance(hyp[k], list) else hyp[k] * f
+    model.hyp = hyp
+    model.nc = {t: model.get_head(t).nc for t in model.heads}
+    model.names = names or {t: [str(i) for i in range(model.get_head(t).nc)] for t in model.heads}
+    return hyp
+
+
+def train(hyp, opt, device, train_dataset=None, val_dataset=None):
+    from cerberusdet_amd.models import CerberusDet
+    from cerberusdet_amd.trainers import Averaging
+
+    tasks = opt.tasks.split(",")
+    nc = [int(v) for v in opt.nc.split(",")]
+    bs = [int(v) for v in str(opt.batch_size).split(",")]
+    bs = bs * len(tasks) if len(bs) == 1 else bs
+    cfg = yaml.safe_load(open(opt.cfg))
+    torch.manual_seed(0)
+    model = CerberusDet(tasks, nc, cfg=cfg, verbose=RANK in (-1, 0))
+    if cfg.get("cerber"):
+        model.sequential_split(cfg["cerber"], "cpu")
+    if opt.weights:
+        ck = torch.load(opt.weights, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["state_dict"], strict=False)
+    model = model.to(device).train()
+    hyp = fill_tasks_parameters(model, hyp, opt.imgsz)
+    if WORLD_SIZE > 1:
+        for t in list(model.state_dict().values()):  # what DDP's constructor does in the reference (train.py:182-184)
+            dist.broadcast(t, src=0)
+    if train_dataset is None:
+        if opt.data != "synthetic":
+            raise NotImplementedError("cerberusdet_amd.train: pass per-task iterables of batch dicts as train_dataset, or --data synthetic")
+        import bench
+
+        def gen(ti, t):
+            i = 0
+            while True:
+                yield bench.synth_batch(max(RANK, 0), ti, i % 4, bs[ti], nc[ti], opt.imgsz, device)
+                i += 1
+        train_dataset = {t: gen(ti, t) for ti, t in enumerate(tasks)}
+        nb = opt.iters_per_epoch
+    else:
+        nb = max(len(d) if hasattr(d, "__len__") else opt.iters_per_epoch for d in train_dataset.values())
+    trainer = Averaging(device, model, hyp, tasks, epochs=max(opt.epochs, 2), nb=nb, linear_lr=opt.linear_lr, rank=RANK, world_size=WORLD_SIZE)
+    iters = {t: iter(d) for t, d in train_dataset.items()}
+    results = {}
+    for epoch in range(opt.epochs):
+        trainer.epoch = epoch
+        t0 = time.time()
+        for i in range(nb):
+            batches = {}
+            for t in tasks:
+                try:
+                    batches[t] = next(iters[t])
+                except StopIteration:
+                    iters[t] = iter(train_dataset[t])
+                    batches[t] = next(iters[t])
+                batches[t] = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batches[t].items()}
+            items = trainer.train_step(batches, ni=i + nb * epoch)
+        torch.cuda.synchronize()
+        results = {t: [float(v) for v in items[t].tolist()] for t in tasks}
+        if RANK in (-1, 0):
+            ips = nb * sum(bs) * WORLD_SIZE / (time.time() - t0)
+            print(f"epoch {epoch}: " + "  ".join(f"{t}: box {r[0]:.4f} cls {r[1]:.4f} dfl {r[2]:.4f}" for t, r in results.items()) + f"  [{ips:.1f} img/s]")
+    if RANK in (-1, 0) and not opt.nosave:
+        from cerberusdet_amd.cerberusdet_inference import save_checkpoint
+
+        out = Path(opt.project) / opt.name
+        out.mkdir(parents=True, exist_ok=True)
+        save_checkpoint(out / "last.pt", trainer.ema.ema if trainer.ema else model, getattr(model, "names", None))
+    return results, opt.epochs - 1
+
+
+def main(opt):
+    device = torch.device("cuda", max(LOCAL_RANK, 0))
+    torch.cuda.set_device(device)
+    if LOCAL_RANK != -1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if dist.is_nccl_available() else "gloo", device_id=device)
+    hyp = dict(DEFAULT_HYP)
+    if opt.hyp:
+        hyp.update(yaml.safe_load(open(opt.hyp)))
+    res = train(hyp, opt, device)
+    if WORLD_SIZE > 1 and RANK == 0:
+        print("Destroying process group... ")
+    if LOCAL_RANK != -1:
+        dist.destroy_process_group()
+    return res
+
+
+def run(**kwargs):
+    opt = parse_opt(True)
+    for k, v in kwargs.items():
+        setattr(opt, k, v)
+    return main(opt)
+
+
+if __name__ == "__main__":
+    main(parse_opt())
