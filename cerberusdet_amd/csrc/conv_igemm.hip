@@ -13,6 +13,8 @@
 // single LDS stage + register prefetch of the next K step (global loads fly under the MFMAs).
 // Workgroup ids are remapped so that the cout-blocks of one pixel-block run back to back on ONE XCD
 // (their im2col tile is served by that XCD's L2 instead of HBM).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cdet {
@@ -288,6 +290,319 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+// ================================================================================================
+// v2 (default): same tiling / fragments as above, re-engineered around what the ablations on the MI355X showed
+// (profiles/r01_conv_ablation.txt): the K loop was NOT the problem -- ~6000 instructions of prologue + epilogue per wave
+// cost ~20 us per workgroup (as much as the 45 K steps of the dominant layer).
+//   * operand staging: HBM -> LDS directly with global_load_lds (16 B per lane, no VGPR staging / ds_write pass). The LDS
+//     image of a wave-instruction is lane-linear (8 rows x 128 B), so the XOR swizzle is applied to the SOURCE address:
+//     the lane that owns physical slot s of row r fetches logical k-vector s ^ ((r>>1)&7); padding taps fetch a zero page;
+//   * two LDS stages, ONE barrier per K step: the DMA of step t+1 is issued before the MFMAs of step t and waited for
+//     (vmcnt(0), placed by the compiler in front of the barrier) after them;
+//   * prologue: one integer division per thread (further rows advance incrementally), tap validity as a bit mask built
+//     from separable row / column bits, 32-bit element offsets;
+//   * epilogue: compile-time specialised (raw | scale-bias-act-residual) x (16-bit | fp32 out), v_cvt_pk_bf16_f32, rcp
+//     instead of IEEE division in SiLU, row base addresses hoisted.
+// ================================================================================================
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if (DT == CDET_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+
+// bit k set <=> tap k of one axis reads a valid source coordinate
+template <bool DGRAD>
+__device__ __forceinline__ unsigned axis_bits(int base, int K, int stride, int limit) {
+    unsigned bits = 0u;
+    for (int k = 0; k < K; ++k) {
+        int s;
+        bool ok = true;
+        if (DGRAD) {
+            const int t = base - k;
+            if (stride == 2) {
+                ok = (t & 1) == 0;
+                s = t >> 1;
+            } else {
+                s = t;
+            }
+        } else {
+            s = base + k;
+        }
+        if (ok && (unsigned)s < (unsigned)limit) bits |= 1u << k;
+    }
+    return bits;
+}
+
+constexpr int EPI_RAW = 0, EPI_FULL = 1;
+
+template <int DT, int WAVES_M, int WAVES_N, bool DGRAD, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvArgs a) {
+    constexpr int BP = 64 * WAVES_M;
+    constexpr int BC = 80 * WAVES_N;
+    constexpr int XI = BP / 32;                 // X wave-instructions per wave per K step (8 rows each)
+    constexpr int WI_TOTAL = BC / 8;            // W wave-instructions per K step in the block
+    constexpr int WI = (WI_TOTAL + 3) / 4;      // per wave (last waves may have one fewer)
+    constexpr int STAGE = (BP + BC) * ROW_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int cblk = L % a.n_cblk;
+    const int pblk = L / a.n_cblk;
+    const int p0 = pblk * BP;
+    const int c0 = cblk * BC;
+
+    const int slot = lane & 7;
+    const int lr = lane >> 3;  // row within a wave-instruction
+    // ---- X rows owned by this thread: row(j) = wave*8*XI + 8*j + lr ---------------------------------------------------
+    int rowoff[XI];
+    unsigned tapmask[XI];
+    const int ntap = a.KH * a.KW;
+    {
+        int p = p0 + wave * (8 * XI) + lr;
+        const int hw = a.Hd * a.Wd;
+        int n = p / hw;
+        int rem = p - n * hw;
+        int py = rem / a.Wd;
+        int px = rem - py * a.Wd;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            rowoff[j] = 0;
+            tapmask[j] = 0u;
+            if (p < a.M) {
+                int by, bx;  // base source coordinates of tap (0,0)
+                if (DGRAD) {
+                    by = py + a.pad;
+                    bx = px + a.pad;
+                } else {
+                    by = py * a.stride - a.pad;
+                    bx = px * a.stride - a.pad;
+                }
+                const unsigned rb = axis_bits<DGRAD>(by, a.KH, a.stride, a.Hs);
+                const unsigned cb = axis_bits<DGRAD>(bx, a.KW, a.stride, a.Ws);
+                unsigned m = 0u;
+                for (int kh = 0; kh < a.KH; ++kh)
+                    if ((rb >> kh) & 1u) m |= cb << (kh * a.KW);
+                tapmask[j] = m;
+                const int oy = (DGRAD && a.stride == 2) ? by >> 1 : by;
+                const int ox = (DGRAD && a.stride == 2) ? bx >> 1 : bx;
+                rowoff[j] = ((n * a.Hs + oy) * a.Ws + ox) * a.src_ld + a.src_coff;
+            }
+            p += 8;
+            px += 8;
+            while (px >= a.Wd) {
+                px -= a.Wd;
+                if (++py == a.Hd) {
+                    py = 0;
+                    ++n;
+                }
+            }
+        }
+    }
+    // two K cursors: even j use k-vector (slot ^ sw0), odd j use that ^ 4 (rows 8 apart flip bit 2 of (row>>1)&7)
+    const int sw0 = ((wave * (8 * XI) + lr) >> 1) & 7;
+    int kc[2], ktap[2], kkh[2], kkw[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int kv = slot ^ sw0 ^ (c ? 4 : 0);
+        const int k = kv * 8;
+        ktap[c] = k / a.Cs;
+        kc[c] = k - ktap[c] * a.Cs;
+        kkh[c] = ktap[c] / a.KW;
+        kkw[c] = ktap[c] - kkh[c] * a.KW;
+    }
+    // ---- W rows: wave-instruction id wi = wave + 4*j covers rows 8*wi + lr ---------------------------------------------
+    const uint16_t* wptr[WI];
+    bool wadv[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int wi = wave + 4 * j;
+        const int r = 8 * wi + lr;
+        const int co = c0 + r;
+        const int kv = slot ^ ((r >> 1) & 7);
+        wadv[j] = wi < WI_TOTAL && co < a.Cd;  // rows beyond Cd stream zeros from the zero page (pointer not advanced)
+        wptr[j] = wadv[j] ? a.w + (int64_t)co * a.Kpad + kv * 8 : reinterpret_cast<const uint16_t*>(g_zero_page);
+    }
+
+    auto stage = [&](int buf) {
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* wsm = xs + BP * ROW_BYTES;
+        int toff[2];
+        bool tin[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            tin[c] = ktap[c] < ntap;
+            int o;
+            if (DGRAD) o = a.stride == 2 ? -(((kkh[c] >> 1) * a.Ws + (kkw[c] >> 1)) * a.src_ld) : -((kkh[c] * a.Ws + kkw[c]) * a.src_ld);
+            else o = (kkh[c] * a.Ws + kkw[c]) * a.src_ld;
+            toff[c] = o + kc[c];
+        }
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int c = j & 1;
+            const bool ok = tin[c] && ((tapmask[j] >> ktap[c]) & 1u);
+            const uint16_t* src = ok ? a.x + (rowoff[j] + toff[c]) : reinterpret_cast<const uint16_t*>(g_zero_page);
+            glds16(src, xs + (wave * (8 * XI) + 8 * j) * ROW_BYTES);
+        }
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            if (wave + 4 * j < WI_TOTAL) {
+                glds16(wptr[j], wsm + (8 * (wave + 4 * j)) * ROW_BYTES);
+                if (wadv[j]) wptr[j] += BK;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            kc[c] += BK;
+            while (kc[c] >= a.Cs) {
+                kc[c] -= a.Cs;
+                ++ktap[c];
+                if (++kkw[c] == a.KW) {
+                    kkw[c] = 0;
+                    ++kkh[c];
+                }
+            }
+        }
+    };
+
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+
+    stage(0);
+    __syncthreads();
+    for (int ks = 0; ks < a.nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < a.nk) stage(cur ^ 1);
+        const unsigned char* Xs = smem + cur * STAGE;
+        const unsigned char* Wsm = Xs + BP * ROW_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 af[5], bf[4];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) af[i] = *reinterpret_cast<const u32x4*>(Wsm + lds_slot(wn * 80 + i * 16 + frow, kk * 4 + fk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(Xs + lds_slot(wm * 64 + j * 16 + frow, kk * 4 + fk));
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<DT>::run(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- BN statistics of the raw convolution (train mode) --------------------------------------------------------------
+    if (a.stats != nullptr) {
+        float* st = reinterpret_cast<float*>(smem);  // [WAVES_M][2][BC]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            f32x4 s = acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+            f32x4 q = acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1] + acc[i][2] * acc[i][2] + acc[i][3] * acc[i][3];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[r] += __shfl_xor(s[r], m);
+                    q[r] += __shfl_xor(q[r], m);
+                }
+            }
+            if (frow == 0) {
+                const int cl = wn * 80 + i * 16 + fk * 4;
+                *reinterpret_cast<f32x4*>(st + (wm * 2 + 0) * BC + cl) = s;
+                *reinterpret_cast<f32x4*>(st + (wm * 2 + 1) * BC + cl) = q;
+            }
+        }
+        __syncthreads();
+        if (t < BC && c0 + t < a.Cd) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int m = 0; m < WAVES_M; ++m) {
+                sv += st[(m * 2 + 0) * BC + t];
+                qv += st[(m * 2 + 1) * BC + t];
+            }
+            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    int64_t obase[4];
+    int64_t rbase[4];
+    bool pvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + wm * 64 + j * 16 + frow;
+        pvalid[j] = p < a.M;
+        obase[j] = (int64_t)p * a.dst_ld + a.dst_coff;
+        rbase[j] = (int64_t)p * a.res_ld + a.res_coff;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int co = c0 + wn * 80 + i * 16 + fk * 4;
+        if (co >= a.Cd) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_FULL) {
+            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+            if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + co);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!pvalid[j]) continue;
+            f32x4 v = acc[i][j];
+            if (EPI == EPI_FULL) {
+                v = v * sc + bi;
+                if (a.act == CDET_ACT_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+                }
+                if (a.res) {
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + rbase[j] + co);
+                    v[0] += Elem<DT>::to_f32((uint16_t)(rv[0] & 0xffff));
+                    v[1] += Elem<DT>::to_f32((uint16_t)(rv[0] >> 16));
+                    v[2] += Elem<DT>::to_f32((uint16_t)(rv[1] & 0xffff));
+                    v[3] += Elem<DT>::to_f32((uint16_t)(rv[1] >> 16));
+                }
+            }
+            if (OUT_F32) {
+                float* yp = reinterpret_cast<float*>(a.y) + obase[j] + co;
+                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
+                *reinterpret_cast<f32x4*>(yp) = v;
+            } else {
+                u32x2 pk;
+                pk[0] = pack2<DT>(v[0], v[1]);
+                pk[1] = pack2<DT>(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.y) + obase[j] + co) = pk;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing: OIHW fp32 -> [rows][Kpad] (bf16/f16), K = (kh, kw, c)
 // ------------------------------------------------------------------------------------------------
@@ -314,15 +629,51 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __rest
 
 static inline int kpad_of(int K) { return (K + BK - 1) / BK * BK; }
 
+static int conv_impl() {
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("CDET_CONV_IMPL");
+        impl = e ? atoi(e) : 2;
+    }
+    return impl;
+}
+
+template <int DT, int WM, int WN, bool DG, int EPI, bool F32>
+static void launch_glds(const ConvArgs& a, hipStream_t s) {
+    constexpr int BP = 64 * WM, BC = 80 * WN;
+    const size_t lds = (size_t)2 * (BP + BC) * ROW_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>), dim3(a.n_pblk * a.n_cblk), dim3(256), lds, s, a);
+}
+
 template <int DT, int WM, int WN>
 static int launch_conv(const ConvArgs& a, bool dgrad, hipStream_t s) {
     constexpr int BP = 64 * WM, BC = 80 * WN;
-    const size_t lds = (size_t)(BP + BC) * ROW_BYTES;
-    dim3 grid(a.n_pblk * a.n_cblk), block(256);
-    if (dgrad)
-        hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, true>), grid, block, lds, s, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, false>), grid, block, lds, s, a);
+    // v2 uses 32-bit element offsets for the im2col gather
+    const bool fits32 = (int64_t)a.N * a.Hs * a.Ws * a.src_ld < (1ll << 31);
+    const bool f32out = a.out_dtype == CDET_F32;
+    const bool same16 = (a.out_dtype == CDET_BF16 && DT == CDET_BF16) || (a.out_dtype == CDET_F16 && DT == CDET_F16);
+    if (conv_impl() == 2 && fits32 && (f32out || same16)) {
+        const bool full = a.scale || a.bias || a.res || a.act != CDET_ACT_NONE;
+        if (dgrad) {
+            if (full) { if (f32out) launch_glds<DT, WM, WN, true, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, true, EPI_FULL, false>(a, s); }
+            else      { if (f32out) launch_glds<DT, WM, WN, true, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, true, EPI_RAW, false>(a, s); }
+        } else {
+            if (full) { if (f32out) launch_glds<DT, WM, WN, false, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, false, EPI_FULL, false>(a, s); }
+            else      { if (f32out) launch_glds<DT, WM, WN, false, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, false, EPI_RAW, false>(a, s); }
+        }
+    } else {
+        const size_t lds = (size_t)(BP + BC) * ROW_BYTES;
+        dim3 grid(a.n_pblk * a.n_cblk), block(256);
+        if (dgrad)
+            hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, true>), grid, block, lds, s, a);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, false>), grid, block, lds, s, a);
+    }
     CDET_LAUNCH_CHECK();
     return 0;
 }
