@@ -52,6 +52,7 @@ _SIGS = {
     "cdet_conv2d_wgrad_ws_elems": (i64, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "cdet_image_to_nhwc8": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_stem_conv_stat_blocks": (i32, [i32, i32, i32]),
     "cdet_stem_conv_wgrad": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "cdet_bn_finalize": (i32, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),

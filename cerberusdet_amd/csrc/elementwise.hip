@@ -21,11 +21,19 @@ __device__ __forceinline__ Vec8 load8(const uint16_t* p) {
     }
     return o;
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_e;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_e;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_e;
+template <int DT>
+__device__ __forceinline__ uint32_t pack2e(float a, float b) {  // v_cvt_pk_bf16_f32 / cvt_f16 (round to nearest even)
+    if (DT == CDET_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_e{a, b}, bf16x2_e));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_e{a, b}, f16x2_e));
+}
 template <int DT>
 __device__ __forceinline__ void store8(uint16_t* p, const Vec8& x) {
     u32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (uint32_t)Elem<DT>::from_f32(x.v[2 * i]) | ((uint32_t)Elem<DT>::from_f32(x.v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) r[i] = pack2e<DT>(x.v[2 * i], x.v[2 * i + 1]);
     *reinterpret_cast<u32x4*>(p) = r;
 }
 __device__ __forceinline__ Vec8 loadf8(const float* p) {
@@ -129,10 +137,46 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const uint16_t* __rest
         sc.v[i] = ga.v[i] * is.v[i];
         sh.v[i] = be.v[i] - mu.v[i] * sc.v[i];
     }
-    for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+    const int64_t step = (int64_t)gridDim.x * cm.rows_per_pass;
+    int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl;
+    for (; r + 3 * step < M; r += 4 * step) {  // 4 independent rows in flight per thread
+        u32x4 zr[4], rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) zr[u] = *reinterpret_cast<const u32x4*>(z + (r + u * step) * z_ld + z_coff + c);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr[u] = *reinterpret_cast<const u32x4*>(res + (r + u * step) * res_ld + res_coff + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Vec8 x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x.v[2 * i] = Elem<DT>::to_f32((uint16_t)(zr[u][i] & 0xffff));
+                x.v[2 * i + 1] = Elem<DT>::to_f32((uint16_t)(zr[u][i] >> 16));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float a = x.v[i] * sc.v[i] + sh.v[i];
+                x.v[i] = a * __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+            }
+            if (res) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x.v[2 * i] += Elem<DT>::to_f32((uint16_t)(rr[u][i] & 0xffff));
+                    x.v[2 * i + 1] += Elem<DT>::to_f32((uint16_t)(rr[u][i] >> 16));
+                }
+            }
+            store8<DT>(y + (r + u * step) * y_ld + y_coff + c, x);
+        }
+    }
+    for (; r < M; r += step) {
         Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x.v[i] = silu_f(x.v[i] * sc.v[i] + sh.v[i]);
+        for (int i = 0; i < 8; ++i) {
+            const float a = x.v[i] * sc.v[i] + sh.v[i];
+            x.v[i] = a * __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+        }
         if (res) {
             const Vec8 rr = load8<DT>(res + r * res_ld + res_coff + c);
 #pragma unroll
@@ -144,7 +188,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const uint16_t* __rest
 
 // d silu(a)/da = s*(1 + a*(1-s)), s = sigmoid(a)
 __device__ __forceinline__ float dsilu_f(float a) {
-    const float s = sigmoid_f(a);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
     return s * (1.f + a * (1.f - s));
 }
 
@@ -163,7 +207,26 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const uint16_t*
     for (int i = 0; i < 8; ++i) s1.v[i] = s2.v[i] = 0.f;
     if (cm.active) {
         const Vec8 mu = loadf8(mean + c), is = loadf8(invstd + c), ga = loadf8(gamma + c), be = loadf8(beta + c);
-        for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+        const int64_t step = (int64_t)gridDim.x * cm.rows_per_pass;
+        int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl;
+        for (; r + 3 * step < M; r += 4 * step) {
+            Vec8 g[4], x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = load8<DT>(dy + (r + u * step) * dy_ld + dy_coff + c);
+                x[u] = load8<DT>(z + (r + u * step) * z_ld + z_coff + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (x[u].v[i] - mu.v[i]) * is.v[i];
+                    const float da = g[u].v[i] * dsilu_f(ga.v[i] * xh + be.v[i]);
+                    s1.v[i] += da;
+                    s2.v[i] += da * xh;
+                }
+        }
+        for (; r < M; r += step) {
             const Vec8 g = load8<DT>(dy + r * dy_ld + dy_coff + c);
             const Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
 #pragma unroll
@@ -191,12 +254,12 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const uint16_t*
 // pass 2a: reduce partials -> sums (and dgamma / dbeta)
 __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums,
                                                           float* dgamma, float* dbeta, int accumulate) {
-    __shared__ double sh[2][4][64];
-    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double sh[2][16][16];
+    const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int b = g; b < nblk; b += 4) {
+        for (int b = g; b < nblk; b += 16) {
             s += (double)part[((int64_t)b * 2 + 0) * C + c];
             q += (double)part[((int64_t)b * 2 + 1) * C + c];
         }
@@ -205,8 +268,13 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
     sh[1][g][cx] = q;
     __syncthreads();
     if (g == 0 && c < C) {
-        s = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-        q = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+        s = 0.0;
+        q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s += sh[0][k][cx];
+            q += sh[1][k][cx];
+        }
         sums[c] = (float)s;
         sums[C + c] = (float)q;
         if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
@@ -232,7 +300,28 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
         m1.v[i] *= inv_count;
         m2.v[i] *= inv_count;
     }
-    for (int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl; r < M; r += (int64_t)gridDim.x * cm.rows_per_pass) {
+    const int64_t step = (int64_t)gridDim.x * cm.rows_per_pass;
+    int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl;
+    for (; r + 3 * step < M; r += 4 * step) {
+        Vec8 g[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[u] = load8<DT>(dy + (r + u * step) * dy_ld + dy_coff + c);
+            x[u] = load8<DT>(z + (r + u * step) * z_ld + z_coff + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Vec8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (x[u].v[i] - mu.v[i]) * is.v[i];
+                const float da = g[u].v[i] * dsilu_f(ga.v[i] * xh + be.v[i]);
+                o.v[i] = ga.v[i] * is.v[i] * (da - m1.v[i] - xh * m2.v[i]);
+            }
+            store8<DT>(dz + (r + u * step) * dz_ld + dz_coff + c, o);
+        }
+    }
+    for (; r < M; r += step) {
         const Vec8 g = load8<DT>(dy + r * dy_ld + dy_coff + c);
         const Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
         Vec8 o;
@@ -450,6 +539,26 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     out[c] = (accumulate ? out[c] : 0.f) + (float)s;
 }
 
+// NCHW image (uint8 scaled by 1/255, or float) -> NHWC with the 3 channels padded to 8 (16-byte pixels), 16-bit: lets the stem
+// run on the generic implicit-GEMM kernels (K = 72 -> 128) instead of a VALU kernel.
+template <int DT>
+__global__ __launch_bounds__(256) void image_to_nhwc8_kernel(const void* __restrict__ img, int img_dtype, uint16_t* __restrict__ out, int N,
+                                                             int H, int W) {
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t plane = (int64_t)H * W;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = p / plane, r = p - n * plane;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t i = (n * 3 + c) * plane + r;
+            v[c] = img_dtype == CDET_U8 ? (float)((const uint8_t*)img)[i] * (1.0f / 255.0f) : load_elem(img, i, img_dtype);
+        }
+        u32x4 o = {pack2e<DT>(v[0], v[1]), pack2e<DT>(v[2], 0.f), 0u, 0u};
+        *reinterpret_cast<u32x4*>(out + p * 8) = o;
+    }
+}
+
 static inline int grid_for(int64_t work_items, int per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -525,7 +634,7 @@ extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_
     CDET_CHECK_ARG(dz_ld % 8 == 0 && dz_coff % 8 == 0 && part && nblk > 0, "cdet_bn_silu_bwd_apply: bad arguments");
     // the reduced sums live behind the partials: part[nblk*2*C .. nblk*2*C + 2*C)
     float* sums = const_cast<float*>(part) + (int64_t)nblk * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(div_up(C, 16)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, dgamma, dbeta, accumulate);
     CDET_LAUNCH_CHECK();
     const int CV = C / 8, rpp = 256 / CV;
     const int grid = grid_for(M, rpp * 8);
@@ -613,6 +722,17 @@ extern "C" int cdet_colsum(const void* src, int32_t ld, int32_t coff, int64_t M,
                                          part, M, C, CV));
     CDET_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(div_up(C_out, 256)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, C_out, out, accumulate);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_image_to_nhwc8(const void* img_nchw, int32_t img_dtype, void* out, int32_t N, int32_t H, int32_t W, int32_t dtype,
+                                   void* stream) {
+    CDET_CHECK_ARG(img_nchw && out, "cdet_image_to_nhwc8: null pointer");
+    CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "cdet_image_to_nhwc8: dtype must be bf16/f16");
+    const int grid = grid_for((int64_t)N * H * W, 256 * 4);
+    DISPATCH16(dtype, hipLaunchKernelGGL((image_to_nhwc8_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, img_nchw, img_dtype,
+                                         (uint16_t*)out, N, H, W));
     CDET_LAUNCH_CHECK();
     return 0;
 }

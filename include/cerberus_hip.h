@@ -99,6 +99,10 @@ int cdet_stem_conv(const void* img_nchw, int32_t img_dtype, const float* w_oihw,
                    void* y, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t out_dtype, int32_t act,
                    float* stats, void* stream);
 int cdet_stem_conv_stat_blocks(int32_t N, int32_t H, int32_t W);
+/* Image repack for running the stem on the generic MFMA kernels: NCHW (uint8 * 1/255, or float) -> NHWC with 3 channels
+ * zero-padded to 8, 16-bit. (trainers/base_trainer.py:61-63 preprocess + the implicit NCHW->channels-last copy.) */
+int cdet_image_to_nhwc8(const void* img_nchw, int32_t img_dtype, void* out_nhwc8, int32_t N, int32_t H, int32_t W, int32_t dtype,
+                        void* stream);
 /* d(stem weight) from dy (NHWC, dtype) and the image; accumulates into fp32 OIHW [Cout,3,3,3]. */
 int cdet_stem_conv_wgrad(const void* img_nchw, int32_t img_dtype, const void* dy, int32_t dtype, float* dw_oihw,
                          int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t accumulate, void* stream);
