@@ -12,6 +12,8 @@
 // Tiling: A = X tile (rows = k columns, 64 per wave), B = dY tile (cols = couts, 80 per wave); block = 128 k-cols x
 // 160 couts (<2,2> waves) or 256 x 80 (<4,1>); 64 pixels per step; the pixel range is split over `S` blocks (split-K),
 // partials go to a workspace [S][Cout_pad][Kpad] and a second kernel reduces them in fixed order into fp32 OIHW.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cdet {
@@ -51,7 +53,8 @@ template <> struct Mfma2<CDET_F16> {
     }
 };
 
-template <int DT, int WAVES_K, int WAVES_C>
+// ABL (profiling only, CDET_WGRAD_ABLATE): 1 = no global loads in the loop, 2 = no LDS fragment reads, 3 = no MFMA
+template <int DT, int WAVES_K, int WAVES_C, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int BKC = 64 * WAVES_K;          // k columns per block
     constexpr int BCO = 80 * WAVES_C;          // couts per block
@@ -68,14 +71,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave / WAVES_C, wc = wave % WAVES_C;
-    int bid = blockIdx.x;
-    const int s = bid % a.S;
-    bid /= a.S;
-    const int cblk = bid % a.n_cblk;
-    const int kblk = bid / a.n_cblk;
+    // Workgroup -> (pixel split s, tile) so that all tiles of one pixel chunk run on ONE XCD at the same time: the chunk's X and
+    // dY rows (a few MB) are then served by that XCD's 4 MiB L2 instead of being re-fetched once per tile (the first mapping,
+    // s fastest, made this kernel HBM-bound: 23 k-blocks x 2 cout-blocks re-read every chunk).
+    int s, tile;
+    {
+        const int ntiles = a.n_kblk * a.n_cblk;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        if (a.S >= 8) {  // S is a multiple of 8
+            s = xcd + 8 * (j / ntiles);
+            tile = j % ntiles;
+        } else {         // S in {1, 2, 4}: 8/S XCDs share a chunk
+            const int g = 8 / a.S;
+            s = xcd % a.S;
+            tile = xcd / a.S + g * j;
+            if (tile >= ntiles) return;
+        }
+    }
+    const int cblk = tile % a.n_cblk;
+    const int kblk = tile / a.n_cblk;
     const int k0 = kblk * BKC, c0 = cblk * BCO;
     const int p_begin = s * a.chunk;
     const int p_end = min(p_begin + a.chunk, a.P);
+    if (p_begin >= p_end) {  // empty split (rounding): still owes zeros to its workspace slab
+        float* wz = a.ws + (int64_t)s * a.Cd_pad * a.Kp;
+        for (int e = threadIdx.x; e < BCO * BKC / 4; e += 256) {
+            const int co = c0 + e / (BKC / 4), k = k0 + (e % (BKC / 4)) * 4;
+            if (co < a.Cd_pad && k < a.Kp) *reinterpret_cast<f32x4*>(wz + (int64_t)co * a.Kp + k) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
 
     // ---- X gather bookkeeping: this thread always loads k-vector `xkv` of rows xrow0 + 16*i (XV == 16 for BKC 128) ----
     const int xkv = t % XV;
@@ -102,18 +127,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         rox[i] = rem - roy[i] * a.Wd;
     }
 
+    // dY vectors of this thread: fixed (row, channel-vector); the pointer just advances by 64 pixels per step
+    const uint16_t* yptr[YR];
+    int yrow[YR];
+    bool ycok[YR];
+#pragma unroll
+    for (int i = 0; i < YR; ++i) {
+        const int v = t + 256 * i;
+        const int row = v / YV, cv = v - row * YV;
+        yrow[i] = row;
+        ycok[i] = v < YTOT && (c0 + cv * 8) < a.Cd;
+        yptr[i] = a.dy + (int64_t)(p_begin + row) * a.dy_ld + a.dy_coff + c0 + cv * 8;
+    }
+    const int64_t ystep = (int64_t)WKP * a.dy_ld;
+    const int xconst = a.src_coff + ci;  // 32-bit element offsets (host checks N*Hs*Ws*src_ld < 2^31)
+    const int sy_off = kh - a.pad, sx_off = kw - a.pad;
+
     u32x4 xreg[XR], yreg[YR];
     auto load_global = [&](int pbase) {
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            const int p = pbase + xrow0 + XRSTEP * i;
-            const int sy = roy[i] * a.stride - a.pad + kh, sx = rox[i] * a.stride - a.pad + kw;
-            const bool ok = k_ok && p < p_end && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+            const int sy = roy[i] * a.stride + sy_off, sx = rox[i] * a.stride + sx_off;
+            const bool ok = k_ok && (pbase + xrow0 + XRSTEP * i) < p_end && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(a.x + ((int64_t)(rn[i] * a.Hs + sy) * a.Ws + sx) * a.src_ld + a.src_coff + ci);
+            if (ok) v = *reinterpret_cast<const u32x4*>(a.x + (((rn[i] * a.Hs + sy) * a.Ws + sx) * a.src_ld + xconst));
             xreg[i] = v;
-            // advance by WKP pixels
-            rox[i] += WKP;
+            rox[i] += WKP;  // advance by WKP pixels
             while (rox[i] >= a.Wd) {
                 rox[i] -= a.Wd;
                 if (++roy[i] == a.Hd) {
@@ -124,12 +163,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < YR; ++i) {
-            const int v = t + 256 * i;
-            const int row = v / YV, cv = v - row * YV;
-            const int p = pbase + row, co = c0 + cv * 8;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (v < YTOT && p < p_end && co < a.Cd) val = *reinterpret_cast<const u32x4*>(a.dy + (int64_t)p * a.dy_ld + a.dy_coff + co);
+            if (ycok[i] && (pbase + yrow[i]) < p_end) val = *reinterpret_cast<const u32x4*>(yptr[i]);
             yreg[i] = val;
+            yptr[i] += ystep;
         }
     };
 
@@ -155,10 +192,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             if (v < YTOT) *reinterpret_cast<u32x4*>(Ys + row * YROW + cv * 16) = yreg[i];
         }
         __syncthreads();
-        if (pb + WKP < p_end) load_global(pb + WKP);
+        if (ABL != 1 && pb + WKP < p_end) load_global(pb + WKP);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {  // two 32-pixel MFMA steps
             u32x4 af[4], bf[5];
+            if (ABL == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = u32x4{(unsigned)pb, 1u, 2u, (unsigned)i};
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bf[j] = u32x4{(unsigned)pb, 1u, 2u, (unsigned)j};
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned char* base = Xs + x_lane_off + kk * 32 * XROW + i * 32;  // 16 channels = 32 B per tile
@@ -171,10 +214,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 const u32x2 lo = tr_read(base), hi = tr_read(base + 16 * YROW);
                 bf[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
+            }
+            if (ABL == 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][0][0] += __uint_as_float(af[i][0] ^ af[i][3]);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[0][j][1] += __uint_as_float(bf[j][0] ^ bf[j][3]);
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 5; ++j) acc[i][j] = Mfma2<DT>::run(af[i], bf[j], acc[i][j]);
+            }
         }
         __syncthreads();
     }
@@ -213,6 +264,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+static int wgrad_impl() {
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("CDET_WGRAD_IMPL");
+        impl = e ? atoi(e) : 2;
+    }
+    return impl;
+}
+
 struct WgradPlan {
     bool wide;
     int BKC, BCO, n_kblk, n_cblk, Kp, Cd_pad, S, chunk;
@@ -236,9 +296,12 @@ static WgradPlan plan_wgrad(const cdet_conv_desc* d) {
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
     if (S > 64) S = 64;
+    // the XCD-aware workgroup mapping wants S in {1, 2, 4} or a multiple of 8
+    if (S >= 8) S = S / 8 * 8;
+    else if (S >= 4) S = 4;
+    else if (S >= 2) S = 2;
     int chunk = (int)((P + S - 1) / S);
     chunk = (chunk + WKP - 1) / WKP * WKP;
-    S = (int)((P + chunk - 1) / chunk);
     p.S = S;
     p.chunk = chunk;
     return p;
@@ -250,7 +313,15 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     constexpr int XROW = BKC * 2 + 32;
     constexpr int YROW = BCO * 2 + ((BCO * 2) % 256 == 0 ? 32 : 0);
     const size_t lds = (size_t)WKP * (XROW + YROW);
-    hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC>), dim3(a.n_kblk * a.n_cblk * a.S), dim3(256), lds, s, a);
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("CDET_WGRAD_ABLATE"); abl = e ? atoi(e) : 0; }
+    const int ntiles = a.n_kblk * a.n_cblk;
+    const dim3 grid(a.S >= 8 ? ntiles * a.S : 8 * ((ntiles + 8 / a.S - 1) / (8 / a.S)));
+    if (abl == 1) hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC, 1>), grid, dim3(256), lds, s, a);
+    else if (abl == 2) hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC, 2>), grid, dim3(256), lds, s, a);
+    else if (abl == 3) hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC, 3>), grid, dim3(256), lds, s, a);
+    else
+    hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC>), grid, dim3(256), lds, s, a);
     CDET_LAUNCH_CHECK();
     return 0;
 }
@@ -282,6 +353,8 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     a.P = d->N * d->Hd * d->Wd; a.chunk = p.chunk; a.n_kblk = p.n_kblk; a.n_cblk = p.n_cblk; a.S = p.S;
     hipStream_t s = (hipStream_t)stream;
     int e;
+    const bool fits32 = (int64_t)d->N * d->Hs * d->Ws * d->src_ld < (1ll << 31);
+    CDET_CHECK_ARG(fits32, "cdet_conv2d_wgrad: tensor too large for 32-bit gather offsets");
     if (d->dtype == CDET_BF16) e = p.wide ? launch_wgrad<CDET_BF16, 2, 2>(a, s) : launch_wgrad<CDET_BF16, 4, 1>(a, s);
     else e = p.wide ? launch_wgrad<CDET_F16, 2, 2>(a, s) : launch_wgrad<CDET_F16, 4, 1>(a, s);
     if (e) return e;
