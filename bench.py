@@ -160,6 +160,60 @@ def kernel_breakdown(trainer, batches, n_max):
     return agg
 
 
+def nms_inputs(bs, nc, na, seed=7, dtype=torch.float16):
+    """boxes cx,cy~U(0,640), w,h~U(10,110); 500 random anchors per image get one class score ~U(.25,.95),
+    every other score ~U(0,.01)."""
+    g = torch.Generator().manual_seed(seed)
+    y = torch.empty(bs, 4 + nc, na)
+    y[:, 0:2] = torch.rand(bs, 2, na, generator=g) * 640
+    y[:, 2:4] = torch.rand(bs, 2, na, generator=g) * 100 + 10
+    y[:, 4:] = torch.rand(bs, nc, na, generator=g) * 0.01
+    for b in range(bs):
+        idx = torch.randperm(na, generator=g)[:500]
+        cls = torch.randint(0, nc, (500,), generator=g)
+        y[b, 4 + cls, idx] = torch.rand(500, generator=g) * 0.7 + 0.25
+    return y.to(dtype)
+
+
+def inference_section(model, device, bs=128, imgsz=640, reps=10, nms_reps=50):
+    """BASELINE.json configs[4]: CerberusDetInference-style fp16 all-heads forward at batch 128 @640 + batched NMS latency."""
+    from cerberusdet_amd.utils.general import non_max_suppression
+
+    out = {}
+    model.eval().half()
+    x = torch.rand(bs, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(3)).half().to(device)
+    with torch.no_grad():
+        for _ in range(2):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model(x)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out["infer_images_per_sec"] = round(bs / dt, 1)
+    out["infer_ms_per_batch"] = round(dt * 1e3, 2)
+    out["infer_config"] = f"YOLOv8x 2-task all-heads forward + decode, fp16 storage, batch {bs} @{imgsz}, BN folded in the epilogue"
+    out["infer_tflops"] = round(bs * 381.31e9 * (imgsz / 640) ** 2 / dt / 1e12, 1)
+    y = nms_inputs(bs, 20, 8400).to(device)
+    for name, kw in (("nms_infer", dict(conf_thres=0.25, iou_thres=0.45, max_det=300)),
+                     ("nms_val", dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300))):
+        ts = []
+        for i in range(nms_reps + 3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = non_max_suppression(y, **kw)
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        out[name] = {"p50_ms": round(ts[len(ts) // 2], 3), "p95_ms": round(ts[int(len(ts) * 0.95)], 3), "batch": bs,
+                     "kept_per_image": round(sum(r.shape[0] for r in res) / bs, 1), "settings": {k: v for k, v in kw.items()}}
+    model.train()
+    model.bfloat16()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +224,7 @@ def main():
     ap.add_argument("--cfg", default="v8x_2task.yaml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="skip the inference + NMS section (secondary part of the metric)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -243,8 +298,24 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": a["n"],
                                "avg_launch_ms": round(a["ms"] / a["n"], 4), "algorithmic_gflop_per_launch": round(a["flops"] / a["n"] / 1e9, 3)}
+            # HBM traffic per launch of that entry point from the committed rocprofv3 PMC passes of this same command
+            # (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction, WRITE_SIZE; separate passes) -- null when absent
+            tf = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
+            if tf:
+                kern = json.load(open(tf[-1]))["kernels"]
+                pref = {"cdet_conv2d_wgrad": ("conv_wgrad_kernel", "wgrad_reduce_kernel"),
+                        "cdet_conv2d[fwd]": ("conv_igemm_glds_kernel<0, 2, 2, false", "conv_igemm_glds_kernel<0, 4, 1, false"),
+                        "cdet_conv2d[dgrad]": ("conv_igemm_glds_kernel<0, 2, 2, true", "conv_igemm_glds_kernel<0, 4, 1, true")}[dom]
+                sel = [v for k, v in kern.items() if k.startswith(pref)]
+                n0 = sum(v["launches"] for k, v in kern.items() if k.startswith(pref[0]))
+                if sel and n0:
+                    out["roofline"]["traffic"] = round(sum(v["fetch_bytes_total"] + v["write_bytes_total"] for v in sel) / n0)
+                    out["roofline"]["traffic_unit"] = "bytes/launch"
+                    out["roofline"]["traffic_source"] = tf[-1].name
             out["mfma_kernels"] = {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "ms": round(v["ms"], 2), "launches": v["n"]}
                                    for k, v in agg.items() if v["flops"] > 0}
+        if not args.no_infer:
+            out["inference"] = inference_section(model, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
