@@ -17,6 +17,10 @@
 
 #include "common.h"
 
+#ifndef CDET_SETPRIO
+#define CDET_SETPRIO 1  // s_setprio(1) around the MFMA cluster: +7 % on the dominant layer (2 workgroups per CU arbitrate)
+#endif
+
 namespace cdet {
 
 struct ConvArgs {
@@ -345,13 +349,20 @@ __device__ __forceinline__ unsigned axis_bits(int base, int K, int stride, int l
 
 constexpr int EPI_RAW = 0, EPI_FULL = 1;
 
+// 8-wave instantiation (<4,2>: 256 pixels x 160 couts, 512 threads, ONE workgroup per CU): three LDS stages (3 x 52 KiB = 156 KiB of
+// the CU's 160 KiB) and a counted-vmcnt pipeline -- the DMA of K step t+2 is issued while step t is computed and step t+1 is
+// still in flight; a wave only waits for ITS OWN pieces of step t (`s_waitcnt vmcnt(pieces of one step)`), then one raw
+// s_barrier per step publishes the tile. __syncthreads() is avoided inside the loop because it would drain the DMA (vmcnt(0)).
 template <int DT, int WAVES_M, int WAVES_N, bool DGRAD, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr bool DEEP = NW == 8;              // 3-stage counted pipeline
+    constexpr bool SETPRIO = CDET_SETPRIO != 0;
     constexpr int BP = 64 * WAVES_M;
     constexpr int BC = 80 * WAVES_N;
-    constexpr int XI = BP / 32;                 // X wave-instructions per wave per K step (8 rows each)
+    constexpr int XI = BP / (8 * NW);           // X wave-instructions per wave per K step (8 rows each)
     constexpr int WI_TOTAL = BC / 8;            // W wave-instructions per K step in the block
-    constexpr int WI = (WI_TOTAL + 3) / 4;      // per wave (last waves may have one fewer)
+    constexpr int WI = (WI_TOTAL + NW - 1) / NW;  // per wave (last waves may have one fewer)
     constexpr int STAGE = (BP + BC) * ROW_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -432,12 +443,12 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvArgs a) 
         kkh[c] = ktap[c] / a.KW;
         kkw[c] = ktap[c] - kkh[c] * a.KW;
     }
-    // ---- W rows: wave-instruction id wi = wave + 4*j covers rows 8*wi + lr ---------------------------------------------
+    // ---- W rows: wave-instruction id wi = wave + NW*j covers rows 8*wi + lr --------------------------------------------
     const uint16_t* wptr[WI];
     bool wadv[WI];
 #pragma unroll
     for (int j = 0; j < WI; ++j) {
-        const int wi = wave + 4 * j;
+        const int wi = wave + NW * j;
         const int r = 8 * wi + lr;
         const int co = c0 + r;
         const int kv = slot ^ ((r >> 1) & 7);
@@ -467,8 +478,8 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvArgs a) 
         }
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
-            if (wave + 4 * j < WI_TOTAL) {
-                glds16(wptr[j], wsm + (8 * (wave + 4 * j)) * ROW_BYTES);
+            if (wave + NW * j < WI_TOTAL) {
+                glds16(wptr[j], wsm + (8 * (wave + NW * j)) * ROW_BYTES);
                 if (wadv[j]) wptr[j] += BK;
             }
         }
@@ -495,12 +506,8 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvArgs a) 
     const int frow = lane & 15;
     const int fk = lane >> 4;
 
-    stage(0);
-    __syncthreads();
-    for (int ks = 0; ks < a.nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < a.nk) stage(cur ^ 1);
-        const unsigned char* Xs = smem + cur * STAGE;
+    auto compute = [&](int buf) {
+        const unsigned char* Xs = smem + buf * STAGE;
         const unsigned char* Wsm = Xs + BP * ROW_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -509,12 +516,45 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvArgs a) 
             for (int i = 0; i < 5; ++i) af[i] = *reinterpret_cast<const u32x4*>(Wsm + lds_slot(wn * 80 + i * 16 + frow, kk * 4 + fk));
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(Xs + lds_slot(wm * 64 + j * 16 + frow, kk * 4 + fk));
+            if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<DT>::run(af[i], bf[j], acc[i][j]);
+            if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    if (DEEP) {
+        // pieces (glds instructions) this wave issues per K step: XI + (its share of the W chunks)
+        const bool w_extra = wave + NW * (WI - 1) < WI_TOTAL;  // wave-uniform
+        stage(0);
+        if (a.nk > 1) stage(1);
+        int buf = 0, nbuf = 2;
+        for (int ks = 0; ks < a.nk; ++ks) {
+            if (ks + 1 < a.nk) {  // step ks+1 may stay in flight
+                if (w_extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI - 1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // tile ks complete for every wave; everyone is done reading the buffer of tile ks-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < a.nk) stage(nbuf);
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+            nbuf = nbuf == 2 ? 0 : nbuf + 1;
         }
         __syncthreads();
+    } else {
+        stage(0);
+        __syncthreads();
+        for (int ks = 0; ks < a.nk; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < a.nk) stage(cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
     }
 
     // ---- BN statistics of the raw convolution (train mode) --------------------------------------------------------------
@@ -640,45 +680,77 @@ static int conv_impl() {
 
 template <int DT, int WM, int WN, bool DG, int EPI, bool F32>
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
-    constexpr int BP = 64 * WM, BC = 80 * WN;
-    const size_t lds = (size_t)2 * (BP + BC) * ROW_BYTES;
+    constexpr int BP = 64 * WM, BC = 80 * WN, NW = WM * WN;
+    const size_t lds = (size_t)(NW == 8 ? 3 : 2) * (BP + BC) * ROW_BYTES;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>), dim3(a.n_pblk * a.n_cblk), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>), dim3(a.n_pblk * a.n_cblk), dim3(64 * NW), lds, s, a);
 }
 
 template <int DT, int WM, int WN>
-static int launch_conv(const ConvArgs& a, bool dgrad, hipStream_t s) {
-    constexpr int BP = 64 * WM, BC = 80 * WN;
+static void launch_glds_variant(const ConvArgs& a, bool dgrad, hipStream_t s) {
+    const bool f32out = a.out_dtype == CDET_F32;
+    const bool full = a.scale || a.bias || a.res || a.act != CDET_ACT_NONE;
+    if (dgrad) {
+        if (full) { if (f32out) launch_glds<DT, WM, WN, true, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, true, EPI_FULL, false>(a, s); }
+        else      { if (f32out) launch_glds<DT, WM, WN, true, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, true, EPI_RAW, false>(a, s); }
+    } else {
+        if (full) { if (f32out) launch_glds<DT, WM, WN, false, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, false, EPI_FULL, false>(a, s); }
+        else      { if (f32out) launch_glds<DT, WM, WN, false, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, false, EPI_RAW, false>(a, s); }
+    }
+}
+
+// tile configuration: 0 = <4,1> 256 px x 80 couts (Cout <= 80), 1 = <2,2> 128 x 160, 2 = <4,2> 256 x 160 with the deep pipeline
+static int pick_cfg(int Cd, int64_t M) {
+    if (Cd <= 80) return 0;
+    static int deep = -1;
+    if (deep < 0) {
+        const char* e = getenv("CDET_CONV_DEEP");
+        deep = e ? atoi(e) : 0;  // measured on MI355X: 0.129 vs 0.127 ms (40x40 320->320), 0.163 vs 0.144 ms (80x80 160->160): off by default
+    }
+    return (deep && conv_impl() == 2 && M >= 4096) ? 2 : 1;
+}
+static inline int cfg_bp(int cfg) { return cfg == 1 ? 128 : (cfg == 0 ? 192 : 256); }  // cfg 0: 3 waves x 64 px (2 x 69 KB LDS -> 2 WGs per CU)
+static inline int cfg_bc(int cfg) { return (cfg == 0 || cfg == 3) ? 80 : 160; }
+
+template <int DT>
+static int launch_conv(const ConvArgs& a, int cfg, bool dgrad, hipStream_t s) {
     // v2 uses 32-bit element offsets for the im2col gather
     const bool fits32 = (int64_t)a.N * a.Hs * a.Ws * a.src_ld < (1ll << 31);
     const bool f32out = a.out_dtype == CDET_F32;
     const bool same16 = (a.out_dtype == CDET_BF16 && DT == CDET_BF16) || (a.out_dtype == CDET_F16 && DT == CDET_F16);
-    if (conv_impl() == 2 && fits32 && (f32out || same16)) {
-        const bool full = a.scale || a.bias || a.res || a.act != CDET_ACT_NONE;
-        if (dgrad) {
-            if (full) { if (f32out) launch_glds<DT, WM, WN, true, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, true, EPI_FULL, false>(a, s); }
-            else      { if (f32out) launch_glds<DT, WM, WN, true, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, true, EPI_RAW, false>(a, s); }
-        } else {
-            if (full) { if (f32out) launch_glds<DT, WM, WN, false, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, false, EPI_FULL, false>(a, s); }
-            else      { if (f32out) launch_glds<DT, WM, WN, false, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, false, EPI_RAW, false>(a, s); }
-        }
+    if (cfg != 3 && conv_impl() == 2 && fits32 && (f32out || same16)) {
+        if (cfg == 0) launch_glds_variant<DT, 3, 1>(a, dgrad, s);
+        else if (cfg == 1) launch_glds_variant<DT, 2, 2>(a, dgrad, s);
+        else launch_glds_variant<DT, 4, 2>(a, dgrad, s);
     } else {
-        const size_t lds = (size_t)(BP + BC) * ROW_BYTES;
         dim3 grid(a.n_pblk * a.n_cblk), block(256);
-        if (dgrad)
-            hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, true>), grid, block, lds, s, a);
-        else
-            hipLaunchKernelGGL((conv_igemm_kernel<DT, WM, WN, false>), grid, block, lds, s, a);
+        if (cfg == 0 || cfg == 3) {  // legacy kernels use 256-pixel tiles (cfg_of maps to cfg 3 when the glds family cannot run)
+            const size_t lds = (size_t)(256 + 80) * ROW_BYTES;
+            if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<DT, 4, 1, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<DT, 4, 1, false>), grid, block, lds, s, a);
+        } else {
+            const size_t lds = (size_t)(128 + 160) * ROW_BYTES;
+            if (dgrad) hipLaunchKernelGGL((conv_igemm_kernel<DT, 2, 2, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<DT, 2, 2, false>), grid, block, lds, s, a);
+        }
     }
     CDET_LAUNCH_CHECK();
     return 0;
 }
 
-static inline bool wide_tile(const cdet_conv_desc* d) { return d->Cd > 80; }
+static inline int cfg_of(const cdet_conv_desc* d) {
+    int cfg = pick_cfg(d->Cd, (int64_t)d->N * d->Hd * d->Wd);
+    const bool fits32 = (int64_t)d->N * d->Hs * d->Ws * d->src_ld < (1ll << 31);
+    const bool f32out = d->out_dtype == CDET_F32;
+    const bool same16 = d->out_dtype == d->dtype;
+    if (cfg == 2 && !(fits32 && (f32out || same16))) cfg = 1;  // the deep variant only exists in the glds family
+    if (cfg == 0 && !(conv_impl() == 2 && fits32 && (f32out || same16))) cfg = 3;  // legacy register-staged <4,1> kernel: 256-px tiles
+    return cfg;
+}
 
 }  // namespace cdet
 
@@ -686,7 +758,7 @@ using namespace cdet;
 
 extern "C" int cdet_conv2d_stat_blocks(const cdet_conv_desc* d) {
     const int64_t M = (int64_t)d->N * d->Hd * d->Wd;
-    return div_up(M, wide_tile(d) ? 128 : 256);
+    return div_up(M, cfg_bp(cfg_of(d)));
 }
 
 extern "C" int64_t cdet_packed_weight_elems(int32_t O, int32_t I, int32_t kh, int32_t kw, int32_t transpose) {
@@ -731,11 +803,11 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
     a.Kpad = kpad_of(d->kh * d->kw * d->Cs); a.nk = a.Kpad / BK;
     a.M = d->N * d->Hd * d->Wd;
     a.act = d->act; a.out_dtype = d->out_dtype; a.accumulate = d->accumulate;
-    const bool wide = wide_tile(d);
-    a.n_pblk = div_up(a.M, wide ? 128 : 256);
-    a.n_cblk = div_up(d->Cd, wide ? 160 : 80);
+    const int cfg = cfg_of(d);
+    a.n_pblk = div_up(a.M, cfg_bp(cfg));
+    a.n_cblk = div_up(d->Cd, cfg_bc(cfg));
     const bool dg = d->mode == CDET_CONV_DGRAD;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == CDET_BF16) return wide ? launch_conv<CDET_BF16, 2, 2>(a, dg, s) : launch_conv<CDET_BF16, 4, 1>(a, dg, s);
-    return wide ? launch_conv<CDET_F16, 2, 2>(a, dg, s) : launch_conv<CDET_F16, 4, 1>(a, dg, s);
+    if (d->dtype == CDET_BF16) return launch_conv<CDET_BF16>(a, cfg, dg, s);
+    return launch_conv<CDET_F16>(a, cfg, dg, s);
 }

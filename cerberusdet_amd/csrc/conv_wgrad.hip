@@ -221,10 +221,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) acc[0][j][1] += __uint_as_float(bf[j][0] ^ bf[j][3]);
             } else {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 5; ++j) acc[i][j] = Mfma2<DT>::run(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
             }
         }
         __syncthreads();

