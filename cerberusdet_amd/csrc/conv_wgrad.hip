@@ -78,9 +78,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     {
         const int ntiles = a.n_kblk * a.n_cblk;
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        if (a.S >= 8) {  // S is a multiple of 8
+        if (a.S >= 8) {  // any S >= 8: the grid is padded to a multiple of 8 splits, surplus workgroups leave at once
             s = xcd + 8 * (j / ntiles);
             tile = j % ntiles;
+            if (s >= a.S) return;
         } else {         // S in {1, 2, 4}: 8/S XCDs share a chunk
             const int g = 8 / a.S;
             s = xcd % a.S;
@@ -293,15 +294,21 @@ static WgradPlan plan_wgrad(const cdet_conv_desc* d) {
     const int64_t P = (int64_t)d->N * d->Hd * d->Wd;
     const int tiles = p.n_kblk * p.n_cblk;
     // aim at ~4 workgroups per CU (1024 on MI355X) but keep >= 256 pixels per split
-    int S = (1024 + tiles - 1) / tiles;
-    const int maxS = (int)((P + 255) / 256);
+    // 2 workgroups fit a CU (LDS + 183 VGPRs) -> 512 slots. Every split costs a full fp32 slab write + re-read, so fewer, longer
+    // splits win over perfect wave quantisation (measured: 46 tiles x 16 splits 0.186 ms vs x 22 splits 0.224 ms): aim at ~768
+    // workgroups with at least 512 pixels per split and at most 128 MB of partial slabs
+    int S = (768 + tiles / 2) / tiles;
+    const int maxS = (int)((P + 511) / 512);
     if (S > maxS) S = maxS;
+    const int64_t slab = (int64_t)p.Cd_pad * p.Kp * 4;
+    const int capS = (int)((128ll << 20) / slab);
+    if (S > capS) S = capS;
     if (S < 1) S = 1;
-    if (S > 64) S = 64;
-    // the XCD-aware workgroup mapping wants S in {1, 2, 4} or a multiple of 8
-    if (S >= 8) S = S / 8 * 8;
-    else if (S >= 4) S = 4;
-    else if (S >= 2) S = 2;
+    // the XCD-aware mapping gives split s to XCD s % 8: S must be a multiple of 8 (or 1, 2, 4) or one XCD gets an extra split
+    // (measured: S = 17 -> 0.222 ms vs S = 16 -> 0.186 ms on the dominant shape)
+    if (S >= 8) S = (S + 4) / 8 * 8;
+    else S = S >= 4 ? 4 : (S >= 2 ? 2 : 1);
+    while (S > 8 && (S > maxS || S > capS)) S -= 8;
     int chunk = (int)((P + S - 1) / S);
     chunk = (chunk + WKP - 1) / WKP * WKP;
     p.S = S;
@@ -318,7 +325,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("CDET_WGRAD_ABLATE"); abl = e ? atoi(e) : 0; }
     const int ntiles = a.n_kblk * a.n_cblk;
-    const dim3 grid(a.S >= 8 ? ntiles * a.S : 8 * ((ntiles + 8 / a.S - 1) / (8 / a.S)));
+    const dim3 grid(a.S >= 8 ? ntiles * ((a.S + 7) / 8 * 8) : 8 * ((ntiles + 8 / a.S - 1) / (8 / a.S)));
     if (abl == 1) hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC, 1>), grid, dim3(256), lds, s, a);
     else if (abl == 2) hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC, 2>), grid, dim3(256), lds, s, a);
     else if (abl == 3) hipLaunchKernelGGL((conv_wgrad_kernel<DT, WK, WC, 3>), grid, dim3(256), lds, s, a);
