@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--cfg", default="v8x_2task.yaml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (BASELINE.json configs[2]); default: per-GPU statistics")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference + NMS section (secondary part of the metric)")
     args = ap.parse_args()
 
@@ -235,24 +236,28 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs the launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CDET_REDUCE_ALWAYS") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     from cerberusdet_amd.trainers import Averaging
 
     model, cfg = build_model(args.cfg, device)
-    if world > 1:  # every rank starts from rank 0's weights (what DDP's constructor broadcast does in the reference, train.py:184)
+    if use_dist:  # every rank starts from rank 0's weights (what DDP's constructor broadcast does in the reference, train.py:184)
         for t in list(model.state_dict().values()):
             dist.broadcast(t, src=0)
-    trainer = Averaging(device, model, HYP, TASKS, epochs=100, nb=1000, rank=rank if world > 1 else -1, world_size=world)
+    trainer = Averaging(device, model, HYP, TASKS, epochs=100, nb=1000, rank=rank if use_dist else -1, world_size=world, sync_bn=args.sync_bn)
     n_iter = args.warmup + args.steps
     n_distinct = min(n_iter, 4)  # a few distinct synthetic batches, resident in HBM, cycled
     data = [{t: synth_batch(rank, ti, i, args.batch, NC[ti], args.imgsz, device) for ti, t in enumerate(TASKS)} for i in range(n_distinct)]
     n_max = 8
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -265,7 +270,7 @@ def main():
         items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -319,7 +324,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

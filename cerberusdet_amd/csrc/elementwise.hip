@@ -629,17 +629,21 @@ extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy
 extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
                                       const float* mean, const float* invstd, const float* gamma, const float* beta, const float* part,
                                       int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate, void* dz, int32_t dz_ld, int32_t dz_coff,
-                                      int64_t M, int32_t C, int32_t dtype, void* stream) {
+                                      int64_t M, int32_t C, int32_t dtype, int64_t count, void* stream) {
     if (int e = check16("cdet_bn_silu_bwd_apply", dtype, C, dy_ld, dy_coff, z_ld, z_coff)) return e;
-    CDET_CHECK_ARG(dz_ld % 8 == 0 && dz_coff % 8 == 0 && part && nblk > 0, "cdet_bn_silu_bwd_apply: bad arguments");
-    // the reduced sums live behind the partials: part[nblk*2*C .. nblk*2*C + 2*C)
+    CDET_CHECK_ARG(dz_ld % 8 == 0 && dz_coff % 8 == 0 && part && nblk >= 0, "cdet_bn_silu_bwd_apply: bad arguments");
+    // nblk > 0: reduce the partials first, the sums live behind them: part[nblk*2*C .. nblk*2*C + 2*C)
+    // nblk == 0 (SyncBatchNorm): `part` already holds the (all-reduced) sums [2C]; dgamma/dbeta were produced by cdet_bn_bwd_sums
     float* sums = const_cast<float*>(part) + (int64_t)nblk * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(div_up(C, 16)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, dgamma, dbeta, accumulate);
-    CDET_LAUNCH_CHECK();
+    if (nblk > 0) {
+        hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(div_up(C, 16)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, dgamma, dbeta, accumulate);
+        CDET_LAUNCH_CHECK();
+    }
+    const int64_t cnt = count > 0 ? count : M;
     const int CV = C / 8, rpp = 256 / CV;
     const int grid = grid_for(M, rpp * 8);
     DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, dy_ld,
-                                         dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)M,
+                                         dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
                                          (uint16_t*)dz, dz_ld, dz_coff, M, C, CV));
     CDET_LAUNCH_CHECK();
     return 0;
@@ -733,6 +737,14 @@ extern "C" int cdet_image_to_nhwc8(const void* img_nchw, int32_t img_dtype, void
     const int grid = grid_for((int64_t)N * H * W, 256 * 4);
     DISPATCH16(dtype, hipLaunchKernelGGL((image_to_nhwc8_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, img_nchw, img_dtype,
                                          (uint16_t*)out, N, H, W));
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_bn_bwd_sums(const float* part, int32_t nblk, int32_t C, float* sums, float* dgamma, float* dbeta, int32_t accumulate,
+                                void* stream) {
+    CDET_CHECK_ARG(part && sums && nblk > 0 && C > 0, "cdet_bn_bwd_sums: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(div_up(C, 16)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, sums, dgamma, dbeta, accumulate);
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -474,7 +474,7 @@ class CerberusDet(nn.Module):
 
         training = self.training if training is None else training
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
-        key = (tuple(tasks), tuple(shape), img_dtype, training, self.compute_dtype)
+        key = (tuple(tasks), tuple(shape), img_dtype, training, self.compute_dtype, bool(getattr(self, "sync_bn", False)))
         plan = self._plans.get(key)
         if plan is None:
             dev = next(super().parameters()).device

@@ -170,7 +170,7 @@ def bn_silu_bwd(dy: View, z: View, mean, invstd, gamma, beta, dz: View, dgamma, 
                                         ptr(part), z.M, z.C, dt(z.dtype), stream()), "cdet_bn_silu_bwd_reduce")
     L.check(lib.cdet_bn_silu_bwd_apply(ptr(dy), dy.ld, dy.coff, ptr(z), z.ld, z.coff, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
                                        ptr(part), nblk, ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dz), dz.ld, dz.coff, z.M, z.C,
-                                       dt(z.dtype), stream()), "cdet_bn_silu_bwd_apply")
+                                       dt(z.dtype), 0, stream()), "cdet_bn_silu_bwd_apply")
     return dz
 
 

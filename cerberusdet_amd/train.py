@@ -44,7 +44,7 @@ def parse_opt(known=False):
     p.add_argument("--nosave", action="store_true")
     p.add_argument("--noval", action="store_true")
     p.add_argument("--device", default="")
-    p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm (not implemented yet: statistics are per GPU)")
+    p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm: per-layer statistics all-reduced over the ranks")
     p.add_argument("--workers", type=int, default=8)
     p.add_argument("--project", default="runs/train")
     p.add_argument("--name", default="exp")
@@ -112,7 +112,8 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         nb = opt.iters_per_epoch
     else:
         nb = max(len(d) if hasattr(d, "__len__") else opt.iters_per_epoch for d in train_dataset.values())
-    trainer = Averaging(device, model, hyp, tasks, epochs=max(opt.epochs, 2), nb=nb, linear_lr=opt.linear_lr, rank=RANK, world_size=WORLD_SIZE)
+    trainer = Averaging(device, model, hyp, tasks, epochs=max(opt.epochs, 2), nb=nb, linear_lr=opt.linear_lr, rank=RANK, world_size=WORLD_SIZE,
+                        sync_bn=opt.sync_bn and WORLD_SIZE > 1)
     iters = {t: iter(d) for t, d in train_dataset.items()}
     results = {}
     for epoch in range(opt.epochs):

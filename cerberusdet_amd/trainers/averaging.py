@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from copy import deepcopy
 from typing import Dict, List, Optional, Sequence
 
@@ -67,7 +68,9 @@ class GradReducer:
 
     def __init__(self, buckets: Dict[int, torch.Tensor], serving: Dict[int, Sequence[str]], task_order: Sequence[str], group=None):
         self.buckets, self.serving, self.task_order, self.group = buckets, serving, list(task_order), group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # CDET_REDUCE_ALWAYS=1 keeps the collective path on for world_size 1 (single-GPU smoke test of the RCCL plumbing)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("CDET_REDUCE_ALWAYS") == "1")
         self.handles: List = []
         self.reduced_bytes = 0
 
@@ -92,9 +95,10 @@ class GradReducer:
 
 class Averaging:
     def __init__(self, device, model, hyp: dict, task_ids: Sequence[str], epochs: int = 100, nb: int = 1000, loss_weights=None,
-                 linear_lr=False, use_ema=True, rank=-1, world_size=1):
+                 linear_lr=False, use_ema=True, rank=-1, world_size=1, sync_bn=False):
         self.device, self.model, self.hyp, self.task_ids = device, model, hyp, list(task_ids)
         self.rank, self.world_size = rank, world_size
+        model.sync_bn = bool(sync_bn)  # SyncBatchNorm: per-layer statistics all-reduced over the ranks (reference train.py:140-143)
         self.epochs, self.nb = epochs, nb
         self.nw = max(round(get_hyperparameter(hyp, "warmup_epochs") * nb), 1000)  # averaging.py:58
         self.lr0, self.lrf = get_hyperparameter(hyp, "lr0"), get_hyperparameter(hyp, "lrf")

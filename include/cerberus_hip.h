@@ -128,7 +128,12 @@ int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy_coff, cons
 int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* part, int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate,
-                           void* dz, int32_t dz_ld, int32_t dz_coff, int64_t M, int32_t C, int32_t dtype, void* stream);
+                           void* dz, int32_t dz_ld, int32_t dz_coff, int64_t M, int32_t C, int32_t dtype, int64_t count, void* stream);
+/* SyncBatchNorm support (train.py:140-143 of the reference): reduce [nblk][2][C] partials (conv statistics or the backward
+ * partials) to sums[2C] so that the host can all-reduce them between kernels; then cdet_bn_finalize(sums, nblk = 1, count =
+ * global count) / cdet_bn_silu_bwd_apply(part = sums, nblk = 0, count = global count). `count` <= 0 means M. */
+int cdet_bn_bwd_sums(const float* part, int32_t nblk, int32_t C, float* sums, float* dgamma, float* dbeta, int32_t accumulate,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data-movement ops of the graph

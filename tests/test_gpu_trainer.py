@@ -102,3 +102,45 @@ def test_grad_accumulation_and_block_division():
     exp_branch = w_branch - lr * (g_branch * coef / 1 + wd * w_branch)
     assert torch.allclose(named[k_shared], exp_shared, rtol=1e-5, atol=1e-7)
     assert torch.allclose(named[k_branch], exp_branch, rtol=1e-5, atol=1e-7)
+
+
+def test_sync_bn_path_world1_equals_local_bn():
+    """SyncBatchNorm launch list (partials -> sums -> all-reduce -> finalize / apply) through RCCL with a 1-rank group must give
+    exactly the per-GPU result (the all-reduce is the identity, counts are multiplied by world = 1)."""
+    import os
+
+    import torch.distributed as dist
+
+    from cerberusdet_amd.trainers import Averaging
+
+    arrays, meta = load_golden("trainer")
+    _, mmeta = load_golden("model_tiny2")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        res = []
+        for sync in (False, True):
+            m = _model(meta, mmeta)
+            tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False, sync_bn=sync)
+            t = meta["tasks"][0]
+            img = torch.from_numpy(synth.det_image(300, 4, 128)).to(DEV)
+            b = synth.make_batch(4, 3, meta["nc"][0], 400)
+            out = tr.forward_backward(t, dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()}), active_tasks=[t])
+            torch.cuda.synchronize()
+            plan = m.get_plan(t, img.shape, img.dtype, training=True)
+            assert plan.sync_bn == sync
+            named = dict(m.named_parameters())
+            res.append((out.clone(), {k: p.grad.clone() for k, p in named.items() if p.grad is not None},
+                        m.state_dict()["blocks.0.model.2.cv1.bn.running_var"].clone()))
+        assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-7)
+        for k in res[0][1]:
+            # fp32 sums instead of double partial accumulation differ in the last bit; bf16 re-rounding amplifies that down the
+            # backward chain (about 1 % at the stem), so compare direction and norm
+            a, b_ = res[0][1][k].flatten().double().cpu(), res[1][1][k].flatten().double().cpu()
+            if float(a.norm()) < 1e-9:  # branches without positives carry (numerically) no gradient
+                continue
+            cos = float(a @ b_ / (a.norm() * b_.norm()))
+            assert cos > 0.99 and abs(float(b_.norm() / a.norm()) - 1) < 0.05, (k, cos)
+    finally:
+        dist.destroy_process_group()
