@@ -38,6 +38,11 @@ struct ConvArgs {
     int M;              // N*Hd*Wd
     int n_pblk, n_cblk;
     int act, out_dtype, accumulate;
+    // stride-2 data gradient, decomposed by output-pixel parity (glds family, MODE 2): class q owns the dX pixels with
+    // (y & 1, x & 1) == (cy, cx); only the taps kh = kh0 + 2*ih, kw = kw0 + 2*iw reach them (2.25 of 9 on average for 3x3)
+    struct ParClass {
+        int cy, cx, kh0, kw0, nh, nw, Hc, Wc, M, nk, blk0, nblk;
+    } pc[4];
 };
 
 constexpr int BK = 64;
@@ -353,8 +358,10 @@ constexpr int EPI_RAW = 0, EPI_FULL = 1;
 // the CU's 160 KiB) and a counted-vmcnt pipeline -- the DMA of K step t+2 is issued while step t is computed and step t+1 is
 // still in flight; a wave only waits for ITS OWN pieces of step t (`s_waitcnt vmcnt(pieces of one step)`), then one raw
 // s_barrier per step publishes the tile. __syncthreads() is avoided inside the loop because it would drain the DMA (vmcnt(0)).
-template <int DT, int WAVES_M, int WAVES_N, bool DGRAD, int EPI, bool OUT_F32>
+template <int DT, int WAVES_M, int WAVES_N, int MODE, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs a) {
+    constexpr bool DGRAD = MODE != 0;
+    constexpr bool PAR = MODE == 2;  // stride-2 dgrad split into the four output-parity classes
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr bool DEEP = NW == 8;              // 3-stage counted pipeline
     constexpr bool SETPRIO = CDET_SETPRIO != 0;
@@ -379,6 +386,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    // parity mode: the linear block index first selects the class (heaviest first), then the tile inside it
+    int cls = 0;
+    if (PAR) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (L >= a.pc[q].blk0) cls = q;
+        L -= a.pc[cls].blk0;
+    }
+    const int cy = PAR ? a.pc[cls].cy : 0, cx = PAR ? a.pc[cls].cx : 0;
+    const int kh0 = PAR ? a.pc[cls].kh0 : 0, kw0 = PAR ? a.pc[cls].kw0 : 0;
+    const int tapsW = PAR ? a.pc[cls].nw : a.KW;                       // taps per kernel row walked by the K cursor
+    const int ntap = PAR ? a.pc[cls].nh * a.pc[cls].nw : a.KH * a.KW;  // taps walked by the K loop
+    const int gH = PAR ? a.pc[cls].Hc : a.Hd, gW = PAR ? a.pc[cls].Wc : a.Wd;  // pixel grid the M index enumerates
+    const int Mloc = PAR ? a.pc[cls].M : a.M;
+    const int nk = PAR ? a.pc[cls].nk : a.nk;
     const int cblk = L % a.n_cblk;
     const int pblk = L / a.n_cblk;
     const int p0 = pblk * BP;
@@ -389,19 +411,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     // ---- X rows owned by this thread: row(j) = wave*8*XI + 8*j + lr ---------------------------------------------------
     int rowoff[XI];
     unsigned tapmask[XI];
-    const int ntap = a.KH * a.KW;
     {
         int p = p0 + wave * (8 * XI) + lr;
-        const int hw = a.Hd * a.Wd;
+        const int hw = gH * gW;
         int n = p / hw;
         int rem = p - n * hw;
-        int py = rem / a.Wd;
-        int px = rem - py * a.Wd;
+        int py = rem / gW;
+        int px = rem - py * gW;
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             rowoff[j] = 0;
             tapmask[j] = 0u;
-            if (p < a.M) {
+            if (PAR) {
+                if (p < Mloc) {
+                    // source coordinate of class tap (ih, iw): (oy - ih, ox - iw), oy = (y + pad - kh0) / 2 (exact)
+                    const int oy = (2 * py + cy + a.pad - kh0) >> 1, ox = (2 * px + cx + a.pad - kw0) >> 1;
+                    unsigned rb = 0u, cb = 0u;
+                    for (int ih = 0; ih < a.pc[cls].nh; ++ih)
+                        if ((unsigned)(oy - ih) < (unsigned)a.Hs) rb |= 1u << ih;
+                    for (int iw = 0; iw < tapsW; ++iw)
+                        if ((unsigned)(ox - iw) < (unsigned)a.Ws) cb |= 1u << iw;
+                    unsigned m = 0u;
+                    for (int ih = 0; ih < a.pc[cls].nh; ++ih)
+                        if ((rb >> ih) & 1u) m |= cb << (ih * tapsW);
+                    tapmask[j] = m;
+                    rowoff[j] = ((n * a.Hs + oy) * a.Ws + ox) * a.src_ld + a.src_coff;
+                }
+            } else if (p < a.M) {
                 int by, bx;  // base source coordinates of tap (0,0)
                 if (DGRAD) {
                     by = py + a.pad;
@@ -422,9 +458,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
             }
             p += 8;
             px += 8;
-            while (px >= a.Wd) {
-                px -= a.Wd;
-                if (++py == a.Hd) {
+            while (px >= gW) {
+                px -= gW;
+                if (++py == gH) {
                     py = 0;
                     ++n;
                 }
@@ -440,10 +476,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         const int k = kv * 8;
         ktap[c] = k / a.Cs;
         kc[c] = k - ktap[c] * a.Cs;
-        kkh[c] = ktap[c] / a.KW;
-        kkw[c] = ktap[c] - kkh[c] * a.KW;
+        kkh[c] = ktap[c] / tapsW;
+        kkw[c] = ktap[c] - kkh[c] * tapsW;
     }
     // ---- W rows: wave-instruction id wi = wave + NW*j covers rows 8*wi + lr --------------------------------------------
+    // (parity mode: the class's taps are not contiguous in the packed [kh][kw][c] rows, so the W pieces follow the X cursors:
+    //  W row-group wi uses cursor (wi ^ wave*XI) & 1 -- the same swizzle phase -- and only its row base is kept here)
     const uint16_t* wptr[WI];
     bool wadv[WI];
 #pragma unroll
@@ -453,7 +491,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         const int co = c0 + r;
         const int kv = slot ^ ((r >> 1) & 7);
         wadv[j] = wi < WI_TOTAL && co < a.Cd;  // rows beyond Cd stream zeros from the zero page (pointer not advanced)
-        wptr[j] = wadv[j] ? a.w + (int64_t)co * a.Kpad + kv * 8 : reinterpret_cast<const uint16_t*>(g_zero_page);
+        wptr[j] = wadv[j] ? a.w + (int64_t)co * a.Kpad + (PAR ? 0 : kv * 8) : reinterpret_cast<const uint16_t*>(g_zero_page);
     }
 
     auto stage = [&](int buf) {
@@ -465,9 +503,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         for (int c = 0; c < 2; ++c) {
             tin[c] = ktap[c] < ntap;
             int o;
-            if (DGRAD) o = a.stride == 2 ? -(((kkh[c] >> 1) * a.Ws + (kkw[c] >> 1)) * a.src_ld) : -((kkh[c] * a.Ws + kkw[c]) * a.src_ld);
+            if (PAR) o = -((kkh[c] * a.Ws + kkw[c]) * a.src_ld);
+            else if (DGRAD) o = a.stride == 2 ? -(((kkh[c] >> 1) * a.Ws + (kkw[c] >> 1)) * a.src_ld) : -((kkh[c] * a.Ws + kkw[c]) * a.src_ld);
             else o = (kkh[c] * a.Ws + kkw[c]) * a.src_ld;
             toff[c] = o + kc[c];
+        }
+        int wk[2];  // parity mode: K offset inside a packed weight row of each cursor's piece
+        if (PAR) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) wk[c] = ((kh0 + 2 * kkh[c]) * a.KW + kw0 + 2 * kkw[c]) * a.Cs + kc[c];
         }
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
@@ -479,8 +523,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
             if (wave + NW * j < WI_TOTAL) {
-                glds16(wptr[j], wsm + (8 * (wave + NW * j)) * ROW_BYTES);
-                if (wadv[j]) wptr[j] += BK;
+                if (PAR) {
+                    const int c = ((wave + NW * j) ^ (wave * XI)) & 1;
+                    const uint16_t* src = (wadv[j] && tin[c]) ? wptr[j] + wk[c] : reinterpret_cast<const uint16_t*>(g_zero_page);
+                    glds16(src, wsm + (8 * (wave + NW * j)) * ROW_BYTES);
+                } else {
+                    glds16(wptr[j], wsm + (8 * (wave + NW * j)) * ROW_BYTES);
+                    if (wadv[j]) wptr[j] += BK;
+                }
             }
         }
 #pragma unroll
@@ -489,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
             while (kc[c] >= a.Cs) {
                 kc[c] -= a.Cs;
                 ++ktap[c];
-                if (++kkw[c] == a.KW) {
+                if (++kkw[c] == tapsW) {
                     kkw[c] = 0;
                     ++kkh[c];
                 }
@@ -529,10 +579,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         // pieces (glds instructions) this wave issues per K step: XI + (its share of the W chunks)
         const bool w_extra = wave + NW * (WI - 1) < WI_TOTAL;  // wave-uniform
         stage(0);
-        if (a.nk > 1) stage(1);
+        if (nk > 1) stage(1);
         int buf = 0, nbuf = 2;
-        for (int ks = 0; ks < a.nk; ++ks) {
-            if (ks + 1 < a.nk) {  // step ks+1 may stay in flight
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk) {  // step ks+1 may stay in flight
                 if (w_extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI - 1) : "memory");
             } else {
@@ -540,7 +590,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
             }
             __builtin_amdgcn_s_barrier();  // tile ks complete for every wave; everyone is done reading the buffer of tile ks-1
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < a.nk) stage(nbuf);
+            if (ks + 2 < nk) stage(nbuf);
             compute(buf);
             buf = buf == 2 ? 0 : buf + 1;
             nbuf = nbuf == 2 ? 0 : nbuf + 1;
@@ -549,9 +599,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     } else {
         stage(0);
         __syncthreads();
-        for (int ks = 0; ks < a.nk; ++ks) {
+        for (int ks = 0; ks < nk; ++ks) {
             const int cur = ks & 1;
-            if (ks + 1 < a.nk) stage(cur ^ 1);
+            if (ks + 1 < nk) stage(cur ^ 1);
             compute(cur);
             __syncthreads();
         }
@@ -597,8 +647,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     bool pvalid[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int p = p0 + wm * 64 + j * 16 + frow;
-        pvalid[j] = p < a.M;
+        int p = p0 + wm * 64 + j * 16 + frow;
+        pvalid[j] = p < Mloc;
+        if (PAR) {  // class pixel -> dX pixel
+            const int hw = gH * gW;
+            const int n = p / hw;
+            const int rem = p - n * hw;
+            const int py = rem / gW;
+            const int px = rem - py * gW;
+            p = (n * a.Hd + 2 * py + cy) * a.Wd + 2 * px + cx;
+        }
         obase[j] = (int64_t)p * a.dst_ld + a.dst_coff;
         rbase[j] = (int64_t)p * a.res_ld + a.res_coff;
     }
@@ -678,7 +736,7 @@ static int conv_impl() {
     return impl;
 }
 
-template <int DT, int WM, int WN, bool DG, int EPI, bool F32>
+template <int DT, int WM, int WN, int DG, int EPI, bool F32>
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
     constexpr int BP = 64 * WM, BC = 80 * WN, NW = WM * WN;
     const size_t lds = (size_t)(NW == 8 ? 3 : 2) * (BP + BC) * ROW_BYTES;
@@ -687,19 +745,24 @@ static void launch_glds(const ConvArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>), dim3(a.n_pblk * a.n_cblk), dim3(64 * NW), lds, s, a);
+    const int nblocks = DG == 2 ? a.pc[3].blk0 + a.pc[3].nblk : a.n_pblk * a.n_cblk;
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>), dim3(nblocks), dim3(64 * NW), lds, s, a);
 }
 
 template <int DT, int WM, int WN>
 static void launch_glds_variant(const ConvArgs& a, bool dgrad, hipStream_t s) {
+    constexpr int NW = WM * WN;
     const bool f32out = a.out_dtype == CDET_F32;
     const bool full = a.scale || a.bias || a.res || a.act != CDET_ACT_NONE;
-    if (dgrad) {
-        if (full) { if (f32out) launch_glds<DT, WM, WN, true, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, true, EPI_FULL, false>(a, s); }
-        else      { if (f32out) launch_glds<DT, WM, WN, true, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, true, EPI_RAW, false>(a, s); }
+    if (dgrad && a.stride == 2 && NW != 8) {  // parity-decomposed stride-2 data gradient
+        if (full) { if (f32out) launch_glds<DT, WM, WN, 2, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, 2, EPI_FULL, false>(a, s); }
+        else      { if (f32out) launch_glds<DT, WM, WN, 2, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, 2, EPI_RAW, false>(a, s); }
+    } else if (dgrad) {
+        if (full) { if (f32out) launch_glds<DT, WM, WN, 1, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, 1, EPI_FULL, false>(a, s); }
+        else      { if (f32out) launch_glds<DT, WM, WN, 1, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, 1, EPI_RAW, false>(a, s); }
     } else {
-        if (full) { if (f32out) launch_glds<DT, WM, WN, false, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, false, EPI_FULL, false>(a, s); }
-        else      { if (f32out) launch_glds<DT, WM, WN, false, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, false, EPI_RAW, false>(a, s); }
+        if (full) { if (f32out) launch_glds<DT, WM, WN, 0, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, 0, EPI_FULL, false>(a, s); }
+        else      { if (f32out) launch_glds<DT, WM, WN, 0, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, 0, EPI_RAW, false>(a, s); }
     }
 }
 
@@ -807,6 +870,34 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
     a.n_pblk = div_up(a.M, cfg_bp(cfg));
     a.n_cblk = div_up(d->Cd, cfg_bc(cfg));
     const bool dg = d->mode == CDET_CONV_DGRAD;
+    for (int q = 0; q < 4; ++q) a.pc[q] = ConvArgs::ParClass{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (dg && d->stride == 2) {
+        // parity classes of the dX pixels, heaviest (most taps) first so the short ones fill the tail
+        int order[4] = {0, 1, 2, 3}, taps[4];
+        ConvArgs::ParClass c4[4];
+        for (int q = 0; q < 4; ++q) {
+            ConvArgs::ParClass& c = c4[q];
+            c.cy = q >> 1; c.cx = q & 1;
+            c.kh0 = (c.cy + d->pad) & 1; c.kw0 = (c.cx + d->pad) & 1;
+            c.nh = c.kh0 < d->kh ? (d->kh - c.kh0 + 1) / 2 : 0;
+            c.nw = c.kw0 < d->kw ? (d->kw - c.kw0 + 1) / 2 : 0;
+            if (c.nh == 0 || c.nw == 0) c.nh = c.nw = 0;
+            c.Hc = (d->Hd - c.cy + 1) / 2; c.Wc = (d->Wd - c.cx + 1) / 2;
+            c.M = d->N * c.Hc * c.Wc;
+            c.nk = div_up(c.nh * c.nw * d->Cs, BK);
+            taps[q] = c.nh * c.nw;
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j)
+                if (taps[order[j]] > taps[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+        int blk = 0;
+        for (int i = 0; i < 4; ++i) {
+            a.pc[i] = c4[order[i]];
+            a.pc[i].blk0 = blk;
+            a.pc[i].nblk = div_up(a.pc[i].M, cfg_bp(cfg)) * a.n_cblk;
+            blk += a.pc[i].nblk;
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == CDET_BF16) return launch_conv<CDET_BF16>(a, cfg, dg, s);
     return launch_conv<CDET_F16>(a, cfg, dg, s);

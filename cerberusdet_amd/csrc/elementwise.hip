@@ -446,60 +446,126 @@ __global__ __launch_bounds__(256) void pool5_kernel(uint16_t* __restrict__ buf, 
     }
 }
 
-// backward of one pool stage (gather form): din[q] += sum over windows p containing q of dout[p] * [argmax_p == q],
-// argmax_p = first maximum of window p in (ky, kx) scan order, recomputed from the saved forward slices.
+// backward of one pool stage: din[q] += sum over windows p containing q of dout[p] * [argmax_p == q], argmax_p = first
+// maximum of window p in (ky, kx) scan order, recomputed from the saved forward input slice. One block owns a 16x16 pixel
+// tile of one image for one 8-channel vector. The 24x24 input halo is decoded once into LDS (-inf outside the image, so the
+// scans need no bounds checks); the argmax is found separably (row pass: first kx per input row, column pass: first ky whose
+// row maximum is the window maximum -- identical to the row-major scan); phase 3 gathers per pixel in fixed (wy, wx) order,
+// so the result is deterministic.
 template <int DT>
 __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restrict__ buf, uint16_t* __restrict__ dbuf, int ld, int coff_in,
-                                                        int coff_out, int N, int H, int W, int CV) {
-    const int64_t total = (int64_t)N * H * W * CV;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = v / CV;
-        const int c = (int)(v - q * CV) * 8;
-        const int x = (int)(q % W);
-        const int64_t t = q / W;
-        const int y = (int)(t % H);
-        const int n = (int)(t / H);
-        const Vec8 mine = load8<DT>(buf + q * ld + coff_in + c);
-        Vec8 acc = load8<DT>(dbuf + q * ld + coff_in + c);
-        for (int wy = -2; wy <= 2; ++wy) {
-            const int py = y + wy;
-            if ((unsigned)py >= (unsigned)H) continue;
-            for (int wx = -2; wx <= 2; ++wx) {
-                const int px = x + wx;
-                if ((unsigned)px >= (unsigned)W) continue;
-                const int64_t p = ((int64_t)n * H + py) * W + px;
-                const Vec8 mx = load8<DT>(buf + p * ld + coff_out + c);
-                const Vec8 g = load8<DT>(dbuf + p * ld + coff_out + c);
-                // q wins window p for channel i iff mine == max AND no EARLIER element of the window equals the max
-                bool cand[8];
-                bool any = false;
+                                                        int coff_out, int N, int H, int W, int CV, int tiles_x, int tiles_y) {
+    __shared__ float s_in[24 * 24][8];
+    __shared__ float s_rmax[24 * 20][8];
+    __shared__ unsigned long long s_rarg[24 * 20];
+    __shared__ u32x4 s_g[20 * 20];
+    __shared__ unsigned long long s_idx[20 * 20];
+    int b = blockIdx.x;
+    const int c = (b % CV) * 8;
+    b /= CV;
+    const int x0 = (b % tiles_x) * 16;
+    b /= tiles_x;
+    const int y0 = (b % tiles_y) * 16;
+    const int n = b / tiles_y;
+    const int tid = threadIdx.x;
+    const int64_t img = (int64_t)n * H * W;
+    for (int i = tid; i < 24 * 24; i += 256) {
+        const int yy = y0 - 4 + i / 24, xx = x0 - 4 + i % 24;
+        Vec8 v;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    cand[i] = mine.v[i] == mx.v[i];
-                    any |= cand[i];
-                }
-                if (!any) continue;
-                // scan elements of window p that come before q in (ky,kx) order
-                for (int ky = -2; ky <= 2; ++ky) {
-                    const int yy = py + ky;
-                    if ((unsigned)yy >= (unsigned)H) continue;
-                    if (yy > y) break;
-                    for (int kx = -2; kx <= 2; ++kx) {
-                        const int xx = px + kx;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        if (yy == y && xx >= x) break;
-                        const Vec8 e = load8<DT>(buf + (((int64_t)n * H + yy) * W + xx) * ld + coff_in + c);
+        for (int k = 0; k < 8; ++k) v.v[k] = -INFINITY;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = load8<DT>(buf + (img + (int64_t)yy * W + xx) * ld + coff_in + c);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) cand[i] = cand[i] && !(e.v[i] == mx.v[i]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (cand[i]) acc.v[i] += g.v[i];
-            }
-        }
-        store8<DT>(dbuf + q * ld + coff_in + c, acc);
+        for (int k = 0; k < 8; ++k) s_in[i][k] = v.v[k];
     }
+    for (int i = tid; i < 20 * 20; i += 256) {
+        const int py = y0 - 2 + i / 20, px = x0 - 2 + i % 20;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W)
+            v = *reinterpret_cast<const u32x4*>(dbuf + (img + (int64_t)py * W + px) * ld + coff_out + c);
+        s_g[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 24 * 20; i += 256) {  // row pass: input row r, window column wx -> max / first kx over the 5 columns
+        const int r = i / 20, wx = i % 20;
+        float best[8];
+        unsigned arg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            best[k] = -INFINITY;
+            arg[k] = 255u;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float* e = s_in[r * 24 + wx + kx];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (e[k] > best[k]) {
+                    best[k] = e[k];
+                    arg[k] = (unsigned)kx;
+                }
+        }
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s_rmax[i][k] = best[k];
+            packed |= (unsigned long long)arg[k] << (8 * k);
+        }
+        s_rarg[i] = packed;
+    }
+    __syncthreads();
+    for (int i = tid; i < 20 * 20; i += 256) {  // column pass
+        const int wy = i / 20, wx = i % 20;
+        const int py = y0 - 2 + wy, px = x0 - 2 + wx;
+        unsigned long long packed = ~0ull;  // windows centred outside the image never match
+        if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+            float best[8];
+            unsigned arg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                best[k] = -INFINITY;
+                arg[k] = 255u;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int ri = (wy + ky) * 20 + wx;
+                const float* e = s_rmax[ri];
+                const unsigned long long ra = s_rarg[ri];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (e[k] > best[k]) {
+                        best[k] = e[k];
+                        arg[k] = (unsigned)(ky * 5) + ((unsigned)(ra >> (8 * k)) & 0xffu);
+                    }
+            }
+            packed = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) packed |= (unsigned long long)(arg[k] & 0xffu) << (8 * k);
+        }
+        s_idx[i] = packed;
+    }
+    __syncthreads();
+    const int qy = tid >> 4, qx = tid & 15;
+    const int y = y0 + qy, x = x0 + qx;
+    if (y >= H || x >= W) return;
+    uint16_t* dq = dbuf + (img + (int64_t)y * W + x) * ld + coff_in + c;
+    Vec8 acc = load8<DT>(dq);
+#pragma unroll
+    for (int wy = 0; wy < 5; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < 5; ++wx) {
+            // window centre p = q + (wy-2, wx-2); q sits at (4-wy, 4-wx) inside it
+            const int wi = (qy + wy) * 20 + qx + wx;
+            const unsigned long long idx = s_idx[wi];
+            const unsigned long long want = 0x0101010101010101ull * (unsigned long long)((4 - wy) * 5 + (4 - wx));
+            const unsigned long long diff = idx ^ want;
+            if (!((diff - 0x0101010101010101ull) & ~diff & 0x8080808080808080ull)) continue;  // no zero byte -> no channel matches
+            const Vec8 g = load8<DT>(reinterpret_cast<const uint16_t*>(&s_g[wi]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((((unsigned)(diff >> (8 * k))) & 0xffu) == 0u) acc.v[k] += g.v[k];
+        }
+    store8<DT>(dq, acc);
 }
 
 
@@ -607,7 +673,7 @@ extern "C" int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, con
 }
 
 extern "C" int cdet_bn_bwd_blocks(int64_t M) {
-    int64_t b = (M + 255) / 256;
+    int64_t b = (M + 31) / 32;  // >= 32 pixel rows per block, at most 4 blocks per CU
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
@@ -705,11 +771,12 @@ extern "C" int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, in
 extern "C" int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C,
                                   int32_t dtype, void* stream) {
     if (int e = check16("cdet_sppf_pool_bwd", dtype, C, ld, coff, 0, 0)) return e;
-    const int CV = C / 8;
+    const int CV = C / 8, tx = div_up(W, 16), ty = div_up(H, 16);
+    CDET_CHECK_ARG((int64_t)N * ty * tx * CV < (1ll << 31), "cdet_sppf_pool_bwd: grid too large");
     for (int i = 2; i >= 0; --i) {
-        DISPATCH16(dtype, hipLaunchKernelGGL((pool5_bwd_kernel<DT>), dim3(grid_for((int64_t)N * H * W * CV, 256)), dim3(256), 0,
+        DISPATCH16(dtype, hipLaunchKernelGGL((pool5_bwd_kernel<DT>), dim3((unsigned)((int64_t)N * ty * tx * CV)), dim3(256), 0,
                                              (hipStream_t)stream, (const uint16_t*)buf, (uint16_t*)dbuf, ld, coff + i * C, coff + (i + 1) * C, N, H,
-                                             W, CV));
+                                             W, CV, tx, ty));
         CDET_LAUNCH_CHECK();
     }
     return 0;

@@ -46,6 +46,8 @@ CONV_CASES = [
     (1, 8, 8, 16, 24, 3, 1, torch.bfloat16),       # tiny channels (v8n-like), Cout not a multiple of 16
     (1, 12, 12, 400, 320, 1, 1, torch.float16),    # fp16, K = 400
     (3, 10, 10, 640, 640, 3, 2, torch.bfloat16),   # large K
+    (2, 21, 17, 80, 160, 3, 2, torch.bfloat16),    # stride 2 on odd maps: the four dX parity classes have different sizes
+    (1, 14, 14, 64, 48, 1, 2, torch.bfloat16),     # 1x1 stride 2: three of the four dX parity classes receive no tap
 ]
 
 
