@@ -43,6 +43,7 @@ struct ConvArgs {
     struct ParClass {
         int cy, cx, kh0, kw0, nh, nw, Hc, Wc, M, nk, blk0, nblk;
     } pc[4];
+    unsigned x_bytes, w_bytes;  // extents of the source / packed-weight buffers (buffer-resource bounds of the pipelined kernel)
 };
 
 constexpr int BK = 64;
@@ -61,6 +62,14 @@ template <> struct Mfma<CDET_F16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+
+// in-place MFMA (accumulator tied to an AGPR tuple): the pipelined kernel touches every accumulator twice per loop iteration
+// from two differently scheduled phases, and the register allocator otherwise ping-pongs them through ~116 v_accvgpr copies
+template <int DT>
+__device__ __forceinline__ void mfma_inplace(const u32x4& a, const u32x4& b, f32x4& c) {
+    if (DT == CDET_BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
 
 template <int DT, int WAVES_M, int WAVES_N, bool DGRAD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -354,6 +363,106 @@ __device__ __forceinline__ unsigned axis_bits(int base, int K, int stride, int l
 
 constexpr int EPI_RAW = 0, EPI_FULL = 1;
 
+// BN partial statistics + store of one block's accumulators (shared by the glds kernels). PAR: the block's pixels are the
+// class-local pixels of one dX parity class and are scattered back to (2*py + cy, 2*px + cx).
+template <int DT, int WAVES_M, int WAVES_N, bool PAR, int EPI, bool OUT_F32>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[5][4], unsigned char* smem, int t, int wm, int wn, int frow, int fk,
+                                              int p0, int c0, int pblk, int Mloc, int gH, int gW, int cy, int cx) {
+    constexpr int BC = 80 * WAVES_N;
+    // ---- BN statistics of the raw convolution (train mode) --------------------------------------------------------------
+    if (a.stats != nullptr) {
+        float* st = reinterpret_cast<float*>(smem);  // [WAVES_M][2][BC]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            f32x4 s = acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+            f32x4 q = acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1] + acc[i][2] * acc[i][2] + acc[i][3] * acc[i][3];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[r] += __shfl_xor(s[r], m);
+                    q[r] += __shfl_xor(q[r], m);
+                }
+            }
+            if (frow == 0) {
+                const int cl = wn * 80 + i * 16 + fk * 4;
+                *reinterpret_cast<f32x4*>(st + (wm * 2 + 0) * BC + cl) = s;
+                *reinterpret_cast<f32x4*>(st + (wm * 2 + 1) * BC + cl) = q;
+            }
+        }
+        __syncthreads();
+        if (t < BC && c0 + t < a.Cd) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int m = 0; m < WAVES_M; ++m) {
+                sv += st[(m * 2 + 0) * BC + t];
+                qv += st[(m * 2 + 1) * BC + t];
+            }
+            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+    int64_t obase[4];
+    int64_t rbase[4];
+    bool pvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int p = p0 + wm * 64 + j * 16 + frow;
+        pvalid[j] = p < Mloc;
+        if (PAR) {  // class pixel -> dX pixel
+            const int hw = gH * gW;
+            const int n = p / hw;
+            const int rem = p - n * hw;
+            const int py = rem / gW;
+            const int px = rem - py * gW;
+            p = (n * a.Hd + 2 * py + cy) * a.Wd + 2 * px + cx;
+        }
+        obase[j] = (int64_t)p * a.dst_ld + a.dst_coff;
+        rbase[j] = (int64_t)p * a.res_ld + a.res_coff;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int co = c0 + wn * 80 + i * 16 + fk * 4;
+        if (co >= a.Cd) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_FULL) {
+            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + co);
+            if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + co);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!pvalid[j]) continue;
+            f32x4 v = acc[i][j];
+            if (EPI == EPI_FULL) {
+                v = v * sc + bi;
+                if (a.act == CDET_ACT_SILU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+                }
+                if (a.res) {
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + rbase[j] + co);
+                    v[0] += Elem<DT>::to_f32((uint16_t)(rv[0] & 0xffff));
+                    v[1] += Elem<DT>::to_f32((uint16_t)(rv[0] >> 16));
+                    v[2] += Elem<DT>::to_f32((uint16_t)(rv[1] & 0xffff));
+                    v[3] += Elem<DT>::to_f32((uint16_t)(rv[1] >> 16));
+                }
+            }
+            if (OUT_F32) {
+                float* yp = reinterpret_cast<float*>(a.y) + obase[j] + co;
+                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
+                *reinterpret_cast<f32x4*>(yp) = v;
+            } else {
+                u32x2 pk;
+                pk[0] = pack2<DT>(v[0], v[1]);
+                pk[1] = pack2<DT>(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.y) + obase[j] + co) = pk;
+            }
+        }
+    }
+}
+
 // 8-wave instantiation (<4,2>: 256 pixels x 160 couts, 512 threads, ONE workgroup per CU): three LDS stages (3 x 52 KiB = 156 KiB of
 // the CU's 160 KiB) and a counted-vmcnt pipeline -- the DMA of K step t+2 is issued while step t is computed and step t+1 is
 // still in flight; a wave only waits for ITS OWN pieces of step t (`s_waitcnt vmcnt(pieces of one step)`), then one raw
@@ -607,98 +716,266 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         }
     }
 
-    // ---- BN statistics of the raw convolution (train mode) --------------------------------------------------------------
-    if (a.stats != nullptr) {
-        float* st = reinterpret_cast<float*>(smem);  // [WAVES_M][2][BC]
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            f32x4 s = acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-            f32x4 q = acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1] + acc[i][2] * acc[i][2] + acc[i][3] * acc[i][3];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[r] += __shfl_xor(s[r], m);
-                    q[r] += __shfl_xor(q[r], m);
-                }
-            }
-            if (frow == 0) {
-                const int cl = wn * 80 + i * 16 + fk * 4;
-                *reinterpret_cast<f32x4*>(st + (wm * 2 + 0) * BC + cl) = s;
-                *reinterpret_cast<f32x4*>(st + (wm * 2 + 1) * BC + cl) = q;
-            }
-        }
-        __syncthreads();
-        if (t < BC && c0 + t < a.Cd) {
-            float sv = 0.f, qv = 0.f;
-#pragma unroll
-            for (int m = 0; m < WAVES_M; ++m) {
-                sv += st[(m * 2 + 0) * BC + t];
-                qv += st[(m * 2 + 1) * BC + t];
-            }
-            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
-            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
-        }
-    }
+    conv_epilogue<DT, WAVES_M, WAVES_N, PAR, EPI, OUT_F32>(a, acc, smem, t, wm, wn, frow, fk, p0, c0, pblk, Mloc, gH, gW, cy, cx);
+}
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------------
-    int64_t obase[4];
-    int64_t rbase[4];
-    bool pvalid[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int p = p0 + wm * 64 + j * 16 + frow;
-        pvalid[j] = p < Mloc;
-        if (PAR) {  // class pixel -> dX pixel
-            const int hw = gH * gW;
-            const int n = p / hw;
-            const int rem = p - n * hw;
-            const int py = rem / gW;
-            const int px = rem - py * gW;
-            p = (n * a.Hd + 2 * py + cy) * a.Wd + 2 * px + cx;
-        }
-        obase[j] = (int64_t)p * a.dst_ld + a.dst_coff;
-        rbase[j] = (int64_t)p * a.res_ld + a.res_coff;
+// ================================================================================================
+// v3: software-pipelined variant of the glds kernel (same tiles, same LDS image, same epilogue).
+// What the ISA of v2 showed (rocprofv3 PMC: MFMA busy 32 % of SIMD cycles on the dominant layer; L2 latency 290 cycles, TLB
+// misses nil): per K step a wave ran [~150 branchy address instructions + 9 DMA] -> [9 ds_read, wait] -> [20 MFMA] ->
+// [9 ds_read, wait] -> [20 MFMA] -> [vmcnt(0), barrier], i.e. nothing of its own overlapped the MFMAs.  Here:
+//   * operands are fetched with buffer_load_dwordx4 ... lds through buffer resources: one 32-bit byte offset per piece,
+//     out-of-range offsets (padding taps, rows beyond Cout, steps beyond K) return zeros -> no zero page, no 64-bit address
+//     math, no branches: the whole K step is ONE basic block;
+//   * K cursors advance branch-free (needs Cs >= 64: at most one tap boundary per 64-wide step);
+//   * the step is split in two phases around the single barrier, with the fragments double-buffered in registers:
+//       A: ds_read fragments (ks, k32 #1) || MFMA on fragments (ks, k32 #0)
+//          s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier     -- tile ks+1 complete, nobody reads buffer `cur` any more
+//       B: DMA of tile ks+2 into `cur`  ||  ds_read fragments (ks+1, k32 #0)  ||  MFMA on fragments (ks, k32 #1)
+//     sched_group_barrier pins the interleave (1 MFMA : 1 DS read : 1 DMA) so the memory instructions issue in the
+//     shadow of the 16-cycle MFMAs.
+// ================================================================================================
+__device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t r, int voff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+// ABL (timing experiments only, results are wrong): 1 = no DMA in the K loop, 2 = no fragment reads, 4 = no MFMA (bits combine)
+template <int DT, int WAVES_M, int WAVES_N, int MODE, int EPI, bool OUT_F32, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_pipe_kernel(const ConvArgs a) {
+    constexpr bool DGRAD = MODE != 0;
+    constexpr bool PAR = MODE == 2;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BP = 64 * WAVES_M;
+    constexpr int BC = 80 * WAVES_N;
+    constexpr int XI = BP / (8 * NW);
+    constexpr int WI_TOTAL = BC / 8;
+    constexpr int WI = (WI_TOTAL + NW - 1) / NW;
+    constexpr int NV = XI + WI;  // DMA instructions per wave per K step
+    constexpr int NS = NW == 8 ? 3 : 2;  // LDS stages: the 8-wave tile owns the CU (3 x 52 KiB) and prefetches two K steps ahead
+    constexpr int STAGE = (BP + BC) * ROW_BYTES;
+    constexpr int SENT = (int)0xfffffff0u;  // byte offset beyond every buffer -> the load returns zeros
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    int cls = 0;
+    if (PAR) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int co = c0 + wn * 80 + i * 16 + fk * 4;
-        if (co >= a.Cd) continue;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (EPI == EPI_FULL) {
-            if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + co);
-            if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + co);
-        }
+        for (int q = 1; q < 4; ++q)
+            if (L >= a.pc[q].blk0) cls = q;
+        L -= a.pc[cls].blk0;
+    }
+    const int cy = PAR ? a.pc[cls].cy : 0, cx = PAR ? a.pc[cls].cx : 0;
+    const int kh0 = PAR ? a.pc[cls].kh0 : 0, kw0 = PAR ? a.pc[cls].kw0 : 0;
+    const int tapsH = PAR ? a.pc[cls].nh : a.KH;
+    const int tapsW = PAR ? a.pc[cls].nw : a.KW;
+    const int ntap = tapsH * tapsW;
+    const int gH = PAR ? a.pc[cls].Hc : a.Hd, gW = PAR ? a.pc[cls].Wc : a.Wd;
+    const int Mloc = PAR ? a.pc[cls].M : a.M;
+    const int nk = PAR ? a.pc[cls].nk : a.nk;
+    const int cblk = L % a.n_cblk;
+    const int pblk = L / a.n_cblk;
+    const int p0 = pblk * BP;
+    const int c0 = cblk * BC;
+
+    const int slot = lane & 7;
+    const int lr = lane >> 3;
+    const int ldB = a.src_ld * 2;
+    // ---- X rows owned by this thread (byte offsets of tap (0,0), validity bit per tap) -----------------------------------
+    int rowoffB[XI];
+    unsigned tapmask[XI];
+    {
+        int p = p0 + wave * (8 * XI) + lr;
+        const int hw = gH * gW;
+        int n = p / hw;
+        int rem = p - n * hw;
+        int py = rem / gW;
+        int px = rem - py * gW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!pvalid[j]) continue;
-            f32x4 v = acc[i][j];
-            if (EPI == EPI_FULL) {
-                v = v * sc + bi;
-                if (a.act == CDET_ACT_SILU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+        for (int j = 0; j < XI; ++j) {
+            rowoffB[j] = 0;
+            tapmask[j] = 0u;
+            if (p < Mloc) {
+                int oy, ox;
+                unsigned rb = 0u, cb = 0u;
+                if (PAR) {
+                    oy = (2 * py + cy + a.pad - kh0) >> 1;
+                    ox = (2 * px + cx + a.pad - kw0) >> 1;
+                } else if (DGRAD) {  // stride 1
+                    oy = py + a.pad;
+                    ox = px + a.pad;
+                } else {
+                    oy = py * a.stride - a.pad;
+                    ox = px * a.stride - a.pad;
                 }
-                if (a.res) {
-                    const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + rbase[j] + co);
-                    v[0] += Elem<DT>::to_f32((uint16_t)(rv[0] & 0xffff));
-                    v[1] += Elem<DT>::to_f32((uint16_t)(rv[0] >> 16));
-                    v[2] += Elem<DT>::to_f32((uint16_t)(rv[1] & 0xffff));
-                    v[3] += Elem<DT>::to_f32((uint16_t)(rv[1] >> 16));
+                for (int k = 0; k < tapsH; ++k)
+                    if ((unsigned)(DGRAD ? oy - k : oy + k) < (unsigned)a.Hs) rb |= 1u << k;
+                for (int k = 0; k < tapsW; ++k)
+                    if ((unsigned)(DGRAD ? ox - k : ox + k) < (unsigned)a.Ws) cb |= 1u << k;
+                unsigned m = 0u;
+                for (int k = 0; k < tapsH; ++k)
+                    if ((rb >> k) & 1u) m |= cb << (k * tapsW);
+                tapmask[j] = m;
+                rowoffB[j] = (((n * a.Hs + oy) * a.Ws + ox) * a.src_ld + a.src_coff) * 2;
+            }
+            p += 8;
+            px += 8;
+            while (px >= gW) {
+                px -= gW;
+                if (++py == gH) {
+                    py = 0;
+                    ++n;
                 }
             }
-            if (OUT_F32) {
-                float* yp = reinterpret_cast<float*>(a.y) + obase[j] + co;
-                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(yp);
-                *reinterpret_cast<f32x4*>(yp) = v;
+        }
+    }
+    // ---- two K cursors (even / odd row groups differ in bit 2 of the swizzle); Cs >= 64 -> they start inside tap 0 ------
+    const int sw0 = ((wave * (8 * XI) + lr) >> 1) & 7;
+    const int CsB = a.Cs * 2;
+    const int sgn = DGRAD ? -1 : 1;
+    const int dTap = sgn * ldB - CsB;                               // cursor crosses into the next tap of the same kernel row
+    const int dRow = sgn * (a.Ws - (tapsW - 1)) * ldB - CsB;        // ... into the first tap of the next kernel row
+    const int wTap = PAR ? CsB : 0;                                 // parity mode: packed-row offset skips one tap
+    const int wRow = PAR ? ((2 * a.KW - 2 * (tapsW - 1)) * a.Cs - a.Cs) * 2 : 0;
+    int kc[2], ktap[2], kkw[2], toffB[2], wkB[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int kv = slot ^ sw0 ^ (c ? 4 : 0);
+        kc[c] = kv * 8;
+        ktap[c] = 0;
+        kkw[c] = 0;
+        toffB[c] = kv * 16;
+        wkB[c] = ((kh0 * a.KW + kw0) * a.Cs + kv * 8) * 2;
+    }
+    // ---- W pieces: row group wi = wave + NW*j (a wave without a last group repeats its previous one: same data, same place)
+    int woffB[WI];
+    int wdst[WI];
+    int wcur[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        int wi = wave + NW * j;
+        if (wi >= WI_TOTAL) wi -= NW;
+        const int r = 8 * wi + lr;
+        const int co = c0 + r;
+        const int kv = slot ^ ((r >> 1) & 7);
+        woffB[j] = co * a.Kpad * 2 + (PAR ? 0 : kv * 16);  // rows >= Cd lie beyond w_bytes -> zeros
+        wdst[j] = 8 * wi * ROW_BYTES;
+        wcur[j] = (wi ^ (wave * XI)) & 1;
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);  // empty: every load is zero
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);
+
+    // one DMA instruction of the K step the cursors point at: pieces 0..XI-1 are X row groups, XI..NV-1 W row groups
+    auto dma_piece = [&](int idx, int buf, bool live) {
+        unsigned char* xs = smem + buf * STAGE;
+        unsigned char* wsm = xs + BP * ROW_BYTES;
+        if (idx < XI) {
+            const int j = idx, c = j & 1;
+            const bool ok = (tapmask[j] >> ktap[c]) & 1u;
+            bufload_lds16(live ? rs_x : rs_x0, ok ? rowoffB[j] + toffB[c] : SENT, xs + (wave * (8 * XI) + 8 * j) * ROW_BYTES);
+        } else {
+            const int j = idx - XI;
+            int voff;
+            if (PAR) {
+                const int c = wcur[j];
+                voff = ktap[c] < ntap ? woffB[j] + wkB[c] : SENT;
             } else {
-                u32x2 pk;
-                pk[0] = pack2<DT>(v[0], v[1]);
-                pk[1] = pack2<DT>(v[2], v[3]);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.y) + obase[j] + co) = pk;
+                voff = woffB[j];
+                woffB[j] += 2 * BK;
             }
+            bufload_lds16(live ? rs_w : rs_w0, voff, wsm + wdst[j]);
         }
+    };
+    auto advance = [&](int c) {
+        kc[c] += BK;
+        const bool wrap = kc[c] >= a.Cs;
+        kc[c] -= wrap ? a.Cs : 0;
+        ktap[c] += wrap ? 1 : 0;
+        kkw[c] += wrap ? 1 : 0;
+        const bool roww = kkw[c] == tapsW;
+        kkw[c] = roww ? 0 : kkw[c];
+        toffB[c] += 2 * BK + (wrap ? (roww ? dRow : dTap) : 0);
+        if (PAR) wkB[c] += 2 * BK + (wrap ? (roww ? wRow : wTap) : 0);
+    };
+    auto stage = [&](int buf, bool live) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dma_piece(i, buf, live);
+        advance(0);
+        advance(1);
+    };
+
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+
+    // fragment r of a k32 half: r < 5 -> weight rows (A operand), else pixel rows (B operand)
+    auto frag1 = [&](int buf, int kk, int r, u32x4 (&af)[5], u32x4 (&bf)[4]) {
+        const unsigned char* Xs = smem + buf * STAGE;
+        const unsigned char* Wsm = Xs + BP * ROW_BYTES;
+        if (r < 5) af[r] = *reinterpret_cast<const u32x4*>(Wsm + lds_slot(wn * 80 + r * 16 + frow, kk * 4 + fk));
+        else bf[r - 5] = *reinterpret_cast<const u32x4*>(Xs + lds_slot(wm * 64 + (r - 5) * 16 + frow, kk * 4 + fk));
+    };
+    // read order: the first MFMAs of the next phase need A row 0 and all four B rows
+    constexpr int RORD[9] = {0, 5, 6, 7, 8, 1, 2, 3, 4};
+
+    u32x4 a0[5], b0[4], a1[5], b1[4];
+    stage(0, true);
+    if (NS == 3) stage(1, nk > 1);
+    __syncthreads();
+    stage(NS - 1, nk > NS - 1);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) frag1(0, 0, r, a0, b0);
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int nxt = cur + 1 == NS ? 0 : cur + 1;
+        const bool live = ks + NS < nk;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase A: MFMA on (ks, k32 #0) with the fragment reads of (ks, k32 #1) in their shadow ----
+#pragma unroll
+        for (int idx = 0; idx < 20; ++idx) {
+            if (!(ABL & 4)) mfma_inplace<DT>(a0[idx >> 2], b0[idx & 3], acc[idx >> 2][idx & 3]);
+            if (!(ABL & 2) && (idx & 1) == 0 && (idx >> 1) < 9) frag1(cur, 1, RORD[idx >> 1], a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // tile ks+1 landed for every wave (with 3 stages the NV pieces of tile ks+2 may stay in flight); buffer `cur` is free
+        if (NS == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: MFMA on (ks, k32 #1); DMA of tile ks+NS and fragment reads of (ks+1, k32 #0) in their shadow ----
+#pragma unroll
+        for (int idx = 0; idx < 20; ++idx) {
+            if (!(ABL & 4)) mfma_inplace<DT>(a1[idx >> 2], b1[idx & 3], acc[idx >> 2][idx & 3]);
+            if (!(ABL & 1) && idx < NV) dma_piece(idx, cur, live);
+            if (idx == NV) advance(0);
+            if (idx == NV + 1) advance(1);
+            if (!(ABL & 2) && idx >= 20 - 9 - 1 && idx < 20 - 1) frag1(nxt, 0, RORD[idx - (20 - 9 - 1)], a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to the hazard recogniser: let the last ones retire before acc is read
+    __syncthreads();  // drains the (empty) trailing DMA before LDS is reused below
+
+    conv_epilogue<DT, WAVES_M, WAVES_N, PAR, EPI, OUT_F32>(a, acc, smem, t, wm, wn, frow, fk, p0, c0, pblk, Mloc, gH, gW, cy, cx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -731,7 +1008,7 @@ static int conv_impl() {
     static int impl = -1;
     if (impl < 0) {
         const char* e = getenv("CDET_CONV_IMPL");
-        impl = e ? atoi(e) : 2;
+        impl = e ? atoi(e) : 3;  // 1 = register-staged v1, 2 = global_load_lds v2, 3 = v2 tiles + software-pipelined K loop (v3)
     }
     return impl;
 }
@@ -740,12 +1017,43 @@ template <int DT, int WM, int WN, int DG, int EPI, bool F32>
 static void launch_glds(const ConvArgs& a, hipStream_t s) {
     constexpr int BP = 64 * WM, BC = 80 * WN, NW = WM * WN;
     const size_t lds = (size_t)(NW == 8 ? 3 : 2) * (BP + BC) * ROW_BYTES;
+    const int nblocks = DG == 2 ? a.pc[3].blk0 + a.pc[3].nblk : a.n_pblk * a.n_cblk;
+    // pipelined variant: one tap boundary per K step at most (Cs >= 64), buffer-resource bounds fit 32 bits; stride-2 dgrad only as parity classes
+    const bool pipe = conv_impl() >= 3 && a.Cs >= BK && a.x_bytes != 0 && !(DG == 1 && a.stride != 1);
+    if (pipe) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)conv_igemm_pipe_kernel<DT, WM, WN, DG, EPI, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr3 = true;
+        }
+        if constexpr (DT == CDET_BF16 && WM == 2 && WN == 2 && DG == 0 && EPI == EPI_RAW && !F32) {
+            static int abl = -1;
+            if (abl < 0) {
+                const char* e = getenv("CDET_CONV_ABLATE");
+                abl = e ? atoi(e) : 0;
+            }
+            if (abl) {
+#define CDET_ABL_CASE(N)                                                                                                                       \
+    case N:                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)conv_igemm_pipe_kernel<DT, WM, WN, DG, EPI, F32, N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                                                   \
+        hipLaunchKernelGGL((conv_igemm_pipe_kernel<DT, WM, WN, DG, EPI, F32, N>), dim3(nblocks), dim3(64 * NW), lds, s, a);                      \
+        return;
+                switch (abl) {
+                    CDET_ABL_CASE(1) CDET_ABL_CASE(2) CDET_ABL_CASE(3) CDET_ABL_CASE(4) CDET_ABL_CASE(5) CDET_ABL_CASE(6) CDET_ABL_CASE(7)
+                    default: break;
+                }
+#undef CDET_ABL_CASE
+            }
+        }
+        hipLaunchKernelGGL((conv_igemm_pipe_kernel<DT, WM, WN, DG, EPI, F32>), dim3(nblocks), dim3(64 * NW), lds, s, a);
+        return;
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const int nblocks = DG == 2 ? a.pc[3].blk0 + a.pc[3].nblk : a.n_pblk * a.n_cblk;
     hipLaunchKernelGGL((conv_igemm_glds_kernel<DT, WM, WN, DG, EPI, F32>), dim3(nblocks), dim3(64 * NW), lds, s, a);
 }
 
@@ -754,7 +1062,7 @@ static void launch_glds_variant(const ConvArgs& a, bool dgrad, hipStream_t s) {
     constexpr int NW = WM * WN;
     const bool f32out = a.out_dtype == CDET_F32;
     const bool full = a.scale || a.bias || a.res || a.act != CDET_ACT_NONE;
-    if (dgrad && a.stride == 2 && NW != 8) {  // parity-decomposed stride-2 data gradient
+    if (dgrad && a.stride == 2) {  // parity-decomposed stride-2 data gradient
         if (full) { if (f32out) launch_glds<DT, WM, WN, 2, EPI_FULL, true>(a, s); else launch_glds<DT, WM, WN, 2, EPI_FULL, false>(a, s); }
         else      { if (f32out) launch_glds<DT, WM, WN, 2, EPI_RAW, true>(a, s);  else launch_glds<DT, WM, WN, 2, EPI_RAW, false>(a, s); }
     } else if (dgrad) {
@@ -774,7 +1082,7 @@ static int pick_cfg(int Cd, int64_t M) {
         const char* e = getenv("CDET_CONV_DEEP");
         deep = e ? atoi(e) : 0;  // measured on MI355X: 0.129 vs 0.127 ms (40x40 320->320), 0.163 vs 0.144 ms (80x80 160->160): off by default
     }
-    return (deep && conv_impl() == 2 && M >= 4096) ? 2 : 1;
+    return (deep && conv_impl() >= 2 && M >= 4096) ? 2 : 1;
 }
 static inline int cfg_bp(int cfg) { return cfg == 1 ? 128 : (cfg == 0 ? 192 : 256); }  // cfg 0: 3 waves x 64 px (2 x 69 KB LDS -> 2 WGs per CU)
 static inline int cfg_bc(int cfg) { return (cfg == 0 || cfg == 3) ? 80 : 160; }
@@ -785,7 +1093,7 @@ static int launch_conv(const ConvArgs& a, int cfg, bool dgrad, hipStream_t s) {
     const bool fits32 = (int64_t)a.N * a.Hs * a.Ws * a.src_ld < (1ll << 31);
     const bool f32out = a.out_dtype == CDET_F32;
     const bool same16 = (a.out_dtype == CDET_BF16 && DT == CDET_BF16) || (a.out_dtype == CDET_F16 && DT == CDET_F16);
-    if (cfg != 3 && conv_impl() == 2 && fits32 && (f32out || same16)) {
+    if (cfg != 3 && conv_impl() >= 2 && fits32 && (f32out || same16)) {
         if (cfg == 0) launch_glds_variant<DT, 3, 1>(a, dgrad, s);
         else if (cfg == 1) launch_glds_variant<DT, 2, 2>(a, dgrad, s);
         else launch_glds_variant<DT, 4, 2>(a, dgrad, s);
@@ -811,7 +1119,7 @@ static inline int cfg_of(const cdet_conv_desc* d) {
     const bool f32out = d->out_dtype == CDET_F32;
     const bool same16 = d->out_dtype == d->dtype;
     if (cfg == 2 && !(fits32 && (f32out || same16))) cfg = 1;  // the deep variant only exists in the glds family
-    if (cfg == 0 && !(conv_impl() == 2 && fits32 && (f32out || same16))) cfg = 3;  // legacy register-staged <4,1> kernel: 256-px tiles
+    if (cfg == 0 && !(conv_impl() >= 2 && fits32 && (f32out || same16))) cfg = 3;  // legacy register-staged <4,1> kernel: 256-px tiles
     return cfg;
 }
 
@@ -870,6 +1178,12 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
     a.n_pblk = div_up(a.M, cfg_bp(cfg));
     a.n_cblk = div_up(d->Cd, cfg_bc(cfg));
     const bool dg = d->mode == CDET_CONV_DGRAD;
+    {
+        const int64_t xb = (int64_t)d->N * d->Hs * d->Ws * d->src_ld * 2, wb = (int64_t)d->Cd * a.Kpad * 2;
+        const bool ok = xb < 0xfffffff0ll - 256 && wb < 0xfffffff0ll - 65536;
+        a.x_bytes = ok ? (unsigned)xb : 0u;  // 0 -> the pipelined kernel is not used
+        a.w_bytes = ok ? (unsigned)wb : 0u;
+    }
     for (int q = 0; q < 4; ++q) a.pc[q] = ConvArgs::ParClass{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (dg && d->stride == 2) {
         // parity classes of the dX pixels, heaviest (most taps) first so the short ones fill the tail

@@ -597,12 +597,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const uint16_t* __r
     }
 }
 
+// 16 channels x 16 partial-row groups per workgroup, fixed summation order (same shape as bn_bwd_sums_kernel)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblk, int C, int C_out, float* out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C_out) return;
+    __shared__ double sh[16][16];
+    const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * C + c];
-    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+    if (c < C_out)
+        for (int b = g; b < nblk; b += 16) s += (double)part[(int64_t)b * C + c];
+    sh[g][cx] = s;
+    __syncthreads();
+    if (g == 0 && c < C_out) {
+        s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sh[k][cx];
+        out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+    }
 }
 
 // NCHW image (uint8 scaled by 1/255, or float) -> NHWC with the 3 channels padded to 8 (16-byte pixels), 16-bit: lets the stem
@@ -792,7 +802,7 @@ extern "C" int cdet_colsum(const void* src, int32_t ld, int32_t coff, int64_t M,
     DISPATCH16(dtype, hipLaunchKernelGGL((colsum_partial_kernel<DT>), dim3(nblk), dim3(256), shm, (hipStream_t)stream, (const uint16_t*)src, ld, coff,
                                          part, M, C, CV));
     CDET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(div_up(C_out, 256)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, C_out, out, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(div_up(C_out, 16)), dim3(256), 0, (hipStream_t)stream, part, nblk, C, C_out, out, accumulate);
     CDET_LAUNCH_CHECK();
     return 0;
 }
