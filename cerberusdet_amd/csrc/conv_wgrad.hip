@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const WgradArgs a,
 
     // ---- X instructions of this wave: instruction i covers pixel rows (wave*XI + i)*RPP + lane/XV, physical slot lane%XV ----
     const int xslot = lane % XV, xrl = lane / XV;
-    int vsy[NVAR], vsx[NVAR], vconst[NVAR];  // per swizzle phase: tap offsets and the constant byte offset; vconst < 0 -> k column beyond K
+    // per swizzle phase: tap offsets (rows / columns / source pixels) and the constant byte offset; vconst < 0 -> k column beyond K
+    int vsy[NVAR], vsx[NVAR], vtap[NVAR], vconst[NVAR];
 #pragma unroll
     for (int c = 0; c < NVAR; ++c) {
         const int rowbits = ((wave * XI + c) * RPP + xrl) & 7;  // (row & 7) of every instruction i with i % NVAR == c
@@ -337,19 +338,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const WgradArgs a,
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
         vsy[c] = kh - a.pad;
         vsx[c] = kw - a.pad;
+        vtap[c] = (kh - a.pad) * a.Ws + kw - a.pad;
         vconst[c] = kcol < a.Ktot ? (a.src_coff + ci) * 2 : -1;
     }
-    int rn[XI], roy[XI], rox[XI], rp[XI];
+    // running state of each instruction's pixel: linear output pixel rp, source row / column of tap (pad, pad) and the linear
+    // source pixel spix of that tap; all advance by 64 output pixels per step with at most one carry per axis
+    int rp[XI], rsy[XI], rsx[XI], spix[XI];
     {
         const int hw = a.Hd * a.Wd;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int p = p_begin + (wave * XI + i) * RPP + xrl;
             const int n = p / hw, rem = p - n * hw;
+            const int oy = rem / a.Wd, ox = rem - oy * a.Wd;
             rp[i] = p;
-            rn[i] = n;
-            roy[i] = rem / a.Wd;
-            rox[i] = rem - roy[i] * a.Wd;
+            rsy[i] = oy * a.stride;
+            rsx[i] = ox * a.stride;
+            spix[i] = (n * a.Hs + rsy[i]) * a.Ws + rsx[i];
         }
     }
     // 64 pixels = an images + ay rows + ax pixels
@@ -357,6 +362,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const WgradArgs a,
     const int ay = (WKP - an * a.Hd * a.Wd) / a.Wd;
     const int ax = WKP - an * a.Hd * a.Wd - ay * a.Wd;
     const int ldB = a.src_ld * 2;
+    const int dsx = ax * a.stride, dsy = ay * a.stride;
+    const int limx = a.Wd * a.stride, limy = a.Hd * a.stride;           // wrap limits of rsx / rsy
+    const int dS = (an * a.Hs + dsy) * a.Ws + dsx;                       // source-pixel advance without carries
+    const int dCx = a.stride * a.Ws - limx;                              // column carry: next output row, column - Wd
+    const int dCy = a.Hs * a.Ws - limy * a.Ws;                           // row carry: next image, row - Hd
 
     // ---- dY instructions: vector v = (wave*YI + i)*64 + lane of the step's 64 x YV vectors (a wave without a last one repeats)
     int yoff[YI], ystep[YI], ydst[YI];
@@ -382,19 +392,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const WgradArgs a,
         unsigned char* ys = xs + WKP * XROW;
         if (idx < XI) {
             const int i = idx, c = i % NVAR;
-            const int sy = roy[i] * a.stride + vsy[c], sx = rox[i] * a.stride + vsx[c];
-            const bool ok = vconst[c] >= 0 && rp[i] < a.P && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-            const int off = ((rn[i] * a.Hs + sy) * a.Ws + sx) * ldB + vconst[c];
+            const int sy = rsy[i] + vsy[c], sx = rsx[i] + vsx[c];
+            const bool ok = (vconst[c] >= 0) & (rp[i] < a.P) & ((unsigned)sy < (unsigned)a.Hs) & ((unsigned)sx < (unsigned)a.Ws);
+            const int off = (int)(__umul24((unsigned)(spix[i] + vtap[c]), (unsigned)ldB) + (unsigned)vconst[c]);
             bufload_lds16_w(live ? rs_x : rs_x0, ok ? off : SENT, xs + (wave * XI + i) * 1024);
             // advance this instruction's pixel by 64
             rp[i] += WKP;
-            rox[i] += ax;
-            const bool cx = rox[i] >= a.Wd;
-            rox[i] -= cx ? a.Wd : 0;
-            roy[i] += ay + (cx ? 1 : 0);
-            const bool cyw = roy[i] >= a.Hd;
-            roy[i] -= cyw ? a.Hd : 0;
-            rn[i] += an + (cyw ? 1 : 0);
+            rsx[i] += dsx;
+            const bool cx = rsx[i] >= limx;
+            rsx[i] -= cx ? limx : 0;
+            rsy[i] += dsy + (cx ? a.stride : 0);
+            const bool cyw = rsy[i] >= limy;
+            rsy[i] -= cyw ? limy : 0;
+            spix[i] += dS + (cx ? dCx : 0) + (cyw ? dCy : 0);
         } else {
             const int i = idx - XI;
             bufload_lds16_w(live ? rs_y : rs_y0, yoff[i], ys + ydst[i]);
@@ -550,22 +560,23 @@ static WgradPlan plan_wgrad(const cdet_conv_desc* d) {
     p.Cd_pad = p.n_cblk * p.BCO;
     const int64_t P = (int64_t)d->N * d->Hd * d->Wd;
     const int tiles = p.n_kblk * p.n_cblk;
-    // aim at ~4 workgroups per CU (1024 on MI355X) but keep >= 256 pixels per split
-    // 2 workgroups fit a CU (LDS + 183 VGPRs) -> 512 slots. Every split costs a full fp32 slab write + re-read, so fewer, longer
-    // splits win over perfect wave quantisation (measured: 46 tiles x 16 splits 0.186 ms vs x 22 splits 0.224 ms): aim at ~768
-    // workgroups with at least 512 pixels per split and at most 128 MB of partial slabs
-    int S = (768 + tiles / 2) / tiles;
-    const int maxS = (int)((P + 511) / 512);
+    // 2 workgroups fit a CU -> 512 resident slots. Every split costs a full fp32 slab write + re-read and a partly filled second
+    // round costs a whole round, so: the largest split count (multiple of 8 for the XCD mapping, or 4 / 2 / 1) whose grid still fits
+    // ONE round. Measured per task pass with the pipelined kernel: target 768 workgroups 15.9 ms, 576 16.7 (spills into a second
+    // round on the 12-tile layers), 512 14.4, 448 14.0, 256 20.9.
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("CDET_WGRAD_TARGET");
+        target = e ? atoi(e) : 512;
+    }
+    int S = target / tiles;
+    const int maxS = (int)((P + 511) / 512);  // at least 512 pixels per split
     if (S > maxS) S = maxS;
     const int64_t slab = (int64_t)p.Cd_pad * p.Kp * 4;
-    const int capS = (int)((128ll << 20) / slab);
+    const int capS = (int)((128ll << 20) / slab);  // at most 128 MB of partial slabs
     if (S > capS) S = capS;
-    if (S < 1) S = 1;
-    // the XCD-aware mapping gives split s to XCD s % 8: S must be a multiple of 8 (or 1, 2, 4) or one XCD gets an extra split
-    // (measured: S = 17 -> 0.222 ms vs S = 16 -> 0.186 ms on the dominant shape)
-    if (S >= 8) S = (S + 4) / 8 * 8;
+    if (S >= 8) S = S / 8 * 8;
     else S = S >= 4 ? 4 : (S >= 2 ? 2 : 1);
-    while (S > 8 && (S > maxS || S > capS)) S -= 8;
     int chunk = (int)((P + S - 1) / S);
     chunk = (chunk + WKP - 1) / WKP * WKP;
     p.S = S;
@@ -586,7 +597,8 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     const int64_t xb = (int64_t)a.N * a.Hs * a.Ws * a.src_ld * 2, yb = (int64_t)a.P * a.dy_ld * 2;
     // (the 256 x 80 tile measured slower with the pipelined kernel: 0.342 vs 0.269 ms on 160x160 80->80 -- twice the X DMA instructions
     //  per wave; it keeps the register-staged kernel)
-    if (wgrad_impl() >= 3 && WC == 2 && abl == 0 && xb < 0xfffffff0ll - 256 && yb < 0xfffffff0ll - 256) {
+    const bool pix24 = (int64_t)a.N * a.Hs * a.Ws < (1 << 24) - 65536;  // v_mad_u32_u24 addressing of the source pixels
+    if (wgrad_impl() >= 3 && WC == 2 && abl == 0 && pix24 && xb < 0xfffffff0ll - 256 && yb < 0xfffffff0ll - 256) {
         constexpr int lds3 = 2 * WKP * (BKC * 2 + BCO * 2);
         static bool attr = false;
         if (!attr) {
