@@ -363,6 +363,17 @@ __device__ __forceinline__ unsigned axis_bits(int base, int K, int stride, int l
 
 constexpr int EPI_RAW = 0, EPI_FULL = 1;
 
+// sum over the 16 lanes of a DPP row; every lane ends up with the total
+__device__ __forceinline__ float dpp_sum16(float v) {
+#define CDET_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    CDET_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    CDET_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    CDET_DPP_ADD(0x141);  // row_half_mirror
+    CDET_DPP_ADD(0x140);  // row_mirror
+#undef CDET_DPP_ADD
+    return v;
+}
+
 // BN partial statistics + store of one block's accumulators (shared by the glds kernels). PAR: the block's pixels are the
 // class-local pixels of one dX parity class and are scattered back to (2*py + cy, 2*px + cx).
 template <int DT, int WAVES_M, int WAVES_N, bool PAR, int EPI, bool OUT_F32>
@@ -377,12 +388,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[5]
             f32x4 s = acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
             f32x4 q = acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1] + acc[i][2] * acc[i][2] + acc[i][3] * acc[i][3];
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[r] += __shfl_xor(s[r], m);
-                    q[r] += __shfl_xor(q[r], m);
-                }
+            for (int r = 0; r < 4; ++r) {  // sum over the 16 pixel lanes of the MFMA tile row (one DPP row): VALU only, no LDS crossbar
+                s[r] = dpp_sum16(s[r]);
+                q[r] = dpp_sum16(q[r]);
             }
             if (frow == 0) {
                 const int cl = wn * 80 + i * 16 + fk * 4;
@@ -739,7 +747,8 @@ __device__ __forceinline__ void bufload_lds16(__amdgpu_buffer_rsrc_t r, int voff
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-// ABL (timing experiments only, results are wrong): 1 = no DMA in the K loop, 2 = no fragment reads, 4 = no MFMA (bits combine)
+// ABL (timing experiments only, results are wrong): 1 = no DMA in the K loop, 2 = no fragment reads, 4 = no MFMA (bits combine),
+// 8 = no X (pixel) DMA, 16 = no W (weight) DMA
 template <int DT, int WAVES_M, int WAVES_N, int MODE, int EPI, bool OUT_F32, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_pipe_kernel(const ConvArgs a) {
     constexpr bool DGRAD = MODE != 0;
@@ -964,7 +973,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_pipe_kernel
 #pragma unroll
         for (int idx = 0; idx < 20; ++idx) {
             if (!(ABL & 4)) mfma_inplace<DT>(a1[idx >> 2], b1[idx & 3], acc[idx >> 2][idx & 3]);
-            if (!(ABL & 1) && idx < NV) dma_piece(idx, cur, live);
+            if (!(ABL & 1) && idx < NV && !((ABL & 8) && idx < XI) && !((ABL & 16) && idx >= XI)) dma_piece(idx, cur, live);
             if (idx == NV) advance(0);
             if (idx == NV + 1) advance(1);
             if (!(ABL & 2) && idx >= 20 - 9 - 1 && idx < 20 - 1) frag1(nxt, 0, RORD[idx - (20 - 9 - 1)], a0, b0);
@@ -1041,6 +1050,7 @@ static void launch_glds(const ConvArgs& a, hipStream_t s) {
         return;
                 switch (abl) {
                     CDET_ABL_CASE(1) CDET_ABL_CASE(2) CDET_ABL_CASE(3) CDET_ABL_CASE(4) CDET_ABL_CASE(5) CDET_ABL_CASE(6) CDET_ABL_CASE(7)
+                    CDET_ABL_CASE(8) CDET_ABL_CASE(16)
                     default: break;
                 }
 #undef CDET_ABL_CASE
@@ -1167,6 +1177,11 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
     ConvArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
     a.y = y; a.stats = stats;
+    {  // timing experiment only: CDET_CONV_NOSTATS=1 drops the BN partial statistics (results of the BN that follows are wrong)
+        static int nostats = -1;
+        if (nostats < 0) { const char* e = getenv("CDET_CONV_NOSTATS"); nostats = e ? atoi(e) : 0; }
+        if (nostats) a.stats = nullptr;
+    }
     a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Cs = d->Cs; a.Hd = d->Hd; a.Wd = d->Wd; a.Cd = d->Cd;
     a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;

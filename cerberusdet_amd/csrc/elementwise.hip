@@ -2,6 +2,8 @@
 // (Concat), nearest 2x upsample (+bwd), SPPF max-pool chain (+bwd). All of them move 16-byte (8-channel)
 // vectors per lane; a thread keeps ONE channel vector for its whole life so that the per-channel parameters
 // (mean, invstd, gamma, beta) stay in registers while it walks down the pixel rows.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cdet {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const uint16_t* __rest
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const uint16_t* __restrict__ res, int res_ld, int res_coff,
-                                                          uint16_t* __restrict__ y, int y_ld, int y_coff, int64_t M, int CV) {
+                                                          uint16_t* __restrict__ y, int y_ld, int y_coff, int64_t M, int CV, int rev) {
     const ColMap cm = col_map(CV);
     if (!cm.active) return;
     const int c = cm.cv * 8;
@@ -137,15 +139,17 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const uint16_t* __rest
         sc.v[i] = ga.v[i] * is.v[i];
         sh.v[i] = be.v[i] - mu.v[i] * sc.v[i];
     }
+    // rev: walk the rows from the end (the producer wrote them front to back: its tail is what the L2 / MALL still hold)
     const int64_t step = (int64_t)gridDim.x * cm.rows_per_pass;
     int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl;
+    auto R = [&](int64_t i) { return rev ? M - 1 - i : i; };
     for (; r + 3 * step < M; r += 4 * step) {  // 4 independent rows in flight per thread
         u32x4 zr[4], rr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) zr[u] = *reinterpret_cast<const u32x4*>(z + (r + u * step) * z_ld + z_coff + c);
+        for (int u = 0; u < 4; ++u) zr[u] = *reinterpret_cast<const u32x4*>(z + R(r + u * step) * z_ld + z_coff + c);
         if (res) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rr[u] = *reinterpret_cast<const u32x4*>(res + (r + u * step) * res_ld + res_coff + c);
+            for (int u = 0; u < 4; ++u) rr[u] = *reinterpret_cast<const u32x4*>(res + R(r + u * step) * res_ld + res_coff + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -167,22 +171,22 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const uint16_t* __rest
                     x.v[2 * i + 1] += Elem<DT>::to_f32((uint16_t)(rr[u][i] >> 16));
                 }
             }
-            store8<DT>(y + (r + u * step) * y_ld + y_coff + c, x);
+            store8<DT>(y + R(r + u * step) * y_ld + y_coff + c, x);
         }
     }
     for (; r < M; r += step) {
-        Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
+        Vec8 x = load8<DT>(z + R(r) * z_ld + z_coff + c);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float a = x.v[i] * sc.v[i] + sh.v[i];
             x.v[i] = a * __builtin_amdgcn_rcpf(1.0f + __expf(-a));
         }
         if (res) {
-            const Vec8 rr = load8<DT>(res + r * res_ld + res_coff + c);
+            const Vec8 rr = load8<DT>(res + R(r) * res_ld + res_coff + c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) x.v[i] += rr.v[i];
         }
-        store8<DT>(y + r * y_ld + y_coff + c, x);
+        store8<DT>(y + R(r) * y_ld + y_coff + c, x);
     }
 }
 
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ sums, float inv_count,
-                                                                uint16_t* __restrict__ dz, int dz_ld, int dz_coff, int64_t M, int C, int CV) {
+                                                                uint16_t* __restrict__ dz, int dz_ld, int dz_coff, int64_t M, int C, int CV, int rev) {
     const ColMap cm = col_map(CV);
     if (!cm.active) return;
     const int c = cm.cv * 8;
@@ -302,12 +306,13 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
     }
     const int64_t step = (int64_t)gridDim.x * cm.rows_per_pass;
     int64_t r = (int64_t)blockIdx.x * cm.rows_per_pass + cm.rl;
+    auto R = [&](int64_t i) { return rev ? M - 1 - i : i; };
     for (; r + 3 * step < M; r += 4 * step) {
         Vec8 g[4], x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            g[u] = load8<DT>(dy + (r + u * step) * dy_ld + dy_coff + c);
-            x[u] = load8<DT>(z + (r + u * step) * z_ld + z_coff + c);
+            g[u] = load8<DT>(dy + R(r + u * step) * dy_ld + dy_coff + c);
+            x[u] = load8<DT>(z + R(r + u * step) * z_ld + z_coff + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -318,12 +323,12 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
                 const float da = g[u].v[i] * dsilu_f(ga.v[i] * xh + be.v[i]);
                 o.v[i] = ga.v[i] * is.v[i] * (da - m1.v[i] - xh * m2.v[i]);
             }
-            store8<DT>(dz + (r + u * step) * dz_ld + dz_coff + c, o);
+            store8<DT>(dz + R(r + u * step) * dz_ld + dz_coff + c, o);
         }
     }
     for (; r < M; r += step) {
-        const Vec8 g = load8<DT>(dy + r * dy_ld + dy_coff + c);
-        const Vec8 x = load8<DT>(z + r * z_ld + z_coff + c);
+        const Vec8 g = load8<DT>(dy + R(r) * dy_ld + dy_coff + c);
+        const Vec8 x = load8<DT>(z + R(r) * z_ld + z_coff + c);
         Vec8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
             const float da = g.v[i] * dsilu_f(ga.v[i] * xh + be.v[i]);
             o.v[i] = ga.v[i] * is.v[i] * (da - m1.v[i] - xh * m2.v[i]);
         }
-        store8<DT>(dz + r * dz_ld + dz_coff + c, o);
+        store8<DT>(dz + R(r) * dz_ld + dz_coff + c, o);
     }
 }
 
@@ -635,6 +640,16 @@ __global__ __launch_bounds__(256) void image_to_nhwc8_kernel(const void* __restr
     }
 }
 
+// CDET_BN_REV bit 0: bn_silu_fwd walks rows back to front, bit 1: bn_silu_bwd_apply does
+static int bn_rev() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CDET_BN_REV");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 static inline int grid_for(int64_t work_items, int per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -677,7 +692,7 @@ extern "C" int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, con
     const int grid = grid_for(M, rpp * 8);
     DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_fwd_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)z, z_ld,
                                          z_coff, mean, invstd, gamma, beta, (const uint16_t*)residual, res_ld, res_coff, (uint16_t*)y, y_ld,
-                                         y_coff, M, CV));
+                                         y_coff, M, CV, bn_rev() & 1));
     CDET_LAUNCH_CHECK();
     return 0;
 }
@@ -720,7 +735,7 @@ extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_
     const int grid = grid_for(M, rpp * 8);
     DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, dy_ld,
                                          dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
-                                         (uint16_t*)dz, dz_ld, dz_coff, M, C, CV));
+                                         (uint16_t*)dz, dz_ld, dz_coff, M, C, CV, (bn_rev() >> 1) & 1));
     CDET_LAUNCH_CHECK();
     return 0;
 }
