@@ -308,11 +308,12 @@ def main():
             tf = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
             if tf:
                 kern = json.load(open(tf[-1]))["kernels"]
-                pref = {"cdet_conv2d_wgrad": ("conv_wgrad_kernel", "wgrad_reduce_kernel"),
-                        "cdet_conv2d[fwd]": ("conv_igemm_glds_kernel<0, 2, 2, false", "conv_igemm_glds_kernel<0, 4, 1, false"),
-                        "cdet_conv2d[dgrad]": ("conv_igemm_glds_kernel<0, 2, 2, true", "conv_igemm_glds_kernel<0, 4, 1, true")}[dom]
-                sel = [v for k, v in kern.items() if k.startswith(pref)]
-                n0 = sum(v["launches"] for k, v in kern.items() if k.startswith(pref[0]))
+                fam = [f"conv_igemm_{v}_kernel<0, {t}" for v in ("pipe", "glds") for t in ("2, 2", "3, 1", "4, 2")]
+                main, extra = {"cdet_conv2d_wgrad": (("conv_wgrad_pipe_kernel", "conv_wgrad_kernel"), ("wgrad_reduce",)),
+                               "cdet_conv2d[fwd]": (tuple(f"{f}, 0," for f in fam), ()),
+                               "cdet_conv2d[dgrad]": (tuple(f"{f}, {m}," for f in fam for m in (1, 2)), ())}[dom]
+                sel = [v for k, v in kern.items() if k.startswith(main + extra)]
+                n0 = sum(v["launches"] for k, v in kern.items() if k.startswith(main))
                 if sel and n0:
                     out["roofline"]["traffic"] = round(sum(v["fetch_bytes_total"] + v["write_bytes_total"] for v in sel) / n0)
                     out["roofline"]["traffic_unit"] = "bytes/launch"

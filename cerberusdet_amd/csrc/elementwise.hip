@@ -698,8 +698,15 @@ extern "C" int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, con
 }
 
 extern "C" int cdet_bn_bwd_blocks(int64_t M) {
-    int64_t b = (M + 31) / 32;  // >= 32 pixel rows per block, at most 4 blocks per CU
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    static int div = -1, cap = -1;
+    if (div < 0) {
+        const char* e = getenv("CDET_BN_BWD_DIV");
+        const char* c = getenv("CDET_BN_BWD_CAP");
+        div = e ? atoi(e) : 64;  // measured per task pass (reduce + sums ms): 32/1024 3.16, 64/1024 3.15, 64/512 2.78, 128/512 2.90, 100/384 3.16
+        cap = c ? atoi(c) : 512;
+    }
+    int64_t b = (M + div - 1) / div;  // >= `div` pixel rows per block, at most cap / 256 blocks per CU
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
