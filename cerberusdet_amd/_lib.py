@@ -36,6 +36,11 @@ class NmsDesc(C.Structure):
                 ("classes", vp), ("n_classes", i32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w_oihw", vp), ("w_fwd", vp), ("w_dgrad", vp), ("O", i32), ("O_pad", i32), ("I", i32), ("kh", i32), ("kw", i32),
+                ("first_block", i32), ("n_blocks", i32)]
+
+
 class ParamSlot(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("lr", f32), ("weight_decay", f32),
                 ("inv_div", f32), ("first_step", i32)]
@@ -49,6 +54,7 @@ _SIGS = {
     "cdet_conv2d": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "cdet_packed_weight_elems": (i64, [i32, i32, i32, i32, i32]),
+    "cdet_pack_weights_batched": (i32, [vp, i32, i32, i32, vp]),
     "cdet_conv2d_wgrad_ws_elems": (i64, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),

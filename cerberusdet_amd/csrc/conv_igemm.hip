@@ -1013,6 +1013,52 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __rest
 
 static inline int kpad_of(int K) { return (K + BK - 1) / BK * BK; }
 
+// every pack of a model in one launch: workgroup -> (item, 32 x 32 tile of (o, i)); the OIHW tile is read contiguously
+// (32 rows of 32*taps floats), transposed through LDS and written in both operand layouts in 32-element runs
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const cdet_pack_item* __restrict__ items, int n, int dtype) {
+    __shared__ int s_it;
+    __shared__ float tile[32][32 * 9 + 1];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (items[mid].first_block <= (int)blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        s_it = lo;
+    }
+    __syncthreads();
+    const cdet_pack_item p = items[s_it];
+    const int taps = p.kh * p.kw;
+    const int tiles_i = (p.I + 31) / 32;
+    const int lb = (int)blockIdx.x - p.first_block;
+    const int o0 = (lb / tiles_i) * 32, i0 = (lb % tiles_i) * 32;
+    const int ni = min(32, p.I - i0), no = min(32, p.O - o0);
+    const int run = ni * taps;  // contiguous floats per output channel of this tile
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int o = e / run, r = e - o * run;
+        if (o < no) tile[o][r] = p.w_oihw[((int64_t)(o0 + o) * p.I + i0) * taps + r];
+    }
+    __syncthreads();
+    const int Kf = (taps * p.I + BK - 1) / BK * BK, Kt = (taps * p.O_pad + BK - 1) / BK * BK;
+    uint16_t* wf = reinterpret_cast<uint16_t*>(p.w_fwd);
+    uint16_t* wt = reinterpret_cast<uint16_t*>(p.w_dgrad);
+    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;  // 32 lanes along the contiguous axis, 8 groups over (row, tap)
+    for (int rt = g; rt < 32 * taps; rt += 8) {
+        const int row = rt / taps, tap = rt - row * taps;
+        // forward operand: row = o, run over i
+        if (row < no && l < ni) {
+            const float v = tile[row][l * taps + tap];
+            wf[(int64_t)(o0 + row) * Kf + tap * p.I + i0 + l] = dtype == CDET_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+        }
+        // DGRAD operand: row = i, run over o
+        if (wt != nullptr && row < ni && l < no) {
+            const float v = tile[l][row * taps + tap];
+            wt[(int64_t)(i0 + row) * Kt + tap * p.O_pad + o0 + l] = dtype == CDET_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+        }
+    }
+}
+
 static int conv_impl() {
     static int impl = -1;
     if (impl < 0) {
@@ -1158,6 +1204,14 @@ extern "C" int cdet_pack_weight(const float* w, void* out, int32_t O, int32_t O_
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)out, O, O_pad, I, kh, kw,
                        transpose, row_scale, dtype, rows, Kpad);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_pack_weights_batched(const cdet_pack_item* items, int32_t n_items, int32_t n_blocks_total, int32_t dtype, void* stream) {
+    CDET_CHECK_ARG(items && n_items > 0 && n_blocks_total >= n_items, "cdet_pack_weights_batched: bad arguments (kh*kw <= 9 is the caller's duty)");
+    CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "cdet_pack_weights_batched: dtype must be bf16/f16");
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(n_blocks_total), dim3(256), 0, (hipStream_t)stream, items, n_items, dtype);
     CDET_LAUNCH_CHECK();
     return 0;
 }

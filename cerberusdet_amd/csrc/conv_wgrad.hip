@@ -500,37 +500,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_elem_kernel(const float* __r
     }
 }
 
-// dw[o][i][kh][kw] (+)= sum_s ws[s][o][(kh,kw,i)], fixed order over s. One thread owns one (o, i) pair: its taps are read
-// with i fastest across the threads (coalesced slab reads) and written as KH*KW consecutive floats (adjacent threads write
-// adjacent runs; the first version wrote 4-byte elements KH*KW floats apart: 4x write amplification in the PMC counters).
-template <int TAPS>
+// dw[o][i][kh][kw] (+)= sum_s ws[s][o][(kh,kw,i)], fixed order over s. One thread owns one kernel ROW of one (o, i) pair
+// (kh fastest across threads): its KW taps are read with i running across the lanes of equal kh (coalesced slab reads) and
+// written as KW consecutive floats, adjacent threads writing adjacent runs (the per-element version writes 4-byte elements
+// KH*KW floats apart: 4x write amplification in the PMC counters).
+template <int KH, int KW>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int O, int Cd_pad, int I,
-                                                          int taps_rt, int Kp, int accumulate) {
-    const int taps = TAPS > 0 ? TAPS : taps_rt;
-    const int64_t total = (int64_t)O * I;
+                                                          int Kp, int accumulate) {
+    const int64_t total = (int64_t)O * I * KH;
     const int64_t slab = (int64_t)Cd_pad * Kp;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx % I);
-        const int o = (int)(idx / I);
-        const float* src = ws + (int64_t)o * Kp + i;
-        float* d = dw + idx * taps;
-        if (TAPS > 0) {
-            float sum[TAPS > 0 ? TAPS : 1];
+        const int kh = (int)(idx % KH);
+        const int64_t oi = idx / KH;
+        const int i = (int)(oi % I);
+        const int o = (int)(oi / I);
+        const float* src = ws + (int64_t)o * Kp + kh * KW * I + i;
+        float* d = dw + oi * (KH * KW) + kh * KW;
+        float sum[KW];
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) sum[tp] = 0.f;
-            for (int s = 0; s < S; ++s) {
+        for (int tp = 0; tp < KW; ++tp) sum[tp] = 0.f;
+        for (int s = 0; s < S; ++s) {
 #pragma unroll
-                for (int tp = 0; tp < TAPS; ++tp) sum[tp] += src[(int64_t)s * slab + tp * I];
-            }
-#pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) d[tp] = accumulate ? d[tp] + sum[tp] : sum[tp];
-        } else {
-            for (int tp = 0; tp < taps; ++tp) {
-                float sum = 0.f;
-                for (int s = 0; s < S; ++s) sum += src[(int64_t)s * slab + tp * I];
-                d[tp] = accumulate ? d[tp] + sum : sum;
-            }
+            for (int tp = 0; tp < KW; ++tp) sum[tp] += src[(int64_t)s * slab + tp * I];
         }
+#pragma unroll
+        for (int tp = 0; tp < KW; ++tp) d[tp] = accumulate ? d[tp] + sum[tp] : sum[tp];
     }
 }
 
@@ -650,18 +644,20 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     if (d->dtype == CDET_BF16) e = p.wide ? launch_wgrad<CDET_BF16, 2, 2>(a, s) : launch_wgrad<CDET_BF16, 4, 1>(a, s);
     else e = p.wide ? launch_wgrad<CDET_F16, 2, 2>(a, s) : launch_wgrad<CDET_F16, 4, 1>(a, s);
     if (e) return e;
-    const int64_t total = (int64_t)d->Cd * d->Cs;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
     const int taps = d->kh * d->kw;
-    if (total * (taps == 1 ? 4 : 1) < 65536) {  // narrow layers: one thread per element keeps the chip busy
-        const int64_t tot_e = total * taps;
+    const int64_t rows = (int64_t)d->Cd * d->Cs * d->kh;  // threads of the row-wise reduction
+    const bool rowwise = ((d->kh == 3 && d->kw == 3) || taps == 1) && rows >= 32768;
+    if (!rowwise) {  // small layers / other kernel sizes: one thread per element keeps the chip busy
+        const int64_t tot_e = (int64_t)d->Cd * d->Cs * taps;
         int be = (int)((tot_e + 255) / 256);
         if (be > 4096) be = 4096;
         hipLaunchKernelGGL(wgrad_reduce_elem_kernel, dim3(be), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, d->kh, d->kw, p.Kp, accumulate);
-    } else if (taps == 9) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, taps, p.Kp, accumulate);
-    else if (taps == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, taps, p.Kp, accumulate);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, taps, p.Kp, accumulate);
+    } else {
+        int blocks = (int)((rows + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<3, 3>), dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, p.Kp, accumulate);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, p.Kp, accumulate);
+    }
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -389,7 +389,7 @@ class CerberusDet(nn.Module):
         return super().state_dict(*a, **k)
 
     _RUNTIME_ATTRS = ("_plan_slots", "_stem_slots", "_pack_key", "_stem_key", "_wp", "_wpt", "_scale", "_bias", "_bias_pad",
-                      "_stem_scale", "_stem_bias", "_w8", "_gw8", "_stem8")
+                      "_stem_scale", "_stem_bias", "_w8", "_gw8", "_stem8", "_wp_zeroed")
 
     def _grad_buffer(self, p):
         g = self._pgrad.get(id(p))

@@ -85,6 +85,22 @@ int cdet_pack_weight(const float* w_oihw, void* w_packed, int32_t O, int32_t O_p
 /* O_pad >= O: output channels O..O_pad-1 are zero (head maps are padded to a multiple of 8 channels). */
 int64_t cdet_packed_weight_elems(int32_t O_pad, int32_t I, int32_t kh, int32_t kw, int32_t transpose);
 
+/* The forward AND the DGRAD operand of many convolutions in ONE launch: after an optimizer step every Conv of the model needs
+ * both re-cast (the per-module autocast casts of trainers/averaging.py:158; ~320 launches per step otherwise, each reading
+ * OIHW with a 36-byte stride). One workgroup transposes a [32 o][32 i][kh*kw] tile through LDS: the fp32 master is read once,
+ * contiguously, and both layouts are written in runs of 32 elements. Only VALID elements are written: the K tail up to Kpad
+ * and the rows O..O_pad-1 of the destination buffers must have been zeroed once by the caller. kh*kw <= 9.
+ * `items` is a DEVICE array; first_block / n_blocks (= ceil(O/32)*ceil(I/32)) partition the grid of n_blocks_total workgroups
+ * (first_block ascending, contiguous). w_dgrad may be NULL. */
+typedef struct {
+    const float* w_oihw;
+    void* w_fwd;   /* cdet_pack_weight(..., transpose = 0) layout */
+    void* w_dgrad; /* cdet_pack_weight(..., transpose = 1) layout, or NULL */
+    int32_t O, O_pad, I, kh, kw;
+    int32_t first_block, n_blocks;
+} cdet_pack_item;
+int cdet_pack_weights_batched(const cdet_pack_item* items, int32_t n_items, int32_t n_blocks_total, int32_t dtype, void* stream);
+
 /* Weight gradient: dw[o][i][kh][kw] (+)= sum_{n,oy,ox} dy[n,oy,ox,o] * x[n,oy*s-pad+kh,ox*s-pad+kw,i]
  * (autograd's convolution_backward(weight) for models/common.py:57). dw is fp32 OIHW; `ws` is a caller-provided
  * fp32 workspace of cdet_conv2d_wgrad_ws_elems(d) elements (split-K partials), may be NULL when that is 0. */

@@ -352,3 +352,35 @@ def test_sgd_ema_step_matches_oracle():
             _close(ed[k], eref[k], 1e-5, 1e-6)
             assert float(gd[k].abs().max()) == 0.0
             gd[k].copy_(gr[k])
+
+
+def test_pack_weights_batched_equals_per_item_pack():
+    """cdet_pack_weights_batched (one launch, LDS tile transpose, valid elements only) against cdet_pack_weight per operand."""
+    import ctypes as C
+
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(80, 8, 3, 3, 80), (160, 80, 3, 3, 160), (320, 400, 1, 1, 320), (20, 320, 1, 1, 24), (64, 80, 1, 1, 64), (48, 72, 3, 3, 48)]
+    for dtype in (torch.bfloat16, torch.float16):
+        ws, refs, outs = [], [], []
+        arr = (L.PackItem * len(shapes))()
+        blk = 0
+        for it, (O, I, kh, kw, Op) in zip(arr, shapes):
+            w = torch.randn(O, I, kh, kw, generator=g).to(DEV)
+            ws.append(w)
+            refs.append((ops.pack_weight(w, dtype, o_pad=Op), ops.pack_weight(w, dtype, transpose=True, o_pad=Op)))
+            wf, wt = torch.zeros_like(refs[-1][0]), torch.zeros_like(refs[-1][1])
+            outs.append((wf, wt))
+            nb = ((O + 31) // 32) * ((I + 31) // 32)
+            it.w_oihw, it.w_fwd, it.w_dgrad = w.data_ptr(), wf.data_ptr(), wt.data_ptr()
+            it.O, it.O_pad, it.I, it.kh, it.kw, it.first_block, it.n_blocks = O, Op, I, kh, kw, blk, nb
+            blk += nb
+        dtab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+        L.check(lib.cdet_pack_weights_batched(dtab.data_ptr(), len(shapes), blk, ops.dt(dtype), ops.stream()), "cdet_pack_weights_batched")
+        torch.cuda.synchronize()
+        for (rf, rt), (wf, wt), shp in zip(refs, outs, shapes):
+            assert torch.equal(rf.view(torch.int16), wf.view(torch.int16)), ("fwd", shp, dtype)
+            assert torch.equal(rt.view(torch.int16), wt.view(torch.int16)), ("dgrad", shp, dtype)
