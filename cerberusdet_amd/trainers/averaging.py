@@ -95,8 +95,13 @@ class GradReducer:
 
 class Averaging:
     def __init__(self, device, model, hyp: dict, task_ids: Sequence[str], epochs: int = 100, nb: int = 1000, loss_weights=None,
-                 linear_lr=False, use_ema=True, rank=-1, world_size=1, sync_bn=False):
+                 linear_lr=False, use_ema=True, rank=-1, world_size=1, sync_bn=False, task_streams: Optional[bool] = None):
         self.device, self.model, self.hyp, self.task_ids = device, model, hyp, list(task_ids)
+        # one HIP stream per task pass (see _run_tasks_on_streams); off under SyncBatchNorm, whose per-layer collectives must be
+        # enqueued in one order on every rank
+        if task_streams is None:
+            task_streams = os.environ.get("CDET_TASK_STREAMS", "1") != "0"
+        self.task_streams = bool(task_streams) and not sync_bn and torch.device(device).type == "cuda"
         self.rank, self.world_size = rank, world_size
         model.sync_bn = bool(sync_bn)  # SyncBatchNorm: per-layer statistics all-reduced over the ranks (reference train.py:140-143)
         self.epochs, self.nb = epochs, nb
@@ -182,6 +187,47 @@ class Averaging:
         plan.run_backward()
         return loss5
 
+    def _run_tasks_on_streams(self, active, batches, n_max, out):
+        """The task passes of one iteration on one HIP stream each. The passes are independent except on the blocks they share
+        (read-modify-write of the shared BatchNorm running statistics in forward and of the shared gradient buffers in backward):
+        there a per-block event chain keeps the reference's task order, so the results are bit-identical to the sequential
+        schedule. What the overlap buys: one pass's latency-bound launches (BN partial-sum kernels, ~400 per pass) and the
+        partly filled last round of its convolution grids run under the other pass's kernels (measured 113.8 -> 101.9 ms)."""
+        from ..engine import BlockSync
+
+        cur = torch.cuda.current_stream()
+        key = tuple(active)
+        cache = self.__dict__.setdefault("_stream_sync", {})
+        if key not in cache:
+            streams = [torch.cuda.Stream() for _ in active]
+            syncs = {t: BlockSync() for t in active}
+            for idx, ts in self.serving.items():
+                chain = [t for t in active if t in ts]
+                for a_, b_ in zip(chain[:-1], chain[1:]):
+                    ef, eb = torch.cuda.Event(), torch.cuda.Event()
+                    syncs[a_].done_fwd[idx], syncs[b_].wait_fwd[idx] = ef, ef
+                    syncs[a_].done_bwd[idx], syncs[b_].wait_bwd[idx] = eb, eb
+            cache[key] = (streams, syncs)
+        streams, syncs = cache[key]
+        plans = []
+        for t in active:
+            img = batches[t]["img"]
+            plan = self.model.get_plan(t, img.shape, img.dtype, training=True)
+            plan.refresh_weights()  # all re-packs on the current stream, before the fork
+            plan.attach_grads()
+            plans.append(plan)
+        try:
+            for t, st, plan in zip(active, streams, plans):
+                plan.block_sync = syncs[t]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
+        finally:
+            for plan in plans:
+                plan.block_sync = None
+        for st in streams:
+            cur.wait_stream(st)
+
     def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None):
         self.reducer.wait()
         first = self.steps == 0
@@ -219,8 +265,11 @@ class Averaging:
         lrs, mom = self.lrs(ni, self.epoch)
         active = [t for t in self.task_ids if t in batches]
         out = {}
-        for t in active:
-            out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
+        if self.task_streams and len(active) > 1:
+            self._run_tasks_on_streams(active, batches, n_max, out)
+        else:
+            for t in active:
+                out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
         n_serving = None
         if len(active) != len(self.task_ids):
             n_serving = {i: max(len([t for t in ts if t in active]), 1) for i, ts in self.serving.items()}

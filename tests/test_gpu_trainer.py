@@ -71,6 +71,41 @@ def test_two_iterations_vs_reference_golden():
         assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters() if p.grad is not None)
 
 
+def test_task_streams_bit_identical_to_sequential_schedule():
+    """train_step with one HIP stream per task pass (event chain on the shared blocks) must give bit-identical weights, BN running
+    statistics, EMA and loss items to the sequential schedule of the reference (trainers/averaging.py:132-194)."""
+    from cerberusdet_amd.trainers import Averaging
+
+    arrays, meta = load_golden("trainer")
+    _, mmeta = load_golden("model_tiny2")
+    res = []
+    for streams in (False, True):
+        m = _model(meta, mmeta)
+        tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, task_streams=streams)
+        assert tr.task_streams == streams
+        items = []
+        for it in range(3):
+            batches = {}
+            for ti, t in enumerate(meta["tasks"]):
+                img = torch.from_numpy(synth.det_image(500 + 10 * it + ti, 4, 128)).to(DEV)
+                b = synth.make_batch(4, 3, meta["nc"][ti], 600 + 10 * it + ti)
+                batches[t] = dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()})
+            out = tr.train_step(batches, ni=2000 + it)  # past warm-up: every group has lr > 0
+            items.append({t: v.clone() for t, v in out.items()})
+        torch.cuda.synchronize()
+        res.append((items, {k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in tr.ema.ema.state_dict().items()}))
+    (ia, sa, ea), (ib, sb, eb) = res
+    for x, y in zip(ia, ib):
+        for t in x:
+            assert torch.equal(x[t], y[t]), t
+    changed = 0
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+        assert torch.equal(ea[k], eb[k]), k
+        changed += int(not torch.equal(sa[k].float().cpu(), torch.from_numpy(synth.det_tensor(mmeta["seed"], k, sa[k].shape)).float()))
+    assert changed > len(sa) // 2  # the steps really moved the model
+
+
 def test_grad_accumulation_and_block_division():
     """Shared blocks accumulate both tasks' gradients and are divided by 2, branch blocks by 1 (averaging.py:211-217):
     with lr > 0 only for one group we can read the applied update back."""
