@@ -17,7 +17,9 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # task-pass streams + RCCL streams need more than the default 4 hardware queues
+
+import torch  # noqa: E402
 import torch.distributed as dist
 import yaml
 
