@@ -41,6 +41,10 @@ class PackItem(C.Structure):
                 ("first_block", i32), ("n_blocks", i32)]
 
 
+class MergeDesc(C.Structure):
+    _fields_ = [("N", i32), ("T", i32), ("max_det", i32), ("iou_thres", f32), ("rows", vp * 8), ("counts", vp * 8), ("cls_offset", i32 * 8)]
+
+
 class ParamSlot(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("lr", f32), ("weight_decay", f32),
                 ("inv_div", f32), ("first_step", i32)]
@@ -79,6 +83,7 @@ _SIGS = {
     "cdet_det_loss_ws_bytes": (i64, [C.POINTER(LossDesc)]),
     "cdet_det_loss": (i32, [C.POINTER(LossDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_nms_ws_bytes": (i64, [C.POINTER(NmsDesc)]),
+    "cdet_merge_tasks": (i32, [C.POINTER(MergeDesc), vp, vp, vp, vp]),
     "cdet_nms_batched": (i32, [C.POINTER(NmsDesc), vp, vp, vp, vp, vp]),
     "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp]),
     "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, f32, f32, vp]),

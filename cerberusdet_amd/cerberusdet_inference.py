@@ -87,26 +87,36 @@ class CerberusDetInference:
 
     def postprocess(self, y_per_task: Dict[str, torch.Tensor], net_shape, original_shape=None, max_det=300, agnostic_nms=False,
                     conf_thres=0.25, iou_thres=0.45, iou_thres_between_tasks=0.8) -> List[List[Dict]]:
-        per_task = {t: [d.cpu() for d in non_max_suppression(y, conf_thres, iou_thres, agnostic=agnostic_nms, max_det=max_det)]
-                    for t, y in y_per_task.items()}
+        from . import ops
+
+        tasks = list(y_per_task.keys())
+        dev = next(iter(y_per_task.values())).device
         bs = next(iter(y_per_task.values())).shape[0]
+        # per-task batched NMS, then class remap + cross-task suppression + scale_boxes().round() in ONE more launch; a single
+        # device->host copy per batch feeds the result dicts
+        rows, cnts = zip(*(ops.nms_batched(y_per_task[t].contiguous(), conf_thres, iou_thres, agnostic=agnostic_nms, max_det=max_det)
+                           for t in tasks))
+        offs = [self.categories_inds_map[t][0] for t in tasks]  # local id -> global id is a per-task offset (cerberusdet_inference.py:56-70)
+        scale = None
+        if original_shape is not None:
+            shapes = original_shape if isinstance(original_shape, list) else [original_shape] * bs
+            sc = []
+            for shp in shapes:
+                gain = min(net_shape[0] / shp[0], net_shape[1] / shp[1])
+                sc.append([gain, (net_shape[1] - shp[1] * gain) / 2, (net_shape[0] - shp[0] * gain) / 2, shp[0], shp[1]])
+            scale = torch.tensor(sc, dtype=torch.float32, device=dev)
+        out, cnt = ops.merge_tasks(rows, cnts, offs, iou_thres_between_tasks, scale)
+        out, cnt = out.cpu(), cnt.cpu().tolist()
+        bounds = []
+        for t in tasks:
+            ids = self.categories_inds_map[t]
+            bounds.append((min(ids.values()), max(ids.values()), t))
         results = []
         for i in range(bs):
-            det = torch.zeros((0, 6))
-            for t, lst in per_task.items():
-                d = lst[i].clone()
-                if d.shape[0]:
-                    off = self.categories_inds_map[t][0]  # local id -> global id is a per-task offset (cerberusdet_inference.py:56-70)
-                    d[:, 5] += off
-                    det = torch.cat((det, d), 0)
-            det = nms_between_tasks(det, self.categories_inds_map, iou_thres=iou_thres_between_tasks)
-            if len(det) > 0 and original_shape is not None:
-                shp = original_shape[i] if isinstance(original_shape, list) else original_shape
-                det[:, :4] = scale_boxes(net_shape, det[:, :4], shp).round()
             img = []
-            for row in det.tolist():
+            for row in out[i, :cnt[i]].tolist():
                 c = int(row[5])
-                task = next((tn for tn, mp in self.categories_inds_map.items() if c in mp.values()), "unknown")
+                task = next((tn for lo, hi, tn in bounds if lo <= c <= hi), "unknown")
                 img.append({"box": [int(v) for v in row[:4]], "score": float(row[4]), "label": c, "label_name": self.all_class_names[c],
                             "task": task})
             results.append(img)

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
 
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2, float by2,
                                        float barea, float thr) {
+#pragma clang fp contract(off)  // torchvision evaluates w*h and (a + b - inter) separately: no FMA fusion
     const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1), xx2 = fminf(ax2, bx2), yy2 = fminf(ay2, by2);
     const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
     const float inter = w * h;
@@ -252,6 +253,122 @@ static inline int next_pow2(int v) {
     return p;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// cross-task merge (one workgroup per image): see cdet_merge_tasks in include/cerberus_hip.h
+// ------------------------------------------------------------------------------------------------
+constexpr int MERGE_MAX = 2048;
+
+__global__ __launch_bounds__(256) void merge_tasks_kernel(const cdet_merge_desc d, const float* __restrict__ scale, float* __restrict__ out_rows,
+                                                          int* __restrict__ out_count) {
+#pragma clang fp contract(off)  // torch evaluates w*h, the sums and the division as separate fp32 operations: no FMA fusion here
+    __shared__ float bx[MERGE_MAX][6];
+    __shared__ unsigned char tk[MERGE_MAX], dead[MERGE_MAX], hit[MERGE_MAX];
+    __shared__ int start[9];
+    __shared__ unsigned long long wbest[4];
+    __shared__ int s_any, s_n_dead;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int acc = 0;
+        for (int t = 0; t < d.T; ++t) {
+            start[t] = acc;
+            acc += min(d.counts[t][img], d.max_det);
+        }
+        start[d.T] = acc;
+        s_n_dead = 0;
+    }
+    __syncthreads();
+    const int n = start[d.T];
+    for (int t = 0; t < d.T; ++t) {
+        const int cnt = start[t + 1] - start[t];
+        const float* src = d.rows[t] + (int64_t)img * d.max_det * 6;
+        for (int e = tid; e < cnt * 6; e += 256) {
+            const int r = e / 6, c = e - r * 6;
+            float v = src[e];
+            if (c == 5) v += (float)d.cls_offset[t];
+            bx[start[t] + r][c] = v;
+        }
+        for (int r = tid; r < cnt; r += 256) {
+            tk[start[t] + r] = (unsigned char)t;
+            dead[start[t] + r] = 0;
+        }
+    }
+    __syncthreads();
+    // greedy row scan (general.py:527-545). Rows of the last task have no later task -> no hits.
+    const int r_end = start[d.T - 1];
+    for (int r = 0; r < r_end; ++r) {
+        if (dead[r]) continue;  // uniform: LDS flag, barrier-separated from its writers
+        const float ax1 = bx[r][0], ay1 = bx[r][1], ax2 = bx[r][2], ay2 = bx[r][3];
+        const float aarea = (ax2 - ax1) * (ay2 - ay1);
+        const int j0 = start[tk[r] + 1];
+        // best hit: highest score, lowest index on ties -> key = (score bits, ~index); scores are positive floats
+        unsigned long long best = 0ull;
+        for (int j = j0 + tid; j < n; j += 256) {
+            const float iw = fmaxf(fminf(ax2, bx[j][2]) - fmaxf(ax1, bx[j][0]), 0.f);
+            const float ih = fmaxf(fminf(ay2, bx[j][3]) - fmaxf(ay1, bx[j][1]), 0.f);
+            const float inter = iw * ih;
+            const float iou = inter / (aarea + (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]) - inter + 1e-7f);
+            const bool h = iou > d.iou_thres;
+            hit[j] = h ? 1 : 0;
+            if (h) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(bx[j][4]) << 32) | (unsigned)(0xffffffffu - (unsigned)j);
+                best = key > best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = __shfl_xor(best, m);
+            best = o > best ? o : best;
+        }
+        if ((tid & 63) == 0) wbest[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = wbest[0];
+            for (int w = 1; w < 4; ++w) b = wbest[w] > b ? wbest[w] : b;
+            wbest[0] = b;
+            s_any = b != 0ull;
+        }
+        __syncthreads();
+        if (s_any) {  // uniform
+            const unsigned long long b = wbest[0];
+            const int bj = (int)(0xffffffffu - (unsigned)(b & 0xffffffffull));
+            const float bs = __uint_as_float((unsigned)(b >> 32));
+            const bool row_wins = bx[r][4] > bs;  // the row itself comes LAST in the candidate list: it needs a strictly higher score
+            for (int j = j0 + tid; j < n; j += 256)
+                if (hit[j] && (row_wins || j != bj)) dead[j] = 1;
+            if (tid == 0 && !row_wins) dead[r] = 1;
+        }
+        __syncthreads();
+    }
+    // survivors (all rows if everything was deleted, general.py:547-548), order preserved
+    if (tid == 0) {
+        int nd = 0;
+        for (int i = 0; i < n; ++i) nd += dead[i];
+        s_n_dead = nd;
+    }
+    __syncthreads();
+    const bool keep_all = s_n_dead == n;
+    float* dst = out_rows + (int64_t)img * d.T * d.max_det * 6;
+    if (tid == 0) {
+        int k = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!keep_all && dead[i]) continue;
+            float x1 = bx[i][0], y1 = bx[i][1], x2 = bx[i][2], y2 = bx[i][3];
+            if (scale != nullptr) {  // scale_boxes + clip_boxes + round (cerberusdet_inference.py:161, general.py:313-357)
+                const float g = scale[img * 5 + 0], px = scale[img * 5 + 1], py = scale[img * 5 + 2], h0 = scale[img * 5 + 3], w0 = scale[img * 5 + 4];
+                x1 = rintf(fminf(fmaxf((x1 - px) / g, 0.f), w0));
+                y1 = rintf(fminf(fmaxf((y1 - py) / g, 0.f), h0));
+                x2 = rintf(fminf(fmaxf((x2 - px) / g, 0.f), w0));
+                y2 = rintf(fminf(fmaxf((y2 - py) / g, 0.f), h0));
+            }
+            float* o = dst + (int64_t)k * 6;
+            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = bx[i][4]; o[5] = bx[i][5];
+            ++k;
+        }
+        out_count[img] = k;
+    }
+}
+
 }  // namespace cdet
 
 using namespace cdet;
@@ -288,6 +405,16 @@ extern "C" int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float*
     hipLaunchKernelGGL(nms_sort_kernel, dim3(d->N), dim3(1024), 0, s, a);
     CDET_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(d->N), dim3(64), 0, s, a);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_merge_tasks(const cdet_merge_desc* d, const float* scale, float* out_rows, int32_t* out_count, void* stream) {
+    CDET_CHECK_ARG(d && out_rows && out_count, "cdet_merge_tasks: null pointer");
+    CDET_CHECK_ARG(d->N > 0 && d->T >= 1 && d->T <= 8 && d->max_det > 0 && d->T * d->max_det <= MERGE_MAX,
+                   "cdet_merge_tasks: needs 1 <= T <= 8 and T*max_det <= %d (T=%d max_det=%d)", MERGE_MAX, d->T, d->max_det);
+    for (int t = 0; t < d->T; ++t) CDET_CHECK_ARG(d->rows[t] && d->counts[t], "cdet_merge_tasks: null per-task pointer");
+    hipLaunchKernelGGL(merge_tasks_kernel, dim3(d->N), dim3(256), 0, (hipStream_t)stream, *d, scale, out_rows, out_count);
     CDET_LAUNCH_CHECK();
     return 0;
 }

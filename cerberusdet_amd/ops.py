@@ -280,3 +280,21 @@ def nms_batched(pred: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=Non
     cnt = torch.zeros(N, dtype=torch.int32, device=pred.device)
     L.check(lib.cdet_nms_batched(C.byref(d), ptr(pred), ptr(rows), ptr(cnt), ptr(ws), stream()), "cdet_nms_batched")
     return rows, cnt
+
+
+def merge_tasks(rows_per_task, counts_per_task, cls_offsets, iou_thres=0.8, scale=None):
+    """Per-task NMS outputs ([N,max_det,6] fp32 + [N] i32 each, task order) -> (rows [N, T*max_det, 6] with global class ids,
+    counts [N]): cross-task suppression, and with scale [N,5] (gain, pad_x, pad_y, h0, w0) scale_boxes().round()."""
+    lib = L.load()
+    T = len(rows_per_task)
+    N, max_det, _ = rows_per_task[0].shape
+    d = L.MergeDesc()
+    d.N, d.T, d.max_det, d.iou_thres = N, T, max_det, iou_thres
+    for t in range(T):
+        assert rows_per_task[t].is_contiguous() and rows_per_task[t].dtype == torch.float32 and counts_per_task[t].dtype == torch.int32
+        d.rows[t], d.counts[t], d.cls_offset[t] = ptr(rows_per_task[t]), ptr(counts_per_task[t]), int(cls_offsets[t])
+    dev = rows_per_task[0].device
+    out = torch.zeros((N, T * max_det, 6), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+    L.check(lib.cdet_merge_tasks(C.byref(d), ptr(scale), ptr(out), ptr(cnt), stream()), "cdet_merge_tasks")
+    return out, cnt

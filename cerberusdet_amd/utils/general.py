@@ -85,42 +85,29 @@ def box_iou(box1, box2, eps=1e-7):
 
 
 def nms_between_tasks(bboxes: torch.Tensor, categories_map_per_task: Dict[str, Dict[int, int]], iou_thres: float) -> torch.Tensor:
-    """Cross-task suppression on the (few hundred) rows that survive per-task NMS (reference general.py:484-554): rows are
-    regrouped by task, IoU is evaluated between boxes of DIFFERENT tasks only (upper triangle), then a greedy row scan
-    deletes, for each row with hits, everything but the best-scoring box of {row} U hits. Vectorised on the host."""
-    b = bboxes.detach().cpu()
-    n = b.shape[0]
+    """Cross-task suppression on the rows that survive per-task NMS (reference general.py:484-554): rows are regrouped by task,
+    IoU is evaluated between boxes of DIFFERENT tasks only, then a greedy row scan deletes, for each live row with hits, everything
+    but the best-scoring box of hits U {row}. Runs on the GPU (cdet_merge_tasks, one workgroup per image); this wrapper keeps the
+    reference's single-image signature (rows [n,6] with GLOBAL class ids) -- CerberusDetInference batches the call itself."""
+    from .. import ops
+
+    n = bboxes.shape[0]
     if n == 0:
         return bboxes
+    dev = bboxes.device if bboxes.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    b = bboxes.detach().to(dev, torch.float32)
     cls = b[:, 5].to(torch.int64)
     tasks = list(categories_map_per_task.keys())
-    task_of = torch.full((n,), -1, dtype=torch.int64)
-    for ti, t in enumerate(tasks):
-        ids = torch.tensor(sorted(categories_map_per_task[t].values()), dtype=torch.int64)
-        task_of[torch.isin(cls, ids)] = ti
-    order = torch.cat([torch.nonzero(task_of == ti).flatten() for ti in range(len(tasks))])
-    b = b[order]
-    tk = task_of[order]
-    iou = torch.zeros((n, n))
-    m = b.shape[0]
-    if m:
-        full = box_iou(b[:, :4], b[:, :4])
-        upper = tk.view(-1, 1) < tk.view(1, -1)
-        iou[:m, :m] = torch.where(upper, full, torch.zeros_like(full))
-    if not torch.any(iou > iou_thres):
-        return b.to(bboxes.device)
-    hit = (iou > iou_thres).numpy()
-    scores = b[:, 4].numpy()
-    deleted = np.zeros(m, bool)
-    for r in range(m):
-        if deleted[r]:
-            continue
-        idxs = np.nonzero(hit[r])[0]
-        if len(idxs) == 0:
-            continue
-        idxs = np.concatenate((idxs, [r]))
-        best = int(np.argmax(scores[idxs]))
-        deleted[np.delete(idxs, best)] = True
-    if deleted.all():
-        return b.to(bboxes.device)
-    return b[torch.from_numpy(~deleted)].to(bboxes.device)
+    groups = []
+    for t in tasks:
+        ids = torch.tensor(sorted(categories_map_per_task[t].values()), dtype=torch.int64, device=dev)
+        groups.append(torch.nonzero(torch.isin(cls, ids)).flatten())
+    max_det = max(max(int(g.numel()) for g in groups), 1)
+    rows, cnts = [], []
+    for g in groups:
+        r = torch.zeros((1, max_det, 6), dtype=torch.float32, device=dev)
+        r[0, :g.numel()] = b[g]
+        rows.append(r)
+        cnts.append(torch.tensor([g.numel()], dtype=torch.int32, device=dev))
+    out, cnt = ops.merge_tasks(rows, cnts, [0] * len(tasks), iou_thres, None)  # class ids are already global: offsets 0
+    return out[0, :int(cnt[0])].to(bboxes.device)

@@ -231,6 +231,24 @@ typedef struct {
 int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d);
 int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, void* ws, void* stream);
 
+/* Cross-task merge after the per-task NMS -- everything between non_max_suppression and the result dicts of
+ * CerberusDetInference.predict (cerberusdet_inference.py:72-83, 140-177; utils/general.py:484-554 nms_between_tasks, 313-357
+ * scale_boxes / clip_boxes): local class ids -> global ids (task-order offsets), rows grouped by task, IoU between boxes of
+ * DIFFERENT tasks only (box_iou of utils/metrics.py:415-433, eps 1e-7), greedy row scan: a live row with hits keeps only the
+ * best-scoring box of hits U {row} (first maximum in the order [hits ascending, row]); "nothing survives" keeps everything,
+ * as the reference does. Then optionally scale_boxes(net -> original shape) and round-half-even, all in fp32 like torch.
+ *   rows[t]   [N, max_det, 6] fp32 (x1,y1,x2,y2,conf,local cls) and counts[t] [N] i32: outputs of cdet_nms_batched per task
+ *   scale     [N, 5] fp32 (gain, pad_x, pad_y, h0, w0) or NULL (boxes stay in network coordinates, not rounded)
+ *   out_rows  [N, T*max_det, 6] fp32 (global class ids), out_count [N] i32.  T <= 8, T*max_det <= 2048. */
+typedef struct {
+    int32_t N, T, max_det;
+    float iou_thres;
+    const float* rows[8];
+    const int32_t* counts[8];
+    int32_t cls_offset[8];
+} cdet_merge_desc;
+int cdet_merge_tasks(const cdet_merge_desc* d, const float* scale, float* out_rows, int32_t* out_count, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor optimizer step (trainers/averaging.py:205-223, utils/torch_utils.py:302-312)
  * ---------------------------------------------------------------------------------------------- */

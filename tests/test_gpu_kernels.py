@@ -384,3 +384,72 @@ def test_pack_weights_batched_equals_per_item_pack():
         for (rf, rt), (wf, wt), shp in zip(refs, outs, shapes):
             assert torch.equal(rf.view(torch.int16), wf.view(torch.int16)), ("fwd", shp, dtype)
             assert torch.equal(rt.view(torch.int16), wt.view(torch.int16)), ("dgrad", shp, dtype)
+
+
+@pytest.mark.parametrize("with_scale", [False, True])
+def test_merge_tasks_matches_oracle_bit_exact(with_scale):
+    """cdet_merge_tasks (class remap + cross-task suppression + scale_boxes().round()) against the CPU restatement of
+    utils/general.py:484-554 / 313-357 on boxes with many cross-task overlaps, score ties and an all-deleted image."""
+    from oracle import nms as onms
+
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    N, T, max_det, ncs = 5, 3, 40, [4, 3, 5]
+    offs = [0, 4, 7]
+    cmap = {f"t{t}": {i: i + offs[t] for i in range(ncs[t])} for t in range(T)}
+    rows = [np.zeros((N, max_det, 6), np.float32) for _ in range(T)]
+    cnts = [np.zeros(N, np.int32) for _ in range(T)]
+    for n in range(N):
+        base = rng.uniform(0, 500, (max_det, 2)).astype(np.float32)
+        wh = rng.uniform(20, 120, (max_det, 2)).astype(np.float32)
+        for t in range(T):
+            k = int(rng.integers(max_det // 2, max_det + 1)) if n != 3 else 0 if t == 1 else 6
+            jit = rng.uniform(-3, 3, (max_det, 4)).astype(np.float32) * (t > 0)
+            b = np.concatenate([base, base + wh], 1) + jit
+            if n == 4:  # exact duplicates with tied scores across all tasks
+                b = np.concatenate([base, base + wh], 1)
+            sc = rng.uniform(0.3, 0.99, max_det).astype(np.float32)
+            if n == 4:
+                sc = np.linspace(0.9, 0.5, max_det).astype(np.float32)
+            order = np.argsort(-sc, kind="stable")
+            rows[t][n, :k, :4] = b[order][:k]
+            rows[t][n, :k, 4] = sc[order][:k]
+            rows[t][n, :k, 5] = rng.integers(0, ncs[t], k)
+            cnts[t][n] = k
+    shapes = [(480, 640), (720, 1280), (333, 500), (640, 640), (1080, 1920)]
+    scale = None
+    if with_scale:
+        sc_rows = []
+        for shp in shapes:
+            gain = min(640 / shp[0], 640 / shp[1])
+            sc_rows.append([gain, (640 - shp[1] * gain) / 2, (640 - shp[0] * gain) / 2, shp[0], shp[1]])
+        scale = torch.tensor(sc_rows, dtype=torch.float32, device=DEV)
+    out, cnt = ops.merge_tasks([torch.from_numpy(r).to(DEV) for r in rows], [torch.from_numpy(c).to(DEV) for c in cnts], offs, 0.8, scale)
+    torch.cuda.synchronize()
+    out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+    n_deleted = 0
+    for n in range(N):
+        det = np.concatenate([np.concatenate([rows[t][n, :cnts[t][n], :5], rows[t][n, :cnts[t][n], 5:6] + offs[t]], 1) for t in range(T)], 0)
+        want = onms.nms_between_tasks(det.copy(), cmap, 0.8) if len(det) else det
+        n_deleted += len(det) - len(want)
+        if with_scale and len(want):
+            want = want.copy()
+            want[:, :4] = np.round(onms.scale_boxes((640, 640), want[:, :4], shapes[n]))
+        assert cnt[n] == len(want), (n, cnt[n], len(want))
+        assert np.array_equal(out[n, :cnt[n]], want.astype(np.float32)), n
+    assert n_deleted > 50  # the suppression really fired
+
+
+def test_nms_between_tasks_api_matches_reference_golden():
+    """The reference-signature wrapper (rows [n,6] with global class ids, single image) on the reference's own golden case."""
+    from cerberusdet_amd.utils.general import nms_between_tasks
+    from oracle import nms as on
+    from util import GOLDEN
+
+    arrays = dict(np.load(GOLDEN / "nms.npz"))
+    _, _, names, _ = synth.predict_inputs()
+    cmap, _ = on.categories_map(names)
+    out = nms_between_tasks(torch.from_numpy(arrays["between/in"]), cmap, 0.8)
+    assert not out.is_cuda and np.array_equal(out.numpy(), arrays["between/out"])
+    out = nms_between_tasks(torch.from_numpy(arrays["between/in"]).to(DEV), cmap, 0.8)
+    assert out.is_cuda and np.array_equal(out.cpu().numpy(), arrays["between/out"])

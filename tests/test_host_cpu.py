@@ -146,13 +146,3 @@ def test_lr_schedule_and_param_groups_match_oracle():
         assert np.allclose(lrs, wl) and abs(mom - wm) < 1e-12
     assert tr.lrs(1001, 0)[0] == [meta["hyp"]["lr0"] * 0.9] * 3
 
-
-def test_nms_between_tasks_host_matches_golden():
-    from cerberusdet_amd.utils.general import nms_between_tasks
-    from oracle import nms as on
-
-    arrays = dict(np.load(GOLDEN / "nms.npz"))
-    _, _, names, _ = synth.predict_inputs()
-    cmap, _ = on.categories_map(names)
-    out = nms_between_tasks(torch.from_numpy(arrays["between/in"]), cmap, 0.8)
-    assert np.array_equal(out.numpy(), arrays["between/out"])
