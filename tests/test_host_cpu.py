@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import synth
-from util import GOLDEN
+from util import GOLDEN, load_golden
 
 ROOT = Path(__file__).resolve().parents[1]
 KA = json.load(open(GOLDEN / "graph_known_answers.json"))
@@ -146,3 +146,24 @@ def test_lr_schedule_and_param_groups_match_oracle():
         assert np.allclose(lrs, wl) and abs(mom - wm) < 1e-12
     assert tr.lrs(1001, 0)[0] == [meta["hyp"]["lr0"] * 0.9] * 3
 
+
+
+@pytest.mark.parametrize("which", ["tiny2", "tiny3"])
+def test_yolo_checkpoint_remap_matches_reference_golden(which):
+    """utils/ckpt_utils.py:dict_to_cerber + intersect_dicts of the reference (golden: tools/make_golden_ckpt.py) -- which YOLO entry
+    lands on which CerberusDet key, incl. the head copied to every task, an unknown layer and a shape mismatch."""
+    import json
+
+    from cerberusdet_amd.models import CerberusDet
+    from cerberusdet_amd.utils.ckpt_utils import dict_to_cerber, intersect_dicts
+
+    g = json.load(open(GOLDEN / "ckpt_remap.json"))[which]
+    _, mmeta = load_golden("model_tiny2" if which == "tiny2" else "model_tiny3")
+    m = CerberusDet(g["tasks"], g["nc"], cfg=copy.deepcopy(mmeta["cfg"]), verbose=False)  # un-split, as ModelsManager.from_ckpt sees it
+    yolo = {k: torch.full(tuple(shp), float(i)) for i, (k, shp) in enumerate(zip(g["yolo_keys"], g["yolo_shapes"]))}
+    mapped = dict_to_cerber(yolo, m)
+    assert {k: int(v.flatten()[0]) for k, v in mapped.items()} == g["mapped"]
+    final = intersect_dicts(mapped, m.state_dict(), exclude=["anchor"])
+    assert {k: int(v.flatten()[0]) for k, v in final.items()} == g["final"]
+    missing, unexpected = m.load_state_dict(final, strict=False)
+    assert not unexpected
