@@ -134,8 +134,14 @@ def kernel_breakdown(trainer, batches, n_max):
     for p in plans:
         p.fwd = instrument(p.fwd)
         p.bwd_groups = [(i, instrument(c)) for i, c in p.bwd_groups]
-    trainer.train_step(batches, n_max=n_max)
-    torch.cuda.synchronize()
+    # the event pairs need the kernels alone on the GPU: replay with the sequential schedule (in the timed region the two task passes
+    # share the GPU on two streams, where a stream-side event pair also spans the other stream's interleaved work)
+    ts, trainer.task_streams = trainer.task_streams, False
+    try:
+        trainer.train_step(batches, n_max=n_max)
+        torch.cuda.synchronize()
+    finally:
+        trainer.task_streams = ts
     for p, (f, b) in zip(plans, saved):
         p.fwd, p.bwd_groups = f, b
     agg = {}
@@ -305,7 +311,8 @@ def main():
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": a["n"],
-                               "avg_launch_ms": round(a["ms"] / a["n"], 4), "algorithmic_gflop_per_launch": round(a["flops"] / a["n"] / 1e9, 3)}
+                               "avg_launch_ms": round(a["ms"] / a["n"], 4), "algorithmic_gflop_per_launch": round(a["flops"] / a["n"] / 1e9, 3),
+                               "measured": "HIP events around every call of a sequential replay of one iteration (task streams off)"}
             # HBM traffic per launch of that entry point from the committed rocprofv3 PMC passes of this same command
             # (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction, WRITE_SIZE; separate passes) -- null when absent
             tf = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
