@@ -71,24 +71,26 @@ def test_two_iterations_vs_reference_golden():
         assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters() if p.grad is not None)
 
 
-def test_task_streams_bit_identical_to_sequential_schedule():
+@pytest.mark.parametrize("which", ["model_tiny2", "model_tiny3"])
+def test_task_streams_bit_identical_to_sequential_schedule(which):
     """train_step with one HIP stream per task pass (event chain on the shared blocks) must give bit-identical weights, BN running
     statistics, EMA and loss items to the sequential schedule of the reference (trainers/averaging.py:132-194)."""
     from cerberusdet_amd.trainers import Averaging
 
     arrays, meta = load_golden("trainer")
-    _, mmeta = load_golden("model_tiny2")
+    _, mmeta = load_golden(which)  # tiny3: three tasks, blocks shared by all of them and by two of them
+    tasks, ncs = mmeta["tasks"], mmeta["nc"]
     res = []
     for streams in (False, True):
         m = _model(meta, mmeta)
-        tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, task_streams=streams)
+        tr = Averaging(torch.device(DEV), m, meta["hyp"], tasks, epochs=100, nb=1000, task_streams=streams)
         assert tr.task_streams == streams
         items = []
         for it in range(3):
             batches = {}
-            for ti, t in enumerate(meta["tasks"]):
+            for ti, t in enumerate(tasks):
                 img = torch.from_numpy(synth.det_image(500 + 10 * it + ti, 4, 128)).to(DEV)
-                b = synth.make_batch(4, 3, meta["nc"][ti], 600 + 10 * it + ti)
+                b = synth.make_batch(4, 3, ncs[ti], 600 + 10 * it + ti)
                 batches[t] = dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()})
             out = tr.train_step(batches, ni=2000 + it)  # past warm-up: every group has lr > 0
             items.append({t: v.clone() for t, v in out.items()})
