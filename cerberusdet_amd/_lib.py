@@ -45,6 +45,10 @@ class MergeDesc(C.Structure):
     _fields_ = [("N", i32), ("T", i32), ("max_det", i32), ("iou_thres", f32), ("rows", vp * 8), ("counts", vp * 8), ("cls_offset", i32 * 8)]
 
 
+class MatchDesc(C.Structure):
+    _fields_ = [("N", i32), ("max_det", i32), ("T", i32), ("max_labels", i32)]
+
+
 class ParamSlot(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("lr", f32), ("weight_decay", f32),
                 ("inv_div", f32), ("first_step", i32)]
@@ -83,6 +87,7 @@ _SIGS = {
     "cdet_det_loss_ws_bytes": (i64, [C.POINTER(LossDesc)]),
     "cdet_det_loss": (i32, [C.POINTER(LossDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_nms_ws_bytes": (i64, [C.POINTER(NmsDesc)]),
+    "cdet_match_predictions": (i32, [C.POINTER(MatchDesc), vp, vp, vp, vp, vp, vp, vp]),
     "cdet_merge_tasks": (i32, [C.POINTER(MergeDesc), vp, vp, vp, vp]),
     "cdet_nms_batched": (i32, [C.POINTER(NmsDesc), vp, vp, vp, vp, vp]),
     "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp]),

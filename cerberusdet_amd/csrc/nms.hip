@@ -369,6 +369,70 @@ __global__ __launch_bounds__(256) void merge_tasks_kernel(const cdet_merge_desc 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// validation matcher (one workgroup per image): see cdet_match_predictions in include/cerberus_hip.h
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_predictions_kernel(const cdet_match_desc d, const float* __restrict__ det_rows,
+                                                                const int* __restrict__ det_count, const float* __restrict__ labels,
+                                                                const int* __restrict__ label_start, const float* __restrict__ iouv,
+                                                                uint8_t* __restrict__ correct) {
+#pragma clang fp contract(off)  // box_iou evaluates products, sums and the division as separate fp32 operations
+    extern __shared__ int owner[];  // [m][T]: lowest proposing prediction index per (label, IoU level)
+    const int img = blockIdx.x, tid = threadIdx.x, T = d.T;
+    const int n = min(det_count[img], d.max_det);
+    const int l0 = label_start[img], m = min(label_start[img + 1] - l0, d.max_labels);
+    for (int e = tid; e < m * T; e += 256) owner[e] = 0x7fffffff;
+    uint8_t* out = correct + (int64_t)img * d.max_det * T;
+    for (int e = tid; e < d.max_det * T; e += 256) out[e] = 0;
+    __syncthreads();
+    const float* lab = labels + (int64_t)l0 * 5;
+    // pass 1: every prediction finds its label and announces itself at the levels it reaches
+    for (int i = tid; i < n; i += 256) {
+        const float* r = det_rows + ((int64_t)img * d.max_det + i) * 6;
+        const float bx1 = r[0], by1 = r[1], bx2 = r[2], by2 = r[3], cls = r[5];
+        const float barea = (bx2 - bx1) * (by2 - by1);
+        float best = -1.f;
+        int bl = -1;
+        for (int l = 0; l < m; ++l) {
+            if (lab[l * 5] != cls) continue;
+            const float ax1 = lab[l * 5 + 1], ay1 = lab[l * 5 + 2], ax2 = lab[l * 5 + 3], ay2 = lab[l * 5 + 4];
+            const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+            const float inter = iw * ih;
+            const float iou = inter / ((ax2 - ax1) * (ay2 - ay1) + barea - inter + 1e-7f);
+            if (iou >= best) {
+                best = iou;
+                bl = l;
+            }
+        }
+        if (bl >= 0)
+            for (int t = 0; t < T; ++t)
+                if (best >= iouv[t]) atomicMin(&owner[bl * T + t], i);
+    }
+    __syncthreads();
+    // pass 2: recompute (cheaper than keeping per-thread state across the barrier for max_det > 256) and test ownership
+    for (int i = tid; i < n; i += 256) {
+        const float* r = det_rows + ((int64_t)img * d.max_det + i) * 6;
+        const float bx1 = r[0], by1 = r[1], bx2 = r[2], by2 = r[3], cls = r[5];
+        const float barea = (bx2 - bx1) * (by2 - by1);
+        float best = -1.f;
+        int bl = -1;
+        for (int l = 0; l < m; ++l) {
+            if (lab[l * 5] != cls) continue;
+            const float ax1 = lab[l * 5 + 1], ay1 = lab[l * 5 + 2], ax2 = lab[l * 5 + 3], ay2 = lab[l * 5 + 4];
+            const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+            const float inter = iw * ih;
+            const float iou = inter / ((ax2 - ax1) * (ay2 - ay1) + barea - inter + 1e-7f);
+            if (iou >= best) {
+                best = iou;
+                bl = l;
+            }
+        }
+        if (bl >= 0)
+            for (int t = 0; t < T; ++t) out[i * T + t] = (best >= iouv[t] && owner[bl * T + t] == i) ? 1 : 0;
+    }
+}
+
 }  // namespace cdet
 
 using namespace cdet;
@@ -415,6 +479,20 @@ extern "C" int cdet_merge_tasks(const cdet_merge_desc* d, const float* scale, fl
                    "cdet_merge_tasks: needs 1 <= T <= 8 and T*max_det <= %d (T=%d max_det=%d)", MERGE_MAX, d->T, d->max_det);
     for (int t = 0; t < d->T; ++t) CDET_CHECK_ARG(d->rows[t] && d->counts[t], "cdet_merge_tasks: null per-task pointer");
     hipLaunchKernelGGL(merge_tasks_kernel, dim3(d->N), dim3(256), 0, (hipStream_t)stream, *d, scale, out_rows, out_count);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_match_predictions(const cdet_match_desc* d, const float* det_rows, const int32_t* det_count, const float* labels,
+                                      const int32_t* label_start, const float* iouv, uint8_t* correct, void* stream) {
+    CDET_CHECK_ARG(d && det_rows && det_count && label_start && iouv && correct, "cdet_match_predictions: null pointer");
+    CDET_CHECK_ARG(d->N > 0 && d->max_det > 0 && d->T >= 1 && d->T <= 16 && d->max_labels >= 0, "cdet_match_predictions: bad descriptor");
+    const size_t shm = (size_t)(d->max_labels > 0 ? d->max_labels : 1) * d->T * sizeof(int);
+    CDET_CHECK_ARG(shm <= 160 * 1024, "cdet_match_predictions: max_labels*T too large for LDS (%d labels)", d->max_labels);
+    CDET_CHECK_ARG(labels || d->max_labels == 0, "cdet_match_predictions: labels is null");
+    if (shm > 48 * 1024) (void)hipFuncSetAttribute((const void*)match_predictions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(match_predictions_kernel, dim3(d->N), dim3(256), shm, (hipStream_t)stream, *d, det_rows, det_count, labels, label_start,
+                       iouv, correct);
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -298,3 +298,22 @@ def merge_tasks(rows_per_task, counts_per_task, cls_offsets, iou_thres=0.8, scal
     cnt = torch.zeros(N, dtype=torch.int32, device=dev)
     L.check(lib.cdet_merge_tasks(C.byref(d), ptr(scale), ptr(out), ptr(cnt), stream()), "cdet_merge_tasks")
     return out, cnt
+
+
+def match_predictions(det_rows: torch.Tensor, det_count: torch.Tensor, labels: torch.Tensor, label_start: torch.Tensor, iouv: torch.Tensor,
+                      max_labels: int) -> torch.Tensor:
+    """det_rows [N,max_det,6] + det_count [N] i32, labels [L,5] (cls,x1,y1,x2,y2) grouped by image via label_start [N+1] i32,
+    iouv [T] -> correct [N,max_det,T] uint8 (val.py:32-54 for the whole batch in one launch)."""
+    lib = L.load()
+    N, max_det, _ = det_rows.shape
+    d = L.MatchDesc()
+    d.N, d.max_det, d.T, d.max_labels = N, max_det, iouv.numel(), int(max_labels)
+    assert det_rows.is_contiguous() and det_rows.dtype == torch.float32 and det_count.dtype == torch.int32 and label_start.dtype == torch.int32
+    labels = labels.contiguous().float()
+    if labels.numel() == 0:  # no label in the whole batch: the kernel still wants a valid pointer
+        labels = torch.zeros((1, 5), dtype=torch.float32, device=det_rows.device)
+    iouv = iouv.contiguous().float()
+    out = torch.empty((N, max_det, d.T), dtype=torch.uint8, device=det_rows.device)
+    L.check(lib.cdet_match_predictions(C.byref(d), ptr(det_rows), ptr(det_count), ptr(labels), ptr(label_start), ptr(iouv),
+                                       ptr(out), stream()), "cdet_match_predictions")
+    return out

@@ -249,6 +249,19 @@ typedef struct {
 } cdet_merge_desc;
 int cdet_merge_tasks(const cdet_merge_desc* d, const float* scale, float* out_rows, int32_t* out_count, void* stream);
 
+/* Validation matcher, batched (val.py:32-54 process_batch + utils/metrics.py:415-433 box_iou): which predictions count as correct
+ * at T IoU levels. Every prediction proposes its best class-matching label (highest IoU; exact IoU ties -> the higher label
+ * index); at level t a label accepts, among the predictions proposing it with IoU >= iouv[t], the one with the LOWEST index.
+ *   det_rows [N, max_det, 6] fp32 (x1,y1,x2,y2,conf,cls) + det_count [N] i32   (cdet_nms_batched / cdet_merge_tasks output)
+ *   labels [L,5] fp32 (cls,x1,y1,x2,y2), grouped by image: image n owns rows label_start[n] .. label_start[n+1]-1
+ *   iouv [T] fp32, T <= 16; max_labels = upper bound of labels per image (sizes the LDS table, max_labels*T*4 <= 160 KiB)
+ *   correct [N, max_det, T] uint8 (rows >= det_count[n] are zeroed) */
+typedef struct {
+    int32_t N, max_det, T, max_labels;
+} cdet_match_desc;
+int cdet_match_predictions(const cdet_match_desc* d, const float* det_rows, const int32_t* det_count, const float* labels,
+                           const int32_t* label_start, const float* iouv, uint8_t* correct, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor optimizer step (trainers/averaging.py:205-223, utils/torch_utils.py:302-312)
  * ---------------------------------------------------------------------------------------------- */

@@ -160,3 +160,36 @@ def predict_inputs():
 TINY_WIDTH, TINY_DEPTH = 0.125, 0.33
 HYP = dict(box=[7.5, 7.5, 7.5], cls=[0.5, 0.5, 0.5], dfl=[1.5, 1.5, 1.5], lr0=0.00309, lrf=0.0956, momentum=0.952,
            weight_decay=0.00037, warmup_epochs=2.04, warmup_momentum=0.898, warmup_bias_lr=0.0502)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# validation matcher / AP cases (tools/make_golden_val.py): (seed, predictions, labels, classes)
+# ---------------------------------------------------------------------------------------------------------------------
+VAL_CASES = [(11, 120, 25, 4), (12, 300, 60, 6), (13, 40, 0, 3), (14, 0, 7, 3), (15, 200, 150, 2), (16, 17, 3, 5)]
+
+
+def val_case(seed, n, m, nc):
+    """n predictions [n,6] (xyxy, conf desc, cls) and m labels [m,5] (cls, xyxy) in a 640 x 480 image; most predictions are
+    jittered copies of labels (so IoUs spread over 0.3..1 and several predictions compete for one label), the rest is clutter."""
+    rng = np.random.default_rng(seed)
+    lab = np.zeros((m, 5), np.float32)
+    if m:
+        xy = rng.uniform(0, [540, 380], (m, 2))
+        wh = rng.uniform(30, 100, (m, 2))
+        lab[:, 1:3], lab[:, 3:5] = xy, xy + wh
+        lab[:, 0] = rng.integers(0, nc, m)
+    det = np.zeros((n, 6), np.float32)
+    if n:
+        for i in range(n):
+            if m and rng.random() < 0.75:
+                j = int(rng.integers(0, m))
+                w, h = lab[j, 3] - lab[j, 1], lab[j, 4] - lab[j, 2]
+                jit = rng.normal(0, 0.08, 4) * np.array([w, h, w, h])
+                det[i, :4] = lab[j, 1:5] + jit
+                det[i, 5] = lab[j, 0] if rng.random() < 0.85 else rng.integers(0, nc)
+            else:
+                xy = rng.uniform(0, [540, 380], 2)
+                det[i, :2], det[i, 2:4] = xy, xy + rng.uniform(30, 100, 2)
+                det[i, 5] = rng.integers(0, nc)
+        det[:, 4] = np.sort(rng.uniform(0.01, 0.99, n).astype(np.float32))[::-1]
+    return det, lab

@@ -453,3 +453,62 @@ def test_nms_between_tasks_api_matches_reference_golden():
     assert not out.is_cuda and np.array_equal(out.numpy(), arrays["between/out"])
     out = nms_between_tasks(torch.from_numpy(arrays["between/in"]).to(DEV), cmap, 0.8)
     assert out.is_cuda and np.array_equal(out.cpu().numpy(), arrays["between/out"])
+
+
+def test_match_predictions_and_ap_match_reference_golden():
+    """cdet_match_predictions (whole batch, one launch) against val.process_batch of the REAL reference (tests/golden/val.npz), the
+    reference-signature wrapper, and the host AP against utils/metrics.ap_per_class."""
+    from cerberusdet_amd.utils.metrics import ap_per_class, process_batch
+    from util import GOLDEN
+
+    ops = _ops()
+    g = dict(np.load(GOLDEN / "val.npz"))
+    cases = [synth.val_case(*c) for c in synth.VAL_CASES]
+    N, max_det = len(cases), max(max(c[0].shape[0] for c in cases), 1)
+    rows = np.zeros((N, max_det, 6), np.float32)
+    cnt = np.zeros(N, np.int32)
+    start = np.zeros(N + 1, np.int32)
+    for i, (det, lab) in enumerate(cases):
+        rows[i, :len(det)], cnt[i], start[i + 1] = det, len(det), start[i] + len(lab)
+    labels = np.concatenate([lab for _, lab in cases], 0)
+    iouv = torch.from_numpy(g["iouv"]).to(DEV)
+    correct = ops.match_predictions(torch.from_numpy(rows).to(DEV), torch.from_numpy(cnt).to(DEV), torch.from_numpy(labels).to(DEV),
+                                    torch.from_numpy(start).to(DEV), iouv, max_labels=max(len(lab) for _, lab in cases))
+    torch.cuda.synchronize()
+    correct = correct.cpu().numpy()
+    stats = []
+    for i, (det, lab) in enumerate(cases):
+        want = g[f"case{i}/correct"]
+        assert np.array_equal(correct[i, :len(det)].astype(bool), want), i
+        assert not correct[i, len(det):].any()
+        if len(det):
+            single = process_batch(torch.from_numpy(det), torch.from_numpy(lab), iouv.cpu())
+            assert np.array_equal(single.numpy(), want), i
+        stats.append((want, det[:, 4], det[:, 5], lab[:, 0]))
+    tp, conf, pcls, tcls = [np.concatenate(x, 0) for x in zip(*stats)]
+    r = ap_per_class(tp, conf, pcls, tcls)
+    for k, v in zip(("tp", "fp", "p", "r", "f1", "ap", "classes"), r):
+        assert np.allclose(np.asarray(v, np.float64), g[f"ap/{k}"].astype(np.float64), rtol=1e-9, atol=1e-12), k
+
+
+def test_val_run_smoke_on_tiny_model():
+    """val.run end to end on the tiny golden model: finite metrics, every image seen, labels counted."""
+    import copy
+
+    from cerberusdet_amd import val
+    from cerberusdet_amd.models import CerberusDet
+    from util import load_golden
+
+    _, mmeta = load_golden("model_tiny2")
+    m = CerberusDet(mmeta["tasks"], mmeta["nc"], cfg=copy.deepcopy(mmeta["cfg"]), verbose=False)
+    m.sequential_split(mmeta["cfg"]["cerber"], "cpu")
+    sd = m.state_dict()
+    m.load_state_dict({k: torch.from_numpy(synth.det_tensor(mmeta["seed"], k, v.shape)) for k, v in sd.items()})
+    m = m.to(DEV).eval()
+    batches = []
+    for i in range(2):
+        b = synth.make_batch(4, 3, mmeta["nc"][0], 700 + i)
+        batches.append(dict(img=torch.from_numpy(synth.det_image(800 + i, 4, 128)), **{k: torch.from_numpy(v) for k, v in b.items()}))
+    res = val.run(m, mmeta["tasks"][0], batches, half=False)
+    assert res["seen"] == 8 and int(res["nt"].sum()) == 24
+    assert all(np.isfinite(res[k]) and 0.0 <= res[k] <= 1.0 for k in ("mp", "mr", "map50", "map"))

@@ -261,3 +261,20 @@ def test_train_fixture_sensitivity():
         of = og.forward(g, wq, x, "voc", training=True)
     errs = [np.linalg.norm(of[i].numpy() - arrays[f"train/voc/feat{i}"]) / np.linalg.norm(arrays[f"train/voc/feat{i}"]) for i in range(3)]
     assert 0.02 < errs[0] < 0.2 and 0.02 < errs[2] < 0.3, errs
+
+
+def test_val_matcher_and_ap_match_reference_golden():
+    """oracle.val.process_batch / ap_per_class against val.py:32-54 and utils/metrics.py:56-148 of the real reference."""
+    from oracle import val as ov
+
+    g = dict(np.load(GOLDEN / "val.npz"))
+    stats = []
+    for ci, (seed, n, m, nc) in enumerate(synth.VAL_CASES):
+        det, lab = synth.val_case(seed, n, m, nc)
+        correct = ov.process_batch(det, lab, g["iouv"])
+        assert np.array_equal(correct, g[f"case{ci}/correct"]), ci
+        stats.append((correct, det[:, 4], det[:, 5], lab[:, 0]))
+    tp, conf, pcls, tcls = [np.concatenate(x, 0) for x in zip(*stats)]
+    r = ov.ap_per_class(tp, conf, pcls, tcls)
+    for k, v in zip(("tp", "fp", "p", "r", "f1", "ap", "classes"), r):
+        assert np.allclose(np.asarray(v, np.float64), g[f"ap/{k}"].astype(np.float64), rtol=1e-9, atol=1e-12), k
