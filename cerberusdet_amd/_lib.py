@@ -111,6 +111,11 @@ def load():
         raise CdetError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C {_HERE / 'csrc'}`). cerberusdet_amd has no CPU fallback by design.")
+    # torch first: it brings its own libamdhip64.so.7, and the extension must resolve its HIP runtime to THAT copy (the same
+    # runtime instance that owns torch's streams and allocations). Loaded the other way round, /opt/rocm's copy comes in as a
+    # second runtime and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
