@@ -1,0 +1,171 @@
+"""Full-size checks on the MI355X at BASELINE.json's configuration (YOLOv8x 2-task, batch 32 per task @640, inference batch 128),
+where no CPU oracle finishes in seconds: size-independent properties that pin the kernels exactly.
+
+* convolution: with small-integer operands every product and every partial sum is an exact fp32 integer, so the checksum identity
+  sum(y) = <colsum(w), im2col-sums(x)> and the adjoint identities <conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)> hold
+  EXACTLY for the layer shapes that dominate the step (stride 1, stride 2 with its parity-class data gradient, 1x1);
+* one training pass of the real model: loss identity scalar = 2*bs*total, finite gradients everywhere, a second identical pass
+  exactly doubles every accumulated gradient (determinism + accumulate variants);
+* NMS at batch 128 x 8400 anchors: descending scores, no surviving same-class pair above the IoU threshold, idempotence;
+* assignment at batch 32: every foreground anchor lies inside its ground-truth box, at most top-k anchors per ground truth, scores
+  only on foreground anchors and on the assigned class.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (N, H, W, Cin, Cout, k, s): the layers that dominate the iteration + a stride-2 and a 1x1 layer
+FULL_CONVS = [(32, 40, 40, 320, 320, 3, 1), (32, 80, 80, 160, 160, 3, 1), (32, 160, 160, 80, 80, 3, 1), (32, 80, 80, 320, 640, 3, 2),
+              (32, 40, 40, 1600, 640, 1, 1)]
+
+
+@pytest.mark.parametrize("case", FULL_CONVS)
+def test_conv_checksum_and_adjoint_identities_exact(case):
+    from cerberusdet_amd import _lib as L
+    from cerberusdet_amd import ops
+
+    N, H, W, Ci, Co, k, s = case
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randint(-2, 3, (N, H, W, Ci), generator=g, device=DEV).to(torch.bfloat16)
+    w = torch.randint(-1, 2, (Co, Ci, k, k), generator=g, device=DEV).float()
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    dy = torch.randint(-2, 3, (N, Ho, Wo, Co), generator=g, device=DEV).to(torch.bfloat16)
+    xv, dyv = ops.View(x), ops.View(dy)
+    # forward into fp32 (exact integers: |y| <= 2 * k*k*Ci)
+    y = ops.new_act(N, Ho, Wo, Co, torch.float32)
+    ops.conv2d(xv, ops.pack_weight(w, torch.bfloat16), y, k, s)
+    # checksum of checksums: sum_p y[p, co] summed over co = sum_k colsum_w[k] * tapsum_x[k]
+    xs = x.float().permute(0, 3, 1, 2)
+    # tapsum[ci, kh, kw] = sum over the output pixels of the input element that tap reads (zero padding included)
+    p = k // 2
+    xp = F.pad(xs, (p, p, p, p)).double()
+    tsum = torch.empty(Ci, k, k, dtype=torch.float64, device=DEV)
+    for kh in range(k):
+        for kw in range(k):
+            tsum[:, kh, kw] = xp[:, :, kh:kh + s * (Ho - 1) + 1:s, kw:kw + s * (Wo - 1) + 1:s].sum((0, 2, 3))
+    want = (w.double().sum(0) * tsum).sum()
+    got = y.buf.double().sum()
+    assert float(got) == float(want), (float(got), float(want))
+    # adjoint identities, all operands exact
+    lhs = (y.buf.double() * dy.double()).sum()
+    dx = ops.new_act(N, H, W, Ci, torch.float32)
+    ops.conv2d(dyv, ops.pack_weight(w, torch.bfloat16, transpose=True), dx, k, s, mode=L.CONV_DGRAD)
+    assert float((dx.buf.double() * x.double()).sum()) == float(lhs)
+    dw = torch.zeros(Co, Ci, k, k, device=DEV)
+    ops.conv2d_wgrad(xv, dyv, dw, k, s)
+    assert float((dw.double() * w.double()).sum()) == float(lhs)
+    assert float(dw.abs().max()) < 2 ** 24  # the fp32 sums really were exact integers
+
+
+@pytest.fixture(scope="module")
+def v8x_trainer():
+    import bench
+    from cerberusdet_amd.trainers import Averaging
+
+    dev = torch.device(DEV, 0)
+    model, _ = bench.build_model("v8x_2task.yaml", dev)
+    tr = Averaging(dev, model, bench.HYP, bench.TASKS, use_ema=False)
+    batches = {t: bench.synth_batch(0, ti, 0, 32, [20, 19][ti], 640, dev) for ti, t in enumerate(bench.TASKS)}
+    return model, tr, batches
+
+
+def test_full_model_pass_loss_identity_and_exact_gradient_doubling(v8x_trainer):
+    model, tr, batches = v8x_trainer
+    import bench
+
+    t = bench.TASKS[0]
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    loss5 = tr.forward_backward(t, batches[t], n_max=8, active_tasks=[t])
+    torch.cuda.synchronize()
+    l = loss5.tolist()
+    assert all(math.isfinite(v) for v in l)
+    assert abs(l[3] - (l[0] + l[1] + l[2])) <= 1e-5 * abs(l[3])          # total = box + cls + dfl (utils/loss.py:176-181)
+    assert abs(l[4] - 2 * 32 * l[3]) <= 1e-5 * abs(l[4])                 # scalar = 2 * bs * total
+    named = {k: p for k, p in model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+    assert len(named) >= 180  # every parameter on the task's path received a gradient
+    g1 = {k: p.grad.clone() for k, p in named.items()}
+    assert all(bool(torch.isfinite(g).all()) for g in g1.values())
+    loss5b = tr.forward_backward(t, batches[t], n_max=8, active_tasks=[t])
+    torch.cuda.synchronize()
+    assert torch.equal(loss5, loss5b)  # train-mode BN uses batch statistics: the second pass is the same computation
+    for k, p in named.items():
+        assert torch.equal(p.grad, 2 * g1[k]), k  # g + g is exact in fp32: bit-identical kernels, correct accumulate variants
+
+
+def test_nms_full_batch_properties():
+    import bench
+    from cerberusdet_amd import ops
+
+    pred = bench.nms_inputs(128, 20, 8400).to(DEV)
+    rows, cnt = ops.nms_batched(pred, 0.25, 0.45, max_det=300)
+    torch.cuda.synchronize()
+    rows_h, cnt_h = rows.cpu(), cnt.cpu().tolist()
+    assert all(0 < c <= 300 for c in cnt_h)
+    for i in (0, 17, 127):
+        r = rows_h[i, :cnt_h[i]]
+        assert bool((r[1:, 4] <= r[:-1, 4]).all())  # descending confidence
+        assert bool((r[:, 4] > 0.25).all())
+        b = r[:, :4] + r[:, 5:6] * 7680.0  # class offsets as in general.py:462
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt, rb = torch.max(b[:, None, :2], b[None, :, :2]), torch.min(b[:, None, 2:], b[None, :, 2:])
+        inter = (rb - lt).clamp(0).prod(2)
+        iou = inter / (area[:, None] + area[None] - inter)
+        iou.fill_diagonal_(0)
+        assert float(iou.max()) <= 0.45  # no surviving pair of one class above the threshold
+    # idempotence: the survivors, fed back as the only candidates, all survive in the same order
+    i = 5
+    k = cnt_h[i]
+    r = rows[i, :k]
+    again = torch.zeros((1, 24, 8400), dtype=torch.float32, device=DEV)
+    again[0, 0, :k], again[0, 1, :k] = (r[:, 0] + r[:, 2]) / 2, (r[:, 1] + r[:, 3]) / 2
+    again[0, 2, :k], again[0, 3, :k] = r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]
+    again[0, 4 + r[:, 5].long(), torch.arange(k, device=DEV)] = r[:, 4]
+    rows2, cnt2 = ops.nms_batched(again, 0.25, 0.45, max_det=300)
+    assert int(cnt2[0]) == k
+    assert torch.equal(rows2[0, :k, 4:], r[:, 4:]) and torch.allclose(rows2[0, :k, :4], r[:, :4], atol=1e-3)
+
+
+def test_assignment_full_batch_properties():
+    import bench
+    from cerberusdet_amd import ops
+    from cerberusdet_amd.utils.loss import pad_targets
+
+    N, nc, topk = 32, 20, 10
+    g = torch.Generator(device=DEV).manual_seed(3)
+    feats = [torch.randn((N, 640 // s, 640 // s, 64 + 24), generator=g, device=DEV) * 0.5 for s in (8, 16, 32)]
+    for f in feats:
+        f[..., 64:64 + nc] -= 4.0  # realistic low class logits
+    batch = bench.synth_batch(0, 0, 1, N, nc, 640, torch.device(DEV, 0))
+    gt = pad_targets(batch, N, (640, 640), torch.device(DEV, 0), n_max=8)
+    loss5, dfe, asg = ops.det_loss(feats, gt, nc, dict(box=7.5, cls=0.5, dfl=1.5), (8, 16, 32), want_assign=True, topk=topk)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss5).all()) and all(bool(torch.isfinite(d).all()) for d in dfe)
+    fg, gi = asg["fg_mask"].bool(), asg["target_gt_idx"].long()
+    # anchor centres in pixels, level by level (utils/tal.py:181-193)
+    pts = []
+    for s in (8, 16, 32):
+        n = 640 // s
+        yy, xx = torch.meshgrid(torch.arange(n, device=DEV) + 0.5, torch.arange(n, device=DEV) + 0.5, indexing="ij")
+        pts.append(torch.stack((xx.flatten(), yy.flatten()), 1) * s)
+    pts = torch.cat(pts, 0)
+    assert int(fg.sum()) > 0
+    for b in range(N):
+        idx = torch.nonzero(fg[b]).flatten()
+        box = gt[b, gi[b, idx], 1:5]
+        c = pts[idx]
+        assert bool(((c[:, 0] > box[:, 0]) & (c[:, 0] < box[:, 2]) & (c[:, 1] > box[:, 1]) & (c[:, 1] < box[:, 3])).all())
+        per_gt = torch.bincount(gi[b, idx], minlength=gt.shape[1])
+        assert int(per_gt.max()) <= topk
+        assert bool((asg["target_labels"][b, idx].long() == gt[b, gi[b, idx], 0].long()).all())
+    ts = asg["target_scores"]
+    assert float(ts[~fg].abs().max()) == 0.0
+    on_label = torch.zeros_like(ts, dtype=torch.bool).scatter_(2, asg["target_labels"].long().clamp(0, nc - 1).unsqueeze(-1), True)
+    assert float(ts[~on_label].abs().max()) == 0.0
