@@ -946,10 +946,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_pipe_kernel
     constexpr int RORD[9] = {0, 5, 6, 7, 8, 1, 2, 3, 4};
 
     u32x4 a0[5], b0[4], a1[5], b1[4];
+    // all NS stages are requested before the first wait: only tile 0's latency is exposed
     stage(0, true);
-    if (NS == 3) stage(1, nk > 1);
-    __syncthreads();
-    stage(NS - 1, nk > NS - 1);
+    stage(1, nk > 1);
+    if (NS == 3) stage(2, nk > 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * NV) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 9; ++r) frag1(0, 0, r, a0, b0);
     int cur = 0;

@@ -437,11 +437,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_pipe_kernel(const WgradArgs a,
     constexpr int RORD[9] = {0, 4, 5, 6, 7, 8, 1, 2, 3};  // the first MFMAs of a phase need A row 0 and all five B columns
 
     u32x4 a0[4], b0[5], a1[4], b1[5];
+    // both stages are requested before the first wait: only step 0's latency is exposed
 #pragma unroll
     for (int i = 0; i < NV; ++i) dma_piece(i, 0, true);
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) dma_piece(i, 1, nsteps > 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 9; ++r) frag1(0, 0, r, a0, b0);
     for (int ks = 0; ks < nsteps; ++ks) {
