@@ -474,14 +474,18 @@ class CerberusDet(nn.Module):
 
         training = self.training if training is None else training
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
-        key = (tuple(tasks), tuple(shape), img_dtype, training, self.compute_dtype, bool(getattr(self, "sync_bn", False)))
+        frozen = ()
+        if training:  # blocks whose parameters are all frozen (freeze_shared_layers) compile in eval form without backward
+            frozen = tuple(i for i, b in enumerate(self.blocks)
+                           if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters()))
+        key = (tuple(tasks), tuple(shape), img_dtype, training, self.compute_dtype, bool(getattr(self, "sync_bn", False)), frozen)
         plan = self._plans.get(key)
         if plan is None:
             dev = next(super().parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
             N, c, H, W = shape
-            plan = Plan(self, tasks, N, H, W, training, self.compute_dtype, img_dtype, dev)
+            plan = Plan(self, tasks, N, H, W, training, self.compute_dtype, img_dtype, dev, frozen=frozen)
             self._plans[key] = plan
         return plan
 

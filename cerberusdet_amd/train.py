@@ -120,6 +120,10 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
     results = {}
     for epoch in range(opt.epochs):
         trainer.epoch = epoch
+        if epoch < opt.freeze_shared_till_epoch:  # reference trainers/averaging.py:100-103
+            trainer.set_shared_frozen(True)
+        elif 0 < opt.freeze_shared_till_epoch == epoch:
+            trainer.set_shared_frozen(False)
         t0 = time.time()
         for i in range(nb):
             batches = {}

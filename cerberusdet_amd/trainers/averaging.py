@@ -73,13 +73,14 @@ class GradReducer:
             dist.get_world_size(group) > 1 or os.environ.get("CDET_REDUCE_ALWAYS") == "1")
         self.handles: List = []
         self.reduced_bytes = 0
+        self.skip_blocks = set()  # frozen blocks: no gradient to reduce
 
     def last_task(self, block_idx: int, active_tasks: Optional[Sequence[str]] = None) -> Optional[str]:
         tasks = [t for t in (active_tasks or self.task_order) if t in self.serving.get(block_idx, ())]
         return tasks[-1] if tasks else None
 
     def on_block_backward(self, block_idx: int, task: str, active_tasks: Optional[Sequence[str]] = None):
-        if not self.enabled or block_idx not in self.buckets:
+        if not self.enabled or block_idx not in self.buckets or block_idx in self.skip_blocks:
             return
         if self.last_task(block_idx, active_tasks) != task:
             return  # a later task of this iteration still adds to the bucket: reduce once, after local summation
@@ -128,7 +129,7 @@ class Averaging:
         model._plans = {}  # plans pre-bind gradient pointers: compile them after the buckets below exist
         buckets: Dict[int, torch.Tensor] = {}
         for bi, block in enumerate(model.blocks):
-            ps = [p for p in block.parameters() if p.requires_grad]
+            ps = list(block.parameters())  # frozen parameters get a (zero) bucket slice too: they may be unfrozen later
             if not ps:
                 continue
             flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=device)
@@ -140,11 +141,9 @@ class Averaging:
                 model._pgrad[id(p)] = g
                 p.grad = g
         for k, p in names.items():
-            if not p.requires_grad:
-                continue
             bi = int(k.split(".")[1])
             self.slots_meta.append(dict(p=p, g=model._pgrad[id(p)], mom=torch.zeros_like(p), ema=ema_sd.get(k), group=group_of[id(p)],
-                                        div=max(len(self.serving[bi]), 1), key=k))
+                                        div=max(len(self.serving[bi]), 1), key=k, stepped=False))
         if self.ema:
             msd = dict(model.named_buffers())
             for k, v in msd.items():
@@ -228,15 +227,27 @@ class Averaging:
         for st in streams:
             cur.wait_stream(st)
 
+    def set_shared_frozen(self, frozen: bool):
+        """--freeze-shared-till-epoch (reference trainers/averaging.py:100-103, models/cerberus.py:885-925): the blocks that serve
+        every task stop training -- their parameters take part in neither the clipping norm nor the update (a frozen slot is an
+        EMA-only slot), their BatchNorms run from the running statistics, and the engine compiles them without a backward."""
+        from ..models import CerberusDet
+
+        (CerberusDet.freeze_shared_layers if frozen else CerberusDet.unfreeze_shared_layers)(self.model)
+        self._slot_key = None
+        self.reducer.skip_blocks = {i for i, b in enumerate(self.model.blocks)
+                                    if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters())}
+
     def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None):
         self.reducer.wait()
-        first = self.steps == 0
-        key = (tuple(lrs), first, tuple(sorted(n_serving.items())) if n_serving else None)
+        live = [m["g"] is not None and m["p"].requires_grad for m in self.slots_meta]
+        fresh = sum(1 for m, a in zip(self.slots_meta, live) if a and not m.get("stepped", True))
+        key = (tuple(lrs), fresh, tuple(sorted(n_serving.items())) if n_serving else None, hash(tuple(live)))
         if key != self._slot_key:
             for i, m in enumerate(self.slots_meta):
                 s = self._slots_host[i]
                 s.p, s.n = m["p"].data_ptr(), m["p"].numel()
-                s.g = m["g"].data_ptr() if m["g"] is not None else None
+                s.g = m["g"].data_ptr() if live[i] else None  # frozen parameter: EMA-only slot
                 s.mom = m["mom"].data_ptr() if m["mom"] is not None else None
                 s.ema = m["ema"].data_ptr() if m["ema"] is not None else None
                 if m["group"] >= 0:
@@ -244,7 +255,7 @@ class Averaging:
                     s.weight_decay = self.weight_decay if m["group"] == 0 else 0.0
                     div = m["div"] if n_serving is None else max(n_serving.get(int(m["key"].split(".")[1]), 1), 1)
                     s.inv_div = 1.0 / div
-                s.first_step = int(first)
+                s.first_step = int(not m.get("stepped", True))  # momentum buffer starts as the first clipped gradient (torch SGD)
             self._slots_dev.copy_(torch.frombuffer(bytearray(bytes(self._slots_host)), dtype=torch.uint8), non_blocking=False)
             self._slot_key = key
         st = torch.cuda.current_stream().cuda_stream
@@ -255,6 +266,10 @@ class Averaging:
             d = self.ema.decay(self.ema.updates)
         L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), 10.0, float(momentum), float(d), st),
                 "cdet_sgd_ema_step")
+        if fresh:
+            for m, a in zip(self.slots_meta, live):
+                if a:
+                    m["stepped"] = True
         self.model.mark_weights_changed()
         self.steps += 1
 

@@ -108,6 +108,72 @@ def test_task_streams_bit_identical_to_sequential_schedule(which):
     assert changed > len(sa) // 2  # the steps really moved the model
 
 
+def test_freeze_shared_layers_then_unfreeze():
+    """--freeze-shared-till-epoch (reference trainers/averaging.py:100-103, cerberus.py:885-925): while frozen, the blocks that serve
+    every task keep their weights AND BatchNorm running statistics bit for bit, run from the running statistics (their output equals
+    the eval forward), the branches keep learning; after unfreezing they move again and their momentum starts fresh."""
+    from cerberusdet_amd.trainers import Averaging
+
+    arrays, meta = load_golden("trainer")
+    _, mmeta = load_golden("model_tiny2")
+    m = _model(meta, mmeta)
+    tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False)
+    shared = {i for i, ts in tr.serving.items() if len(ts) == len(meta["tasks"])}
+    assert shared and len(shared) < len(m.blocks)
+
+    def batches(it):
+        out = {}
+        for ti, t in enumerate(meta["tasks"]):
+            img = torch.from_numpy(synth.det_image(900 + 10 * it + ti, 4, 128)).to(DEV)
+            b = synth.make_batch(4, 3, meta["nc"][ti], 950 + 10 * it + ti)
+            out[t] = dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()})
+        return out
+
+    def snap():
+        return {k: v.clone() for k, v in m.state_dict().items()}
+
+    is_shared = lambda k: int(k.split(".")[1]) in shared  # noqa: E731
+    tr.train_step(batches(0), ni=3000)  # one ordinary step first (running statistics move away from their initial values)
+    tr.set_shared_frozen(True)
+    s0 = snap()
+    x = batches(3)[meta["tasks"][0]]["img"]
+    plan = m.get_plan(meta["tasks"][0], tuple(x.shape), x.dtype, training=True)
+    assert plan.dead == shared and plan.frozen_convs
+    for it in (1, 2):
+        tr.train_step(batches(it), ni=3000 + it)
+    torch.cuda.synchronize()
+    s1 = snap()
+    for k in s0:
+        if "num_batches_tracked" in k:
+            continue
+        if is_shared(k):
+            assert torch.equal(s0[k], s1[k]), k  # weights, biases, BN running statistics: untouched
+    assert sum(int(not torch.equal(s0[k], s1[k])) for k in s0 if not is_shared(k) and s0[k].dtype.is_floating_point) > 50
+    # the frozen trunk computes the eval forward: its last convolution writes the same activations in the training plan and in an
+    # eval plan (same kernels, same folded operands -> bit-identical)
+    plan.run_forward(x)
+    pe = m.get_plan(meta["tasks"][0], tuple(x.shape), x.dtype, training=False)
+    pe.run_forward(x)
+    torch.cuda.synchronize()
+
+    def trunk_out(p):
+        end = dict(p.fwd_marks)[max(shared)]
+        dst = next(args[6] for fn, args in reversed(p.fwd[:end]) if getattr(fn, "__name__", "") == "cdet_conv2d")
+        return next(t for t in p.keep if isinstance(t, torch.Tensor) and t.data_ptr() == dst)
+
+    ta, tb = trunk_out(plan), trunk_out(pe)
+    assert ta.data_ptr() != tb.data_ptr() and float(ta.float().abs().max()) > 0
+    assert torch.equal(ta, tb)
+    # unfreeze: the shared blocks learn again
+    tr.set_shared_frozen(False)
+    tr.train_step(batches(4), ni=3004)
+    torch.cuda.synchronize()
+    s2 = snap()
+    moved = [k for k in s1 if is_shared(k) and s1[k].dtype.is_floating_point and "running" not in k and not torch.equal(s1[k], s2[k])]
+    assert len(moved) > 20
+    assert all(bool(torch.isfinite(v).all()) for v in s2.values() if v.dtype.is_floating_point)
+
+
 def test_grad_accumulation_and_block_division():
     """Shared blocks accumulate both tasks' gradients and are divided by 2, branch blocks by 1 (averaging.py:211-217):
     with lr > 0 only for one group we can read the applied update back."""
