@@ -330,9 +330,9 @@ def main():
                     out["roofline"]["traffic_source"] = tf[-1].name
             out["mfma_kernels"] = {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "ms": round(v["ms"], 2), "launches": v["n"]}
                                    for k, v in agg.items() if v["flops"] > 0}
-        if not args.no_infer:
+        if not args.no_infer and world == 1:
             out["inference"] = inference_section(model, device)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would just wait at the barrier
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
     if use_dist:
