@@ -137,11 +137,12 @@ def kernel_breakdown(trainer, batches, n_max):
     # the event pairs need the kernels alone on the GPU: replay with the sequential schedule (in the timed region the two task passes
     # share the GPU on two streams, where a stream-side event pair also spans the other stream's interleaved work)
     ts, trainer.task_streams = trainer.task_streams, False
+    red, trainer.reducer.enabled = trainer.reducer.enabled, False  # rank 0 replays alone: no collectives in the replay
     try:
         trainer.train_step(batches, n_max=n_max)
         torch.cuda.synchronize()
     finally:
-        trainer.task_streams = ts
+        trainer.task_streams, trainer.reducer.enabled = ts, red
     for p, (f, b) in zip(plans, saved):
         p.fwd, p.bwd_groups = f, b
     agg = {}
@@ -301,7 +302,7 @@ def main():
             "step_tflop_per_gpu": round(step_tflop, 2), "achieved_tflops_per_gpu": round(step_tflop / (ms_per_step / 1e3), 1),
             "loss_items": loss_items, "loss_finite": bool(finite),
         }
-        if not args.no_breakdown:
+        if not args.no_breakdown and not (args.sync_bn and world > 1):  # (SyncBN's per-layer collectives cannot be replayed by one rank)
             agg = kernel_breakdown(trainer, data[0], n_max)
             tot = sum(a["ms"] for a in agg.values())
             out["kernel_ms"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
