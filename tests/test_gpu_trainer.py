@@ -247,3 +247,29 @@ def test_sync_bn_path_world1_equals_local_bn():
             assert cos > 0.99 and abs(float(b_.norm() / a.norm()) - 1) < 0.05, (k, cos)
     finally:
         dist.destroy_process_group()
+
+
+def test_overfits_a_fixed_batch():
+    """End-to-end sanity of the whole loop (forward, criterion, backward, clip, SGD-Nesterov, EMA): repeating one small batch per task
+    must drive both tasks' losses down."""
+    from cerberusdet_amd.trainers import Averaging
+
+    arrays, meta = load_golden("trainer")
+    _, mmeta = load_golden("model_tiny2")
+    m = _model(meta, mmeta)
+    hyp = dict(meta["hyp"], lr0=0.01, warmup_epochs=0.0)
+    tr = Averaging(torch.device(DEV), m, hyp, meta["tasks"], epochs=100, nb=1000)
+    batches = {}
+    for ti, t in enumerate(meta["tasks"]):
+        img = torch.from_numpy(synth.det_image(40 + ti, 8, 128)).to(DEV)
+        b = synth.make_batch(8, 3, meta["nc"][ti], 60 + ti)
+        batches[t] = dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()})
+    hist = []
+    for it in range(120):
+        out = tr.train_step(batches, ni=5000 + it)
+        if it % 10 == 0 or it == 119:
+            hist.append({t: float(v[3]) for t, v in out.items()})
+    print(hist[0], hist[len(hist) // 2], hist[-1])
+    for t in meta["tasks"]:
+        assert all(np.isfinite(h[t]) for h in hist)
+        assert hist[-1][t] < 0.8 * hist[0][t], (t, hist[0][t], hist[-1][t])
