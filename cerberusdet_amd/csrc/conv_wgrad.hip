@@ -496,8 +496,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_elem_kernel(const float* __r
         const int kh = (int)(r % KH);
         const int o = (int)(r / KH);
         const int k = (kh * KW + kw) * I + i;
-        float sum = 0.f;
-        for (int s = 0; s < S; ++s) sum += ws[((int64_t)s * Cd_pad + o) * Kp + k];
+        // eight interleaved partial sums keep eight slab loads in flight (narrow layers have up to ~170 splits); the association
+        // is fixed, so the result stays run-to-run identical
+        const float* src = ws + (int64_t)o * Kp + k;
+        const int64_t slab = (int64_t)Cd_pad * Kp;
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += src[(int64_t)(s + u) * slab];
+        }
+        for (int u = 0; s < S; ++s, ++u) part[u] += src[(int64_t)s * slab];
+        const float sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         float* d = dw + (((int64_t)o * I + i) * KH + kh) * KW + kw;
         *d = accumulate ? *d + sum : sum;
     }
@@ -519,13 +529,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int o = (int)(oi / I);
         const float* src = ws + (int64_t)o * Kp + kh * KW * I + i;
         float* d = dw + oi * (KH * KW) + kh * KW;
-        float sum[KW];
+        float sum[KW], sum2[KW];  // two interleaved chains (fixed association): twice the loads in flight
 #pragma unroll
-        for (int tp = 0; tp < KW; ++tp) sum[tp] = 0.f;
-        for (int s = 0; s < S; ++s) {
+        for (int tp = 0; tp < KW; ++tp) sum[tp] = sum2[tp] = 0.f;
+        int s = 0;
+        for (; s + 2 <= S; s += 2) {
+#pragma unroll
+            for (int tp = 0; tp < KW; ++tp) {
+                sum[tp] += src[(int64_t)s * slab + tp * I];
+                sum2[tp] += src[(int64_t)(s + 1) * slab + tp * I];
+            }
+        }
+        if (s < S) {
 #pragma unroll
             for (int tp = 0; tp < KW; ++tp) sum[tp] += src[(int64_t)s * slab + tp * I];
         }
+#pragma unroll
+        for (int tp = 0; tp < KW; ++tp) sum[tp] += sum2[tp];
 #pragma unroll
         for (int tp = 0; tp < KW; ++tp) d[tp] = accumulate ? d[tp] + sum[tp] : sum[tp];
     }
