@@ -167,3 +167,32 @@ def test_yolo_checkpoint_remap_matches_reference_golden(which):
     assert {k: int(v.flatten()[0]) for k, v in final.items()} == g["final"]
     missing, unexpected = m.load_state_dict(final, strict=False)
     assert not unexpected
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Argument validation happens before any HIP call: error code < 0 and a message from cdet_last_error() (same wording as the
+    reference's assertions where it has them, utils/general.py:404-405)."""
+    import ctypes as C
+
+    from cerberusdet_amd import _lib as L
+
+    lib = L.load()
+    d = L.NmsDesc()
+    d.N, d.nc, d.A, d.dtype, d.conf_thres, d.iou_thres, d.max_det, d.max_nms, d.max_cand = 1, 4, 64, L.F32, 0.25, 2.0, 300, 30000, 64
+    one = C.c_void_p(16)  # never dereferenced: validation fails first
+    rc = lib.cdet_nms_batched(C.byref(d), one, one, one, one, None)
+    assert rc < 0 and "Invalid IoU" in lib.cdet_last_error().decode()
+    d.iou_thres, d.conf_thres = 0.45, -0.5
+    rc = lib.cdet_nms_batched(C.byref(d), one, one, one, one, None)
+    assert rc < 0 and "Invalid Confidence threshold" in lib.cdet_last_error().decode()
+    cd = L.ConvDesc()
+    rc = lib.cdet_conv2d(C.byref(cd), None, None, None, None, None, None, None, None)
+    assert rc < 0 and "null pointer" in lib.cdet_last_error().decode()
+    cd.N, cd.Hs, cd.Ws, cd.Cs, cd.Hd, cd.Wd, cd.Cd, cd.kh, cd.kw, cd.stride, cd.pad = 1, 8, 8, 12, 8, 8, 16, 3, 3, 1, 1
+    cd.dtype, cd.out_dtype, cd.src_ld, cd.dst_ld = L.BF16, L.BF16, 12, 16
+    rc = lib.cdet_conv2d(C.byref(cd), one, one, None, None, None, one, None, None)
+    assert rc < 0 and "multiples of 8" in lib.cdet_last_error().decode()  # Cs = 12
+    md = L.MergeDesc()
+    md.N, md.T, md.max_det, md.iou_thres = 1, 9, 300, 0.8
+    rc = lib.cdet_merge_tasks(C.byref(md), None, one, one, None)
+    assert rc < 0 and "T <= 8" in lib.cdet_last_error().decode()
