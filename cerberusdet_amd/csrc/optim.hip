@@ -46,6 +46,31 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __r
         const float total = sqrtf(sqnorm[0]);
         coef = fminf(max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
     }
+    // 16-byte path when the slot's four arrays allow it (conv weights: 80 % of the bytes); scalar otherwise (odd-sized bias vectors
+    // shift the alignment of the bucket slices behind them)
+    const uintptr_t al = (uintptr_t)sl.p | (uintptr_t)sl.g | (uintptr_t)sl.mom | (uintptr_t)sl.ema;
+    if ((al & 15) == 0 && (sl.n & 3) == 0 && sl.n >= 1024) {
+        const int64_t n4 = sl.n >> 2;
+        f32x4* P = reinterpret_cast<f32x4*>(sl.p);
+        f32x4* G = reinterpret_cast<f32x4*>(sl.g);
+        f32x4* Mo = reinterpret_cast<f32x4*>(sl.mom);
+        f32x4* E = reinterpret_cast<f32x4*>(sl.ema);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            f32x4 p = P[i];
+            if (G) {
+                f32x4 g = G[i] * coef * sl.inv_div;
+                if (sl.weight_decay != 0.f) g += sl.weight_decay * p;
+                const f32x4 buf = sl.first_step ? g : momentum * Mo[i] + g;
+                Mo[i] = buf;
+                g += momentum * buf;
+                p -= sl.lr * g;
+                P[i] = p;
+                G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (E) E[i] = E[i] * ema_decay + (1.f - ema_decay) * p;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sl.n; i += (int64_t)gridDim.x * 256) {
         float p = sl.p[i];
         if (sl.g) {
