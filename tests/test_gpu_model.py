@@ -62,6 +62,31 @@ def test_eval_forward_vs_reference_golden(name):
         assert _rel_l2(outf[t][0].cpu().numpy(), arrays[f"fused/{t}/y"]) < 1e-2
 
 
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_eval_boxes_within_1e3_of_reference_at_fp32_accuracy(name):
+    """BASELINE.json's tolerance -- boxes within 1e-3 relative of the reference -- at the reference's own precision: the eval forward
+    evaluated through the HIP convolution kernels with split-bf16 operands and fp32 accumulation (tests/hiprec.py; the bf16-storage
+    product path is covered by the statistical test above). Tolerances: head maps and boxes 1e-3 of the tensor's scale (max |value|,
+    since logits cross zero), class probabilities 1e-3 absolute."""
+    import hiprec
+
+    arrays, meta = load_golden(name)
+    m = _build(meta).eval()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    out = hiprec.eval_forward(m, x)
+    torch.cuda.synchronize()
+    for t in meta["tasks"]:
+        y, maps = out[t]
+        for i, f in enumerate(maps):
+            ref = arrays[f"eval/{t}/feat{i}"]
+            err = np.abs(f.cpu().numpy() - ref).max()
+            assert err <= 1e-3 * np.abs(ref).max(), (t, i, err, np.abs(ref).max())
+        yr = arrays[f"eval/{t}/y"]
+        yg = y.cpu().numpy()
+        assert np.abs(yg[:, :4] - yr[:, :4]).max() <= 1e-3 * np.abs(yr[:, :4]).max()
+        assert np.abs(yg[:, 4:] - yr[:, 4:]).max() <= 1e-3
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).float()
 
