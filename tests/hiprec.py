@@ -1,9 +1,9 @@
 """fp32-accurate execution of a CerberusDet eval forward THROUGH THE HIP CONVOLUTION KERNELS (test infrastructure).
 
 The product path stores activations and GEMM operands in bf16, which is a statistical match to the fp32 reference. To check the
-kernels and the weight / BatchNorm handling at the reference's own precision, every convolution here is evaluated as three bf16
-MFMA convolutions accumulated in fp32 (operand splitting: x = x_hi + x_lo, w = w_hi + w_lo with 8-bit mantissas each;
-x_hi*w_hi + x_hi*w_lo + x_lo*w_hi leaves a relative error of about 2^-16), followed by the folded BatchNorm + SiLU in fp32.
+kernels and the weight / BatchNorm handling at the reference's own precision, every convolution here is evaluated as six bf16
+MFMA convolutions accumulated in fp32 (operand splitting: x = x_hi + x_mid + x_lo, likewise w, 8 mantissa bits per term; the six
+term pairs above 2^-24 are kept), followed by the folded (or batch-statistics) BatchNorm + SiLU in fp32.
 Plumbing (concat, upsample, max-pool) uses torch ops -- they are exact. The Detect decode runs on the product kernel.
 """
 import torch
@@ -15,9 +15,16 @@ from cerberusdet_amd.models.common import C2f, Concat, Conv, SPPF, Upsample
 
 
 def _split(t32):
+    """fp32 -> three bf16 terms (8 + 8 + 8 mantissa bits): t = hi + mid + lo up to 2^-24."""
     hi = t32.to(torch.bfloat16)
-    lo = (t32 - hi.float()).to(torch.bfloat16)
-    return hi, lo
+    r = t32 - hi.float()
+    mid = r.to(torch.bfloat16)
+    lo = (r - mid.float()).to(torch.bfloat16)
+    return hi.contiguous(), mid.contiguous(), lo.contiguous()
+
+
+# operand-term pairs whose product is above 2^-24 relative: (0,0) (0,1) (1,0) (1,1) (0,2) (2,0)
+_PAIRS = [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)]
 
 
 def conv3(x, w, k, s):
@@ -29,24 +36,91 @@ def conv3(x, w, k, s):
     xn[..., :Ci] = x.permute(0, 2, 3, 1)
     wp = torch.zeros((Op, Cp, k, k), dtype=torch.float32, device=x.device)
     wp[:O, :Ci] = w
-    xh, xl = _split(xn)
-    wh, wl = _split(wp)
+    xs = _split(xn)
+    wpk = [ops.pack_weight(t.float(), torch.bfloat16) for t in _split(wp)]
     Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
     y = ops.new_act(N, Ho, Wo, Op, torch.float32)
-    ph, pl = ops.pack_weight(wh.float(), torch.bfloat16), ops.pack_weight(wl.float(), torch.bfloat16)
-    ops.conv2d(ops.View(xh.contiguous()), ph, y, k, s)
-    ops.conv2d(ops.View(xh.contiguous()), pl, y, k, s, accumulate=True)
-    ops.conv2d(ops.View(xl.contiguous()), ph, y, k, s, accumulate=True)
+    for n_, (i, j) in enumerate(_PAIRS):
+        ops.conv2d(ops.View(xs[i]), wpk[j], y, k, s, accumulate=n_ > 0)
     return y.buf[..., :O].permute(0, 3, 1, 2).contiguous()
 
 
-def conv_unit(m: Conv, x):
+def dgrad3(dy, w, k, s, x_shape):
+    """dX of conv3: three bf16 data-gradient launches (stride 2: the parity-class kernel) accumulated in fp32."""
+    N, Ci, H, W = x_shape
+    O = w.shape[0]
+    Cp, Op = (Ci + 7) // 8 * 8, (O + 7) // 8 * 8
+    dn = torch.zeros((N, dy.shape[2], dy.shape[3], Op), dtype=torch.float32, device=dy.device)
+    dn[..., :O] = dy.permute(0, 2, 3, 1)
+    wp = torch.zeros((O, Cp, k, k), dtype=torch.float32, device=dy.device)
+    wp[:, :Ci] = w
+    ds = _split(dn)
+    wtk = [ops.pack_weight(t.float(), torch.bfloat16, transpose=True, o_pad=Op) for t in _split(wp)]
+    dx = ops.new_act(N, H, W, Cp, torch.float32)
+    for n_, (i, j) in enumerate(_PAIRS):
+        ops.conv2d(ops.View(ds[i]), wtk[j], dx, k, s, mode=L.CONV_DGRAD, accumulate=n_ > 0)
+    return dx.buf[..., :Ci].permute(0, 3, 1, 2).contiguous()
+
+
+def wgrad3(x, dy, k, s, w_shape):
+    """dW of conv3: three bf16 weight-gradient launches accumulated in fp32."""
+    O, Ci = w_shape[0], w_shape[1]
+    N, _, H, W = x.shape
+    Cp, Op = (Ci + 7) // 8 * 8, (O + 7) // 8 * 8
+    xn = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=x.device)
+    xn[..., :Ci] = x.permute(0, 2, 3, 1)
+    dn = torch.zeros((N, dy.shape[2], dy.shape[3], Op), dtype=torch.float32, device=x.device)
+    dn[..., :O] = dy.permute(0, 2, 3, 1)
+    xs, ds = _split(xn), _split(dn)
+    dw = torch.zeros((Op, Cp, k, k), dtype=torch.float32, device=x.device)
+    for n_, (i, j) in enumerate(_PAIRS):
+        ops.conv2d_wgrad(ops.View(xs[i]), ops.View(ds[j]), dw, k, s, accumulate=n_ > 0)
+    return dw[:O, :Ci].contiguous()
+
+
+class Conv3Fn(torch.autograd.Function):
+    """conv3 with its gradients on the HIP data-gradient / weight-gradient kernels (everything around it is torch autograd in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, k, s):
+        ctx.save_for_backward(x, w)
+        ctx.ks = (k, s)
+        return conv3(x, w, k, s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, s = ctx.ks
+        dy = dy.contiguous()
+        dx = dgrad3(dy, w, k, s, x.shape) if ctx.needs_input_grad[0] else None
+        dw = wgrad3(x, dy, k, s, w.shape) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+_PARAMS = None  # {id(model parameter): fp32 leaf used by the autograd run}; None -> detached parameters (eval forward)
+
+
+def _p(t):
+    return t.detach().float() if _PARAMS is None else _PARAMS[id(t)]
+
+
+def _conv(x, w, k, s):
+    return conv3(x, w, k, s) if _PARAMS is None else Conv3Fn.apply(x, w, k, s)
+
+
+def conv_unit(m: Conv, x, training=False):
     if getattr(m, "fused", False):
-        return F.silu(conv3(x, m.conv.weight.detach().float(), m.k, m.s) + m.conv.bias.detach().float().view(1, -1, 1, 1))
+        return F.silu(_conv(x, _p(m.conv.weight), m.k, m.s) + _p(m.conv.bias).view(1, -1, 1, 1))
     bn = m.bn
-    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
-    bias = (bn.bias - bn.running_mean * scale).detach().float()
-    return F.silu(conv3(x, m.conv.weight.detach().float(), m.k, m.s) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    z = _conv(x, _p(m.conv.weight), m.k, m.s)
+    if _TRAIN:
+        return F.silu(F.batch_norm(z, None, None, _p(bn.weight), _p(bn.bias), True, 0.0, bn.eps))
+    scale = _p(bn.weight) / torch.sqrt(bn.running_var.float() + bn.eps)
+    bias = _p(bn.bias) - bn.running_mean.float() * scale
+    return F.silu(z * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+
+
+_TRAIN = False
 
 
 def layer(m, xs):
@@ -70,9 +144,28 @@ def layer(m, xs):
     raise NotImplementedError(type(m))
 
 
+def train_forward(model, img, task):
+    """Train-mode forward of one task (BatchNorm from batch statistics) as a torch autograd graph whose convolutions run on the HIP
+    kernels. Returns (maps, params) with params = {state-dict key: fp32 leaf}; call backward on the maps, read params[k].grad."""
+    global _PARAMS, _TRAIN
+    named = dict(model.named_parameters())
+    leaves = {k: p.detach().clone().float().requires_grad_(True) for k, p in named.items()}
+    _PARAMS, _TRAIN = {id(named[k]): leaves[k] for k in named}, True
+    try:
+        with torch.enable_grad():
+            res = _forward(model, img, [task], decode=False)
+    finally:
+        _PARAMS, _TRAIN = None, False
+    return res[task][1], leaves
+
+
 @torch.no_grad()
 def eval_forward(model, img, tasks=None):
     """-> {task: (y [N,4+nc,A] fp32, [3 maps [N,64+nc,h,w]])} like model.eval()(img)."""
+    return _forward(model, img, tasks, decode=True)
+
+
+def _forward(model, img, tasks, decode):
     tasks = list(model.heads) if tasks is None else tasks
     x = img.float() / 255.0 if img.dtype == torch.uint8 else img.float()
     order, _ = model.execution_plan(tasks)
@@ -97,13 +190,14 @@ def eval_forward(model, img, tasks=None):
                 parts = []
                 for br in (blk.cv2[lvl], blk.cv3[lvl]):
                     t = conv_unit(br[1], conv_unit(br[0], xl))
-                    parts.append(conv3(t, br[2].weight.detach().float(), 1, 1) + br[2].bias.detach().float().view(1, -1, 1, 1))
+                    parts.append(_conv(t, _p(br[2].weight), 1, 1) + _p(br[2].bias).view(1, -1, 1, 1))
                 mp = torch.cat(parts, 1)
                 maps.append(mp)
-                fb = torch.zeros((mp.shape[0], mp.shape[2], mp.shape[3], 64 + ncp), dtype=torch.float32, device=mp.device)
-                fb[..., :64 + blk.nc] = mp.permute(0, 2, 3, 1)
-                feats.append(fb)
-            y = ops.detect_decode(feats, blk.nc, [float(s) for s in blk.stride])
+                if decode:
+                    fb = torch.zeros((mp.shape[0], mp.shape[2], mp.shape[3], 64 + ncp), dtype=torch.float32, device=mp.device)
+                    fb[..., :64 + blk.nc] = mp.permute(0, 2, 3, 1)
+                    feats.append(fb)
+            y = ops.detect_decode(feats, blk.nc, [float(s) for s in blk.stride]) if decode else None
             res[task] = (y, maps)
         else:
             outs[idx] = layer(blk, xs)

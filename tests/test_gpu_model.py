@@ -87,6 +87,43 @@ def test_eval_boxes_within_1e3_of_reference_at_fp32_accuracy(name):
         assert np.abs(yg[:, 4:] - yr[:, 4:]).max() <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_train_gradients_within_1e3_of_oracle_at_fp32_accuracy(name):
+    """The data-gradient (incl. the stride-2 parity classes) and weight-gradient kernels at the reference's precision: the train-mode
+    forward / backward of every task evaluated with split-bf16 operands through the HIP kernels (tests/hiprec.py: autograd graph
+    whose convolutions are the three-launch fp32-accumulating HIP calls), against the fp32 CPU oracle (itself pinned to the
+    reference's golden gradients by tests/test_oracle_golden.py). EVERY parameter gradient within 1e-3 of its tensor's scale."""
+    import hiprec
+
+    _, meta = load_golden(name)
+    m = _build(meta).train()
+    g, w = oracle_model_from_meta(meta)
+    bs, imgsz = 4, 128
+    x_cpu = torch.from_numpy(synth.det_image(77, bs, imgsz))
+    for t in meta["tasks"]:
+        maps, leaves = hiprec.train_forward(m, x_cpu.to(DEV), t)
+        cot = [torch.from_numpy(synth.det_array(77, f"cot/{t}/{i}", f.shape)) for i, f in enumerate(maps)]
+        sum((f * c.to(DEV)).sum() for f, c in zip(maps, cot)).backward()
+        torch.cuda.synchronize()
+        wt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in w.items()}
+        of = og.forward(g, wt, x_cpu, t, training=True, bn_updates={})
+        sum((f * c).sum() for f, c in zip(of, cot)).backward()
+        for i, f in enumerate(maps):
+            ref = of[i].detach().numpy()
+            assert np.abs(f.detach().cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), (t, i)
+        n = 0
+        worst = (0.0, "")
+        for k, v in wt.items():
+            if not (isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None):
+                continue
+            got, ref = leaves[k].grad.cpu().numpy(), v.grad.numpy()
+            rel = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+            worst = max(worst, (rel, k))
+            n += 1
+        print(f"[{name}/{t}] {n} gradient tensors, worst max-error / scale {worst[0]:.2e} ({worst[1]})")
+        assert n == len(meta["grad_keys_with_grad"][t]) and worst[0] <= 1e-3, worst
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).float()
 
