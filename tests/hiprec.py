@@ -144,7 +144,7 @@ def layer(m, xs):
     raise NotImplementedError(type(m))
 
 
-def train_forward(model, img, task):
+def train_forward(model, img, task, img_grad=False):
     """Train-mode forward of one task (BatchNorm from batch statistics) as a torch autograd graph whose convolutions run on the HIP
     kernels. Returns (maps, params) with params = {state-dict key: fp32 leaf}; call backward on the maps, read params[k].grad."""
     global _PARAMS, _TRAIN
@@ -153,6 +153,9 @@ def train_forward(model, img, task):
     _PARAMS, _TRAIN = {id(named[k]): leaves[k] for k in named}, True
     try:
         with torch.enable_grad():
+            if img_grad:
+                img = img.detach().float().requires_grad_(True)
+                leaves["__img__"] = img
             res = _forward(model, img, [task], decode=False)
     finally:
         _PARAMS, _TRAIN = None, False

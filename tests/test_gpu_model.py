@@ -124,6 +124,36 @@ def test_train_gradients_within_1e3_of_oracle_at_fp32_accuracy(name):
         assert n == len(meta["grad_keys_with_grad"][t]) and worst[0] <= 1e-3, worst
 
 
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_train_golden_of_the_real_reference_at_fp32_accuracy(name):
+    """The reference's own train-mode golden (tools/make_golden.py: maps, input gradient and a sample of weight gradients of
+    sum(maps * cot), bs 2 @64) reproduced through the HIP forward / data-gradient / weight-gradient kernels at fp32 accuracy
+    (tests/hiprec.py) within 1e-3 of each tensor's scale -- the regime where 16-bit storage is pure noise (test above)."""
+    import hiprec
+
+    arrays, meta = load_golden(name)
+    m = _build(meta).train()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    for t in meta["tasks"]:
+        maps, leaves = hiprec.train_forward(m, x, t, img_grad=True)
+        cot = [torch.from_numpy(synth.det_array(meta["seed"], f"cot/{t}/{i}", f.shape)).to(DEV) for i, f in enumerate(maps)]
+        sum((f * c).sum() for f, c in zip(maps, cot)).backward()
+        torch.cuda.synchronize()
+        worst = (0.0, "")
+        for i, f in enumerate(maps):
+            ref = arrays[f"train/{t}/feat{i}"]
+            worst = max(worst, (float(np.abs(f.detach().cpu().numpy() - ref).max() / np.abs(ref).max()), f"feat{i}"))
+        ref = arrays[f"train/{t}/dx"]
+        worst = max(worst, (float(np.abs(leaves["__img__"].grad.cpu().numpy() - ref).max() / np.abs(ref).max()), "dx"))
+        keys = [k[len(f"train/{t}/grad/"):] for k in arrays if k.startswith(f"train/{t}/grad/")]
+        assert len(keys) >= 8
+        for k in keys:
+            ref = arrays[f"train/{t}/grad/{k}"]
+            worst = max(worst, (float(np.abs(leaves[k].grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)), k))
+        print(f"[{name}/{t}] maps + dx + {len(keys)} gradients vs the reference golden: worst max-error / scale {worst[0]:.2e} ({worst[1]})")
+        assert worst[0] <= 1e-3, worst
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).float()
 
