@@ -154,6 +154,43 @@ def test_train_golden_of_the_real_reference_at_fp32_accuracy(name):
         assert worst[0] <= 1e-3, worst
 
 
+def test_wide_model_gradients_at_fp32_accuracy_cover_the_pipelined_kernels():
+    """Same check on a half-width YOLOv8 (channels 32 ... 256: the software-pipelined forward / data-gradient / weight-gradient kernels
+    and the wide tiles carry the model, unlike the 8 ... 64-channel golden models): every gradient of one task pass through the HIP
+    kernels at fp32 accuracy against the fp32 CPU oracle."""
+    import hiprec
+
+    _, meta0 = load_golden("model_tiny2")
+    cfg = copy.deepcopy(meta0["cfg"])
+    cfg["width_multiple"], cfg["depth_multiple"] = 0.5, 0.33
+    meta = dict(cfg=cfg, tasks=meta0["tasks"], nc=meta0["nc"], seed=9)
+    from cerberusdet_amd.models import CerberusDet
+
+    m = CerberusDet(meta["tasks"], meta["nc"], cfg=copy.deepcopy(cfg), verbose=False)
+    m.sequential_split(cfg["cerber"], "cpu")
+    m.load_state_dict({k: torch.from_numpy(synth.det_tensor(9, k, v.shape)) for k, v in m.state_dict().items()})
+    m = m.to(DEV).train()
+    assert max(p.shape[0] for k, p in m.named_parameters() if k.endswith("conv.weight")) >= 256
+    g, w = oracle_model_from_meta(meta)
+    x_cpu = torch.from_numpy(synth.det_image(78, 2, 128))
+    t = meta["tasks"][1]
+    maps, leaves = hiprec.train_forward(m, x_cpu.to(DEV), t)
+    cot = [torch.from_numpy(synth.det_array(78, f"cot/{t}/{i}", f.shape)) for i, f in enumerate(maps)]
+    sum((f * c.to(DEV)).sum() for f, c in zip(maps, cot)).backward()
+    torch.cuda.synchronize()
+    wt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in w.items()}
+    of = og.forward(g, wt, x_cpu, t, training=True, bn_updates={})
+    sum((f * c).sum() for f, c in zip(of, cot)).backward()
+    worst, n = (0.0, ""), 0
+    for k, v in wt.items():
+        if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None:
+            ref = v.grad.numpy()
+            worst = max(worst, (float(np.abs(leaves[k].grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-30)), k))
+            n += 1
+    print(f"[half-width/{t}] {n} gradient tensors, worst max-error / scale {worst[0]:.2e} ({worst[1]})")
+    assert n > 150 and worst[0] <= 1e-3, worst
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).float()
 
