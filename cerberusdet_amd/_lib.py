@@ -41,6 +41,11 @@ class PackItem(C.Structure):
                 ("first_block", i32), ("n_blocks", i32)]
 
 
+class PackTiledItem(C.Structure):
+    _fields_ = [("w_oihw", vp), ("w_fwd", vp), ("w_dgrad", vp), ("O", i32), ("I", i32), ("kh", i32), ("kw", i32),
+                ("first_block", i32), ("n_blocks", i32)]
+
+
 class MergeDesc(C.Structure):
     _fields_ = [("N", i32), ("T", i32), ("max_det", i32), ("iou_thres", f32), ("rows", vp * 8), ("counts", vp * 8), ("cls_offset", i32 * 8)]
 
@@ -63,6 +68,12 @@ _SIGS = {
     "cdet_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "cdet_packed_weight_elems": (i64, [i32, i32, i32, i32, i32]),
     "cdet_pack_weights_batched": (i32, [vp, i32, i32, i32, vp]),
+    "cdet_conv2d_tiled_ok": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_tiled_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_tiled": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_tiled_weight_elems": (i64, [i32, i32, i32, i32]),
+    "cdet_pack_weights_tiled": (i32, [vp, i32, i32, i32, vp]),
+    "cdet_pack_weight_tiled": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cdet_conv2d_wgrad_ws_elems": (i64, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
     "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),

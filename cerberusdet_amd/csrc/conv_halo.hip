@@ -1,0 +1,657 @@
+// Tap-resident implicit-GEMM convolution for gfx950 (bf16 / f16 in, fp32 accumulate): stride-1 3x3 and 1x1, FWD and (through a
+// tap-flipped, transposed weight pack) the stride-1 data gradient.
+//
+// What round 1 measured on the register/LDS-staged kernels of conv_igemm.hip (profiles/r01_conv_ablation.txt): the
+// MFMAs alone and the L2 -> LDS operand stream alone each take ~2/3 of the full kernel's time -- a 160 x 128 tile re-fetches every
+// activation pixel once per tap (9x for a 3x3) and moves 36.9 KB per 2.6 MFLOP. This kernel removes the tap redundancy instead of
+// hiding it:
+//   * the K loop runs CHUNK-outer / TAP-inner: for one 32-channel chunk the block's pixels AND THEIR HALO are staged in LDS once
+//     and serve all nine taps. The pixel tile is 256 consecutive pixels of the flattened (n, y, x) index, so its halo is simply the
+//     linear range [p0 - W - 1, p0 + 256 + W + 1): tap (dy, dx) of tile pixel i is halo row i + (W + 1) + dy * W + dx. Taps that leave
+//     the image are redirected per lane to a zero row (9-bit validity mask per pixel), which also covers tiles that straddle
+//     images. X traffic per tap step: 338 rows / 9 instead of 256 rows (W = 40) -> L2 -> LDS bytes per FLOP fall 3.3x;
+//   * the weight operand is pre-packed by cdet_pack_weights_tiled as one contiguous, pre-swizzled 10 KiB tile per (cout block, chunk,
+//     tap): its LDS image is a plain linear copy (buffer_load ... lds, no per-lane address arithmetic, perfectly coalesced);
+//   * MFMA 32x32x16 (the shape that reaches the 2.5 PF/s peak; 16x16x32 tops out ~15 % lower): a wave owns 64 pixels x 160 couts
+//     = 2 x 5 tiles (160 fp32 accumulators), a block = 4 waves = 256 pixels x 160 couts, two blocks per CU (76 KiB LDS each) so
+//     one block's barrier / fragment-read bubbles run under the other's MFMAs;
+//   * 3-stage weight ring with counted vmcnt (never 0 in the loop when LDS allows 3 stages), one s_barrier per 32-deep K step
+//     (20 MFMAs of 32 cycles per wave between barriers).
+// LDS rows are 64 B (32 channels); 16-B slot s of row r sits at physical slot s ^ ((r >> 2) & 3), which makes every
+// ds_read_b128 lane group (MI355X_MICROARCH.md LDS table) hit 16 distinct slots of the 256-B bank row.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace cdet {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct HaloArgs {
+    const uint16_t* x;
+    const uint16_t* w;
+    const float* scale;
+    const float* bias;
+    const uint16_t* res;
+    void* y;
+    float* stats;
+    int H, W, Cd;
+    int M;  // N*H*W
+    int src_ld, src_coff, dst_ld, dst_coff, res_ld, res_coff;
+    int nchunk;  // Cs / 32
+    int n_pblk, n_cblk;
+    int act;
+    int XH;  // halo rows per chunk buffer (multiple of 16)
+    unsigned x_bytes, w_bytes;
+};
+
+constexpr int HP = 256;             // pixels per block
+constexpr int HC = 160;             // couts per block
+constexpr int HROW = 64;            // bytes per LDS row (32 channels)
+constexpr int WTILE = HC * HROW;    // 10240 bytes per (cblk, chunk, tap) weight tile
+constexpr int HZERO = 256;          // LDS bytes reserved in front (zero row)
+constexpr int MAXXP = 7;            // X DMA pieces (16 rows each) per wave per chunk: XH <= 448
+constexpr unsigned HSENT = 0xE0000000u;  // byte offset beyond every buffer: the DMA returns zeros
+
+template <int DT>
+__device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c) {
+    if (DT == CDET_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// wave-uniform counted wait
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+}
+
+typedef __attribute__((ext_vector_type(2))) float hf32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 hf16x2;
+template <int DT>
+__device__ __forceinline__ uint32_t hpack2(float a, float b) {
+    if (DT == CDET_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(hf32x2{a, b}, hbf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hf32x2{a, b}, hf16x2));
+}
+
+// sum over the 32 lanes of a half wave (every lane ends up with the total)
+__device__ __forceinline__ float half_sum32(float v) {
+#define CDET_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    CDET_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    CDET_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    CDET_DPP_ADD(0x141);  // row_half_mirror
+    CDET_DPP_ADD(0x140);  // row_mirror
+#undef CDET_DPP_ADD
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+    return v;
+}
+
+constexpr int HEPI_RAW = 0, HEPI_FULL = 1;
+
+// NT: taps (1 or 9); NSW: weight ring stages (2 or 3); ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop,
+// 2 = no fragment reads, 4 = no MFMA
+template <int DT, int NT, int EPI, int NSW, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // XCD-aware remap (bijective): consecutive logical ids -- the cout blocks of one pixel tile, then the next pixel tile -- run on ONE XCD
+    int L;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int cblk = L % a.n_cblk;
+    const int pblk = L / a.n_cblk;
+    const int p0 = pblk * HP;
+    const int c0 = cblk * HC;
+    const int W = a.W;
+    const int halo0 = NT == 9 ? W + 1 : 0;
+    const int XHB = a.XH * HROW;
+    const int nsteps = a.nchunk * NT;
+    unsigned char* const xbase = smem + HZERO;
+    constexpr int NXB = NT == 1 ? 3 : 2;  // pixel buffers
+    unsigned char* const wbase = smem + HZERO + NXB * XHB;
+
+    if (t < 16) reinterpret_cast<uint32_t*>(smem)[t] = 0u;  // zero row (visible after the first barrier)
+
+    // ---- X DMA pieces of this wave: piece id 4*i + wave covers halo rows 16*id .. 16*id+15, 4 lanes (64 B) per row --------------
+    const int nxp_total = a.XH >> 4;
+    const int nxpw = (nxp_total - wave + 3) >> 2;  // wave-uniform
+    unsigned xvoff[MAXXP];
+#pragma unroll
+    for (int i = 0; i < MAXXP; ++i) {
+        const int hrow = 16 * (4 * i + wave) + (lane >> 2);
+        const int g = p0 - halo0 + hrow;
+        const unsigned off = ((unsigned)g * (unsigned)a.src_ld + (unsigned)a.src_coff) * 2u + ((unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4);
+        xvoff[i] = (g >= 0 && g < a.M) ? off : HSENT;
+    }
+    // ---- W DMA pieces: piece id wave + 4*j (< 10), a plain linear copy of the packed tile ----------------------------------------
+    const int nwp = wave < 2 ? 3 : 2;  // wave-uniform
+    const unsigned wvoff = (unsigned)(wave * 1024 + lane * 16);
+    const unsigned wtile0 = (unsigned)cblk * (unsigned)nsteps * (unsigned)WTILE;
+
+    // Steps / chunks beyond the end are requested through an EMPTY descriptor (every load returns zeros), so the number of DMA
+    // instructions per step -- what the counted vmcnt waits rely on -- never changes.
+    auto dma_w1 = [&](int step, int stage, int j) {  // piece j of this wave of the weight tile of K step `step` -> ring stage `stage`
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, step < nsteps ? (int)a.w_bytes : 0, 0x00020000);
+        unsigned char* dst = wbase + stage * WTILE + wave * 1024 + j * 4096;
+        const unsigned soff = wtile0 + (unsigned)step * (unsigned)WTILE;
+        if (j < nwp) dma16(rs, wvoff + (unsigned)j * 4096u, soff, dst);
+    };
+    auto dma_x = [&](int i, int chunk, int xb) {  // piece i of this wave, channels of `chunk` -> pixel buffer xb
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, chunk < a.nchunk ? (int)a.x_bytes : 0, 0x00020000);
+        unsigned char* dst = xbase + xb * XHB + (4 * i + wave) * 1024;
+        dma16(rs, xvoff[i] + (unsigned)chunk * 64u, 0u, dst);
+    };
+
+    // ---- fragment read offsets -------------------------------------------------------------------------------------------------
+    // A (weights): row f*32 + l31 of the stage, k-slot 2*s + h
+    const int aoff0 = l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
+    // B (pixels): tile pixel wave*64 + g*32 + l31; validity bit per tap
+    int pix[2];
+    unsigned vmask[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        pix[g] = wave * 64 + g * 32 + l31;
+        const int p = p0 + pix[g];
+        unsigned m = 0u;
+        if (p < a.M) {
+            if (NT == 9) {
+                const int x = p % W;
+                const int y = (p / W) % a.H;
+                unsigned rb = 0u, cb = 0u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if ((unsigned)(y + k - 1) < (unsigned)a.H) rb |= 1u << k;
+                    if ((unsigned)(x + k - 1) < (unsigned)W) cb |= 1u << k;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if ((rb >> k) & 1u) m |= cb << (3 * k);
+            } else {
+                m = 1u;
+            }
+        }
+        vmask[g] = m;
+    }
+
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int f = 0; f < 5; ++f)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
+
+    // ---- prologue: chunk 0 of X (1x1: chunks 0 and 1), weight tiles of steps 0 .. NSW-1 -------------------------------------------
+#pragma unroll
+    for (int i = 0; i < MAXXP; ++i)
+        if (i < nxpw) dma_x(i, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dma_w1(0, 0, j);
+    if (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_x(i, 1, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dma_w1(1, 1, j);
+    if (NSW == 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dma_w1(2, 2, j);
+    }
+    wait_vm((NT == 1 ? 4 : 0) + (NSW - 1) * nwp);  // tile 0 and chunk 0 have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // B-fragment byte offsets (relative to smem) of a K step: halo row of each of the lane's two pixels for the step's tap
+    auto b_offsets = [&](int xoff, int tap_, int (&bo)[2]) {
+        const int dy_ = tap_ / 3 - 1, dx_ = tap_ % 3 - 1;
+        // opaque copies: without them the compiler hoists the nine per-tap offset pairs (and their scalar parts) out of the chunk
+        // loop as loop invariants -- 18 VGPRs + ~30 SGPRs the 256-register budget does not have (spills); recomputing costs 8 VALU
+        int Wv = W, p_[2] = {pix[0], pix[1]};
+        asm volatile("" : "+s"(Wv), "+v"(p_[0]), "+v"(p_[1]));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int hrow = p_[g] + halo0 + (NT == 9 ? dy_ * Wv + dx_ : 0);
+            const int off = hrow * HROW + ((h ^ ((hrow >> 2) & 3)) << 4);
+            const bool ok = (vmask[g] >> tap_) & 1u;
+            bo[g] = ok ? off + xoff : 0;  // invalid tap / pixel: the zero row
+        }
+    };
+    // fragment i of a k16 half: i < 2 -> pixel rows (B operand), else weight rows (A operand); read order = use order
+    auto frag = [&](const unsigned char* ws_, const int (&bo)[2], int s_, int i, u32x4 (&af)[5], u32x4 (&bf)[2]) {
+        if (ABL & 2) {
+            if (i < 2) bf[i] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+            else af[i - 2] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+        } else if (i < 2) {
+            bf[i] = *reinterpret_cast<const u32x4*>(smem + (bo[i] ^ (s_ << 5)));
+        } else {
+            af[i - 2] = *reinterpret_cast<const u32x4*>(ws_ + ((aoff0 ^ (s_ << 5)) + (i - 2) * 32 * HROW));
+        }
+    };
+
+    int bo_cur[2], bo_nxt[2];
+    u32x4 a0[5], b0[2], a1[5], b1[2];
+    b_offsets(HZERO, 0, bo_cur);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) frag(wbase, bo_cur, 0, i, a0, b0);
+
+    // One K step. `u` is the step's position inside the unrolled group (3x3: the tap, 9 per chunk; 1x1: 3 chunks per group), a
+    // compile-time constant after unrolling, so the tap offsets, the ring stage (NSW == 3) and the pixel-piece schedule fold away;
+    // `chunk` is the step's channel chunk, `st` its index.
+    auto step = [&](int st, int chunk, int u) {
+        const int tap = NT == 9 ? u : 0;
+        const int sc = NSW == 3 ? u % 3 : (st & 1);           // ring stage of this step's tile (compile-time for NSW == 3)
+        const int sn = NSW == 3 ? (u + 1) % 3 : ((st + 1) & 1);
+        const unsigned char* ws = wbase + sc * WTILE;
+        const unsigned char* wsn = wbase + sn * WTILE;
+        const int tapn = NT == 9 ? (u + 1) % 9 : 0;
+        const int chunkn = NT == 9 ? chunk + (u == 8 ? 1 : 0) : chunk + 1;
+        const int xbn = NT == 9 ? (chunkn & 1) : (u + 1) % 3;  // pixel buffer of step st+1
+        const bool xa = NT == 9 && u < MAXXP && u < nxpw;      // a pixel piece of the next chunk is issued in phase A (wave-uniform)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase A: MFMAs of (st, k16 #0); the fragment reads of (st, k16 #1), the address arithmetic of step st+1 and the pixel
+        //      pieces of the next chunk (3x3: one per step; 1x1: the whole chunk st+2 into the third buffer) in their shadow
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            if (!(ABL & 4)) mfma32<DT>(a0[i >> 1], b0[i & 1], acc[i >> 1][i & 1]);
+            if (i < 7) frag(ws, bo_cur, 1, i, a1, b1);
+            if (i == 7) b_offsets(HZERO + xbn * XHB, tapn, bo_nxt);
+            if (!(ABL & 1)) {
+                if (NT == 9) {
+                    if (i == 8 && u < MAXXP) {
+                        if (xa) dma_x(u, chunk + 1, (chunk + 1) & 1);
+                    }
+                } else if ((i & 1) == 1 && i < 8) {
+                    dma_x(i >> 1, chunk + 2, (u + 2) % 3);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // tile st+1 (and, at a chunk boundary, the next chunk's pixels) have landed -- the weight pieces issued in the previous phase B
+        // and this phase's pixel pieces may stay in flight; nobody reads tile st's stage any more
+        if (NT == 9) {
+            if (NSW == 3) {
+                if (nwp == 3) {
+                    if (xa) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (xa) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                }
+            } else {
+                if (xa) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            if (NSW == 3) {
+                if (nwp == 3) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: MFMAs of (st, k16 #1); DMA of the tile NSW steps ahead into the stage just freed and the fragment reads of
+        //      (st+1, k16 #0) in their shadow
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            if (!(ABL & 4)) mfma32<DT>(a1[i >> 1], b1[i & 1], acc[i >> 1][i & 1]);
+            if (!(ABL & 1)) {
+                if (i == 0) dma_w1(st + NSW, sc, 0);
+                if (i == 3) dma_w1(st + NSW, sc, 1);
+                if (i == 6) dma_w1(st + NSW, sc, 2);
+            }
+            if (i >= 1 && i < 8) frag(wsn, bo_nxt, 0, i - 1, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bo_cur[0] = bo_nxt[0];
+        bo_cur[1] = bo_nxt[1];
+    };
+
+    if (NT == 9) {
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u) step(chunk * 9 + u, chunk, u);
+        }
+    } else {
+        for (int c3 = 0; c3 < a.nchunk; c3 += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (c3 + u < a.nchunk) step(c3 + u, c3 + u, u);
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");  // asm MFMAs are opaque to the hazard recogniser; trailing (dead) DMA drained
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- BN statistics of the raw convolution (train mode): per (pixel block, channel) partial sums ---------------------------------
+    if (a.stats != nullptr) {
+        float* stl = reinterpret_cast<float*>(smem + HZERO);  // [4 waves][2][160]
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v0 = acc[f][0][r], v1 = acc[f][1][r];
+                const float sv = half_sum32(v0 + v1);
+                const float qv = half_sum32(v0 * v0 + v1 * v1);
+                if (l31 == 0) {
+                    const int cl = f * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    stl[(wave * 2 + 0) * HC + cl] = sv;
+                    stl[(wave * 2 + 1) * HC + cl] = qv;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < HC && c0 + t < a.Cd) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                sv += stl[(m * 2 + 0) * HC + t];
+                qv += stl[(m * 2 + 1) * HC + t];
+            }
+            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+        }
+    }
+
+    // ---- epilogue: a lane holds, per 32x32 tile, 4 runs (q) of 4 consecutive couts of ONE pixel; its partner lane (+32) holds the
+    //      neighbouring 4. v_permlane32_swap of run q (even) against run q+1 leaves 8 consecutive couts per lane -> scale / bias /
+    //      residual as 16-byte vectors and ONE 16-byte NHWC store per run pair (half the store instructions of the 8-byte form)
+    uint16_t* const yp = reinterpret_cast<uint16_t*>(a.y);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int p = p0 + wave * 64 + g * 32 + l31;
+        const bool pok = p < a.M;
+        const int64_t ob = (int64_t)p * a.dst_ld + a.dst_coff;
+        const int64_t rb = (int64_t)p * a.res_ld + a.res_coff;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (never __builtin_bit_cast a vector ELEMENT expression: clang reads element 0 of the vector instead)
+                    const float lo = acc[f][g][4 * q + r], hi = acc[f][g][4 * q + 4 + r];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    v[r] = __uint_as_float(s0);
+                    v[4 + r] = __uint_as_float(s1);
+                }
+                const int co = c0 + f * 32 + 8 * (q + h);
+                if (!pok || co >= a.Cd) continue;
+                if (EPI == HEPI_FULL) {
+                    if (a.scale) {
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale + co), s1 = *reinterpret_cast<const f32x4*>(a.scale + co + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] *= s0[r];
+                            v[4 + r] *= s1[r];
+                        }
+                    }
+                    if (a.bias) {
+                        const f32x4 b0v = *reinterpret_cast<const f32x4*>(a.bias + co), b1v = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] += b0v[r];
+                            v[4 + r] += b1v[r];
+                        }
+                    }
+                    if (a.act == CDET_ACT_SILU) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+                    }
+                    if (a.res) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(a.res + rb + co);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[2 * r] += Elem<DT>::to_f32((uint16_t)(rv[r] & 0xffff));
+                            v[2 * r + 1] += Elem<DT>::to_f32((uint16_t)(rv[r] >> 16));
+                        }
+                    }
+                }
+                u32x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = hpack2<DT>(v[2 * r], v[2 * r + 1]);
+                *reinterpret_cast<u32x4*>(yp + ob + co) = pk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Tiled weight pack: OIHW fp32 master -> [row block of 160][chunk of 32 reduction channels][tap][160 rows][32 k], 16-B slots swizzled.
+//   forward operand : rows = o, reduction = i, tap as stored
+//   DGRAD operand   : rows = i, reduction = o, taps flipped (kh, kw) -> (KH-1-kh, KW-1-kw): the stride-1 data gradient becomes a
+//                     plain forward convolution of dY with this operand
+// One workgroup transposes a [32 o][32 i][taps] tile through LDS (the master is read once, in runs of 32*taps floats).
+// ------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t tiled_elem(int row, int chunk, int tap, int k, int nchunk, int taps) {
+    const int cb = row / HC, r = row - cb * HC;
+    const int64_t tile = ((int64_t)cb * nchunk + chunk) * taps + tap;
+    return tile * (HC * 32) + r * 32 + ((((k >> 3) ^ ((r >> 2) & 3)) << 3) | (k & 7));
+}
+
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack_tiled_item* __restrict__ items, int n, cdet_pack_tiled_item single,
+                                                                  int dtype) {
+    __shared__ int s_it;
+    __shared__ float tile[32][32 * 9 + 1];
+    cdet_pack_tiled_item p;
+    if (items != nullptr) {
+        if (threadIdx.x == 0) {
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (items[mid].first_block <= (int)blockIdx.x) lo = mid;
+                else hi = mid - 1;
+            }
+            s_it = lo;
+        }
+        __syncthreads();
+        p = items[s_it];
+    } else {
+        p = single;
+    }
+    const int taps = p.kh * p.kw;
+    const int tiles_i = (p.I + 31) / 32;
+    const int lb = (int)blockIdx.x - p.first_block;
+    const int o0 = (lb / tiles_i) * 32, i0 = (lb % tiles_i) * 32;
+    const int ni = min(32, p.I - i0), no = min(32, p.O - o0);
+    const int run = ni * taps;
+    for (int e = threadIdx.x; e < 32 * 32 * taps; e += 256) {
+        const int o = e / (32 * taps), r = e - o * (32 * taps);
+        tile[o][r] = (o < no && r < run) ? p.w_oihw[((int64_t)(o0 + o) * p.I + i0) * taps + r] : 0.f;
+    }
+    __syncthreads();
+    uint16_t* wf = reinterpret_cast<uint16_t*>(p.w_fwd);
+    uint16_t* wd = reinterpret_cast<uint16_t*>(p.w_dgrad);
+    // one 16-byte piece (8 k values) per work item: (row 0..31, tap, k-slot 0..3)
+    for (int e = threadIdx.x; e < 32 * taps * 4; e += 256) {
+        const int kq = e & 3, tap = (e >> 2) % taps, row = (e >> 2) / taps;
+        if (wf != nullptr && row < no) {  // rows = o, k = i - i0
+            uint16_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = tile[row][(kq * 8 + j) * taps + tap];
+                v[j] = dtype == CDET_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
+            }
+            const int64_t at = tiled_elem(o0 + row, i0 >> 5, tap, kq * 8, p.I >> 5, taps);
+            u32x4 pk = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16), (uint32_t)v[4] | ((uint32_t)v[5] << 16),
+                        (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
+            *reinterpret_cast<u32x4*>(wf + at) = pk;
+        }
+        if (wd != nullptr && row < ni) {  // rows = i, k = o - o0, flipped tap
+            uint16_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = tile[kq * 8 + j][row * taps + tap];
+                v[j] = dtype == CDET_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
+            }
+            const int64_t at = tiled_elem(i0 + row, o0 >> 5, taps - 1 - tap, kq * 8, (p.O + 31) >> 5, taps);
+            u32x4 pk = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16), (uint32_t)v[4] | ((uint32_t)v[5] << 16),
+                        (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
+            *reinterpret_cast<u32x4*>(wd + at) = pk;
+        }
+    }
+}
+
+static inline int halo_xh(int W, int k) { return ((k == 3 ? HP + 2 * (W + 1) : HP) + 15) / 16 * 16; }
+
+// which ring depth fits two workgroups per CU (80 KiB each)
+static inline int halo_nxb(int k) { return k == 1 ? 3 : 2; }
+static inline int halo_nsw(int XH, int k) { return HZERO + halo_nxb(k) * XH * HROW + 3 * WTILE <= 80 * 1024 ? 3 : 2; }
+
+static bool halo_supported(const cdet_conv_desc* d) {
+    if (!(d->kh == d->kw && (d->kh == 1 || d->kh == 3))) return false;
+    if (d->stride != 1 || d->pad != d->kh / 2) return false;
+    if (d->Hs != d->Hd || d->Ws != d->Wd) return false;
+    if (d->Cs % 32 != 0 || d->src_ld % 8 != 0 || d->src_coff % 8 != 0) return false;
+    if (d->Cd % 8 != 0 || d->dst_ld % 8 != 0 || d->dst_coff % 8 != 0) return false;
+    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16) || d->out_dtype != d->dtype || d->accumulate) return false;
+    const int XH = halo_xh(d->Ws, d->kh);
+    if (XH > 16 * 4 * MAXXP) return false;
+    if (d->kh == 1 && XH != HP) return false;
+    const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
+    if (M >= (1ll << 31) - HP) return false;
+    if (M * d->src_ld * 2 >= 0xC0000000ll) return false;
+    const int64_t wb = (int64_t)div_up(d->Cd, HC) * (d->Cs / 32) * d->kh * d->kw * WTILE;
+    if (wb >= 0xC0000000ll) return false;
+    return true;
+}
+
+template <int DT, int NT, int EPI, int NSW>
+static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, EPI, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+#ifdef CDET_PROFILING
+    static int abl = -1;
+    if (abl < 0) {
+        const char* e = getenv("CDET_HALO_ABLATE");
+        abl = e ? atoi(e) : 0;
+        if (abl) fprintf(stderr, "[cdet] CDET_HALO_ABLATE=%d: conv results are WRONG by design (timing experiment)\n", abl);
+    }
+    if constexpr (DT == CDET_BF16 && NT == 9 && EPI == HEPI_FULL && NSW == 3) {
+#define CDET_HABL(N)                                                                                                                         \
+    case N:                                                                                                                                   \
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, EPI, NSW, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((conv_halo_kernel<DT, NT, EPI, NSW, N>), dim3(nblocks), dim3(256), lds, s, a);                                     \
+        return;
+        switch (abl) {
+            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(5) CDET_HABL(6) CDET_HABL(7)
+            default: break;
+        }
+#undef CDET_HABL
+    }
+#endif
+    hipLaunchKernelGGL((conv_halo_kernel<DT, NT, EPI, NSW>), dim3(nblocks), dim3(256), lds, s, a);
+}
+
+template <int DT>
+static void dispatch_halo(const HaloArgs& a, int k, bool full, int nsw, size_t lds, int nblocks, hipStream_t s) {
+#define CDET_HALO_GO(NT, EPI)                                              \
+    do {                                                                   \
+        if (nsw == 3) launch_halo<DT, NT, EPI, 3>(a, lds, nblocks, s);      \
+        else launch_halo<DT, NT, EPI, 2>(a, lds, nblocks, s);               \
+    } while (0)
+    if (k == 3) {
+        if (full) CDET_HALO_GO(9, HEPI_FULL);
+        else CDET_HALO_GO(9, HEPI_RAW);
+    } else {
+        if (full) CDET_HALO_GO(1, HEPI_FULL);
+        else CDET_HALO_GO(1, HEPI_RAW);
+    }
+#undef CDET_HALO_GO
+}
+
+}  // namespace cdet
+
+using namespace cdet;
+
+extern "C" int cdet_conv2d_tiled_ok(const cdet_conv_desc* d) { return d && halo_supported(d) ? 1 : 0; }
+
+extern "C" int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d) { return div_up((int64_t)d->N * d->Hd * d->Wd, HP); }
+
+extern "C" int64_t cdet_tiled_weight_elems(int32_t rows, int32_t red, int32_t kh, int32_t kw) {
+    return (int64_t)div_up(rows, HC) * div_up(red, 32) * kh * kw * (HC * 32);
+}
+
+extern "C" int cdet_pack_weights_tiled(const cdet_pack_tiled_item* items, int32_t n_items, int32_t n_blocks_total, int32_t dtype, void* stream) {
+    CDET_CHECK_ARG(items && n_items > 0 && n_blocks_total >= n_items, "cdet_pack_weights_tiled: bad arguments");
+    CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "cdet_pack_weights_tiled: dtype must be bf16/f16");
+    cdet_pack_tiled_item none = {};
+    hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3(n_blocks_total), dim3(256), 0, (hipStream_t)stream, items, n_items, none, dtype);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_pack_weight_tiled(const float* w_oihw, void* w_fwd, void* w_dgrad, int32_t O, int32_t I, int32_t kh, int32_t kw, int32_t dtype,
+                                      void* stream) {
+    CDET_CHECK_ARG(w_oihw && (w_fwd || w_dgrad) && O > 0 && I > 0, "cdet_pack_weight_tiled: bad arguments");
+    CDET_CHECK_ARG(kh == kw && (kh == 1 || kh == 3), "cdet_pack_weight_tiled: 1x1 / 3x3 only");
+    CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "cdet_pack_weight_tiled: dtype must be bf16/f16");
+    CDET_CHECK_ARG(!w_fwd || I % 32 == 0, "cdet_pack_weight_tiled: forward operand needs I %% 32 == 0 (I=%d)", I);
+    CDET_CHECK_ARG(!w_dgrad || O % 32 == 0, "cdet_pack_weight_tiled: DGRAD operand needs O %% 32 == 0 (O=%d)", O);
+    cdet_pack_tiled_item it = {};
+    it.w_oihw = w_oihw; it.w_fwd = w_fwd; it.w_dgrad = w_dgrad;
+    it.O = O; it.I = I; it.kh = kh; it.kw = kw; it.first_block = 0;
+    it.n_blocks = div_up(O, 32) * div_up(I, 32);
+    hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3(it.n_blocks), dim3(256), 0, (hipStream_t)stream, (const cdet_pack_tiled_item*)nullptr, 1, it, dtype);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
+                                 const void* residual, void* y, float* stats, void* stream) {
+    CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_tiled: null pointer");
+    CDET_CHECK_ARG(halo_supported(d), "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs %% 32 == 0, 16-bit in == out, W <= 95 for 3x3)");
+    CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_tiled: the data gradient is a FWD call on the DGRAD operand of cdet_pack_weights_tiled");
+    CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_tiled: residual ld/coff must be multiples of 8");
+    HaloArgs a;
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_tiled; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
+    a.y = y; a.stats = stats;
+    a.H = d->Hs; a.W = d->Ws; a.Cd = d->Cd;
+    a.M = d->N * d->Hs * d->Ws;
+    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;
+    a.res_ld = d->res_ld; a.res_coff = d->res_coff;
+    a.nchunk = d->Cs / 32;
+    a.n_pblk = div_up(a.M, HP);
+    a.n_cblk = div_up(d->Cd, HC);
+    a.act = d->act;
+    a.XH = halo_xh(d->Ws, d->kh);
+    a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
+    a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * d->kh * d->kw * WTILE);
+    const int nsw = halo_nsw(a.XH, d->kh);
+    const size_t lds = (size_t)HZERO + (size_t)halo_nxb(d->kh) * a.XH * HROW + (size_t)nsw * WTILE;
+    const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
+    const int nblocks = a.n_pblk * a.n_cblk;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == CDET_BF16) dispatch_halo<CDET_BF16>(a, d->kh, full, nsw, lds, nblocks, s);
+    else dispatch_halo<CDET_F16>(a, d->kh, full, nsw, lds, nblocks, s);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}

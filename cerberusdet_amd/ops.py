@@ -105,6 +105,35 @@ def conv2d(src: View, w_packed, dst: View, k, s, scale=None, bias=None, act=L.AC
     return dst
 
 
+def pack_weight_tiled(w_oihw: torch.Tensor, dtype, fwd=True, dgrad=False):
+    """Tiled operands of the tap-resident kernel (cdet_conv2d_tiled): returns (w_fwd | None, w_dgrad | None)."""
+    lib = L.load()
+    O, I, kh, kw = w_oihw.shape
+    w32 = w_oihw.detach().float().contiguous()
+    wf = torch.zeros(lib.cdet_tiled_weight_elems(O, I, kh, kw), dtype=dtype, device=w_oihw.device) if fwd else None
+    wd = torch.zeros(lib.cdet_tiled_weight_elems(I, O, kh, kw), dtype=dtype, device=w_oihw.device) if dgrad else None
+    L.check(lib.cdet_pack_weight_tiled(ptr(w32), ptr(wf), ptr(wd), O, I, kh, kw, dt(dtype), stream()), "cdet_pack_weight_tiled")
+    return wf, wd
+
+
+def conv2d_tiled_ok(src: View, dst: View, k, s) -> bool:
+    d = conv_desc(src, dst, k, s)
+    return bool(L.load().cdet_conv2d_tiled_ok(C.byref(d)))
+
+
+def conv2d_tiled(src: View, w_tiled, dst: View, k, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None, stats=None):
+    lib = L.load()
+    d = conv_desc(src, dst, k, 1, L.CONV_FWD, act, res)
+    L.check(lib.cdet_conv2d_tiled(C.byref(d), ptr(src), ptr(w_tiled), ptr(scale), ptr(bias), ptr(res), ptr(dst), ptr(stats), stream()),
+            "cdet_conv2d_tiled")
+    return dst
+
+
+def conv_tiled_stat_blocks(src: View, dst: View, k) -> int:
+    d = conv_desc(src, dst, k, 1)
+    return L.load().cdet_conv2d_tiled_stat_blocks(C.byref(d))
+
+
 def conv_stat_blocks(src: View, dst: View, k, s) -> int:
     d = conv_desc(src, dst, k, s)
     return L.load().cdet_conv2d_stat_blocks(C.byref(d))

@@ -1,0 +1,123 @@
+"""Tap-resident convolution (csrc/conv_halo.hip, cdet_conv2d_tiled) against an fp32 CPU reference of the same op.
+
+Inputs are exactly representable in the storage dtype, so the differences are the fp32 accumulation order and the one
+output rounding: 2^-7 relative for 16-bit outputs. Shapes cover: tiles that straddle image rows and images, M not a
+multiple of 256, W from 5 to 80 (2- and 3-stage weight rings), Cout not a multiple of 160, 1x1, concat-slice
+source / destination, residual, BN partial sums, and the data gradient through the flipped/transposed operand.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from cerberusdet_amd import ops
+
+    return ops
+
+
+def _rt(x, dtype):
+    return x.to(dtype).float()
+
+
+def _close(a, b, rtol, atol):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), f"max err {err.max():.4g} (ref max {b.abs().max():.4g}), {int(bad.sum())}/{bad.numel()} out of tolerance"
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, dtype
+    (2, 20, 20, 320, 320, 3, torch.bfloat16),   # two cout blocks, 10 chunks, tiles straddle images (800 px = 3.1 tiles)
+    (1, 40, 40, 64, 160, 3, torch.bfloat16),    # W = 40: 3-stage ring, 6.25 tiles
+    (1, 24, 80, 32, 160, 3, torch.bfloat16),    # W = 80: 2-stage ring, one chunk
+    (3, 7, 5, 96, 48, 3, torch.bfloat16),       # tiny odd map: every tile holds several images; Cout < 160 (masked rows)
+    (2, 16, 16, 320, 160, 1, torch.bfloat16),   # 1x1
+    (1, 12, 12, 416, 320, 1, torch.float16),    # fp16, 13 chunks
+    (1, 13, 21, 160, 200, 3, torch.float16),    # Cout not a multiple of 160 (second cout block mostly padding)
+    (1, 33, 95, 32, 32, 3, torch.bfloat16),     # widest supported map for 3x3 (7 X pieces per wave)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tiled_conv_fwd_epilogue_stats(case):
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    N, H, W, Ci, Co, k, dtype = case
+    g = torch.Generator().manual_seed(11)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype)
+    w = _rt(torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k), dtype)
+    scale = torch.rand(Co, generator=g) + 0.5
+    bias = torch.randn(Co, generator=g) * 0.1
+    ref_raw = F.conv2d(x, w, None, 1, k // 2)
+    res = _rt(torch.randn(N, Co, H, W, generator=g), dtype)
+    xb = torch.full((N, H, W, Ci + 16), 3.0, dtype=dtype, device=DEV)   # neighbours of the slice are NOT zero
+    xb[..., 8:8 + Ci] = x.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    src = ops.View(xb, 8, Ci)
+    wf, _ = ops.pack_weight_tiled(w.to(DEV), dtype)
+    # raw output + BN partial sums
+    dst = ops.new_act(N, H, W, Co, dtype)
+    assert ops.conv2d_tiled_ok(src, dst, k, 1)
+    nblk = ops.conv_tiled_stat_blocks(src, dst, k)
+    stats = torch.zeros(nblk * 2 * Co, device=DEV)
+    ops.conv2d_tiled(src, wf, dst, k, stats=stats)
+    torch.cuda.synchronize()
+    _close(dst.nchw(), ref_raw, 2 ** -7, 1e-3)
+    st = stats.view(nblk, 2, Co).sum(0).cpu()
+    _close(st[0], ref_raw.sum((0, 2, 3)), 1e-3, 1e-2)
+    _close(st[1], (ref_raw ** 2).sum((0, 2, 3)), 1e-3, 1e-2)
+    # fused epilogue into a slice of a wider buffer
+    yb = torch.full((N, H, W, Co + 16), 7.0, dtype=dtype, device=DEV)
+    dsl = ops.View(yb, 8, Co)
+    rv = ops.from_nchw(res.to(DEV), dtype)
+    ops.conv2d_tiled(src, wf, dsl, k, scale=scale.to(DEV), bias=bias.to(DEV), act=L.ACT_SILU, res=rv)
+    torch.cuda.synchronize()
+    ref = F.silu(ref_raw * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)) + res
+    _close(dsl.nchw(), ref, 2 ** -7, 2e-2)
+    assert (yb[..., :8].float() == 7.0).all() and (yb[..., 8 + Co:].float() == 7.0).all(), "conv wrote outside its channel slice"
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] % 32 == 0])
+def test_tiled_conv_dgrad_is_forward_on_flipped_operand(case):
+    ops = _ops()
+    N, H, W, Ci, Co, k, dtype = case
+    g = torch.Generator().manual_seed(12)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype).requires_grad_(True)
+    w = _rt(torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k), dtype)
+    y = F.conv2d(x, w, None, 1, k // 2)
+    dy = _rt(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    _, wd = ops.pack_weight_tiled(w.to(DEV), dtype, fwd=False, dgrad=True)
+    dyv = ops.from_nchw(dy.to(DEV), dtype)
+    dx = ops.new_act(N, H, W, Ci, dtype)
+    ops.conv2d_tiled(dyv, wd, dx, k)
+    torch.cuda.synchronize()
+    _close(dx.nchw(), x.grad, 2 ** -7, 2e-3 * float(x.grad.abs().max()))
+    # gradient fan-in: residual = the gradient already there
+    prev = ops.from_nchw(_rt(torch.randn(N, Ci, H, W, generator=g), dtype).to(DEV), dtype)
+    out = ops.new_act(N, H, W, Ci, dtype)
+    ops.conv2d_tiled(dyv, wd, out, k, res=prev)
+    torch.cuda.synchronize()
+    _close(out.nchw(), x.grad + prev.nchw().float().cpu(), 2 ** -7, 4e-3 * float(x.grad.abs().max()))
+
+
+def test_tiled_matches_generic_kernel_on_dominant_shape():
+    """40x40 320->320 3x3 at batch 4: both kernels see identical inputs; results agree to one output rounding."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, dtype = 4, 40, 40, 320, 320, 3, torch.bfloat16
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).to(dtype).float().to(DEV)
+    src = ops.View(x)
+    a, b = ops.new_act(N, H, W, Co, dtype), ops.new_act(N, H, W, Co, dtype)
+    ops.conv2d(src, ops.pack_weight(w, dtype), a, k, 1)
+    ops.conv2d_tiled(src, ops.pack_weight_tiled(w, dtype)[0], b, k)
+    torch.cuda.synchronize()
+    _close(b.torch(), a.torch(), 2 ** -6, 2e-3)
