@@ -150,9 +150,13 @@ def kernel_breakdown(trainer, batches, n_max):
         ms = e0.elapsed_time(e1)
         flops = 0.0
         key = name
-        if name in ("cdet_conv2d", "cdet_conv2d_wgrad"):
+        if name in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad"):
             d = args[0]._obj  # ctypes.byref(desc) keeps the descriptor
-            if name == "cdet_conv2d":
+            if name.startswith("cdet_conv2d_tiled"):
+                # the tap-resident kernel: its data gradient is a forward launch on the flipped operand (same FLOPs as the conv it differentiates)
+                key = "cdet_conv2d_tiled[dgrad]" if name.endswith("dgrad") else "cdet_conv2d_tiled[fwd]"
+                flops = 2.0 * d.N * d.Hd * d.Wd * d.Cd * d.Cs * d.kh * d.kw
+            elif name == "cdet_conv2d":
                 M = d.N * d.Hd * d.Wd
                 if d.mode == L.CONV_DGRAD:
                     key = "cdet_conv2d[dgrad]"
@@ -183,6 +187,30 @@ def nms_inputs(bs, nc, na, seed=7, dtype=torch.float16):
         cls = torch.randint(0, nc, (500,), generator=g)
         y[b, 4 + cls, idx] = torch.rand(500, generator=g) * 0.7 + 0.25
     return y.to(dtype)
+
+
+def north_star_forward(model, device, bs=32, imgsz=640, reps=20):
+    """BASELINE.json north_star: YOLOv8x 2-task all-heads FORWARD at batch 32 @640 (eval form: BN folded into the conv epilogue,
+    decode included), bf16 storage / fp32 accumulate, HIP-event timed on the launch stream in this process. Algorithmic work:
+    381.31 GFLOP per image (README.md:241 of the reference) -> fraction of the 2.5 PF/s dense bf16 MFMA peak."""
+    model.eval().bfloat16()
+    x = torch.rand(bs, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(3)).bfloat16().to(device)
+    with torch.no_grad():
+        for _ in range(3):
+            model(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            model(x)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    tf = bs * 381.31e9 * (imgsz / 640) ** 2 / (ms * 1e-3) / 1e12
+    model.train()
+    return {"ms": round(ms, 3), "tflops": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "images_per_sec": round(bs / ms * 1e3, 1),
+            "config": f"YOLOv8x 2-task all-heads forward + decode, eval form (BN folded), bf16, batch {bs} @{imgsz}",
+            "gflop_per_image": 381.31, "timing": f"HIP events around {reps} back-to-back forwards on the launch stream"}
 
 
 def inference_section(model, device, bs=128, imgsz=640, reps=10, nms_reps=50):
@@ -320,7 +348,8 @@ def main():
             if tf:
                 kern = json.load(open(tf[-1]))["kernels"]
                 fam = [f"conv_igemm_{v}_kernel<0, {t}" for v in ("pipe", "glds") for t in ("2, 2", "3, 1", "4, 2")]
-                main, extra = {"cdet_conv2d_wgrad": (("conv_wgrad_pipe_kernel", "conv_wgrad_kernel"), ("wgrad_reduce",)),
+                main, extra = {"cdet_conv2d_tiled[fwd]": (("conv_halo_kernel",), ()), "cdet_conv2d_tiled[dgrad]": (("conv_halo_kernel",), ()),
+                               "cdet_conv2d_wgrad": (("conv_wgrad_pipe_kernel", "conv_wgrad_kernel"), ("wgrad_reduce",)),
                                "cdet_conv2d[fwd]": (tuple(f"{f}, 0," for f in fam), ()),
                                "cdet_conv2d[dgrad]": (tuple(f"{f}, {m}," for f in fam for m in (1, 2)), ())}[dom]
                 sel = [v for k, v in kern.items() if k.startswith(main + extra)]
@@ -332,6 +361,7 @@ def main():
             out["mfma_kernels"] = {k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), "ms": round(v["ms"], 2), "launches": v["n"]}
                                    for k, v in agg.items() if v["flops"] > 0}
         if not args.no_infer and world == 1:
+            out["north_star_fwd"] = north_star_forward(model, device, bs=args.batch, imgsz=args.imgsz)
             out["inference"] = inference_section(model, device)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would just wait at the barrier
             out["cpu_baseline"] = cpu_baseline(cfg)

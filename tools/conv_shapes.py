@@ -34,11 +34,14 @@ def main():
     groups = OrderedDict()
     for fn, args in calls:
         name = getattr(fn, "__name__", "")
-        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad"):
+        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad"):
             continue
         d = args[0]._obj
-        kind = "wgrad" if name == "cdet_conv2d_wgrad" else ("dgrad" if d.mode == L.CONV_DGRAD else "fwd")
-        if kind == "dgrad":
+        kind = "wgrad" if name == "cdet_conv2d_wgrad" else ("dgrad" if (d.mode == L.CONV_DGRAD or name.endswith("dgrad")) else "fwd")
+        if name.endswith("tiled_dgrad"):
+            key = (kind, d.Hd, d.Wd, d.Cd, d.Cs, d.kh, 1)
+            flops = 2.0 * d.N * d.Hs * d.Ws * d.Cs * d.Cd * d.kh * d.kw
+        elif kind == "dgrad":
             key = (kind, d.Hd, d.Wd, d.Cd, d.Cs, d.kh, d.stride)  # dX spatial, Cin=Cd, Cout=Cs
             flops = 2.0 * d.N * d.Hs * d.Ws * d.Cs * d.Cd * d.kh * d.kw
         else:
