@@ -38,20 +38,21 @@ struct HaloArgs {
     int H, W, Cd;
     int M;  // N*H*W
     int src_ld, src_coff, dst_ld, dst_coff, res_ld, res_coff;
-    int nchunk;  // Cs / 32
+    int nchunk;  // ceil(Cs / 32)
+    int Cs;      // reduction channels (a last partial chunk is zero-filled: multiples of 8)
     int n_pblk, n_cblk;
     int act;
     int XH;  // halo rows per chunk buffer (multiple of 16)
+    int tiles_x, tiles_per_img;  // patch mode: 16x16 pixel patches per image row / per image
     unsigned x_bytes, w_bytes;
 };
 
 constexpr int HP = 256;             // pixels per block
-constexpr int HC = 160;             // couts per block
 constexpr int HROW = 64;            // bytes per LDS row (32 channels)
-constexpr int WTILE = HC * HROW;    // 10240 bytes per (cblk, chunk, tap) weight tile
 constexpr int HZERO = 256;          // LDS bytes reserved in front (zero row)
 constexpr int MAXXP = 7;            // X DMA pieces (16 rows each) per wave per chunk: XH <= 448
 constexpr unsigned HSENT = 0xE0000000u;  // byte offset beyond every buffer: the DMA returns zeros
+constexpr int PATCH_W = 16, PATCH_HPW = PATCH_W + 2;  // patch mode: 16 x 16 pixel tiles, halo pitch 18
 
 template <int DT>
 __device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c) {
@@ -79,6 +80,10 @@ __device__ __forceinline__ void wait_vm(int n) {
         default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     }
 }
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
 
 typedef __attribute__((ext_vector_type(2))) float hf32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
@@ -103,10 +108,33 @@ __device__ __forceinline__ float half_sum32(float v) {
 
 constexpr int HEPI_RAW = 0, HEPI_FULL = 1;
 
-// NT: taps (1 or 9); NSW: weight ring stages (2 or 3); ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop,
-// 2 = no fragment reads, 4 = no MFMA
-template <int DT, int NT, int EPI, int NSW, int ABL = 0>
+#ifdef CDET_PROFILING
+// per-workgroup timeline for tools/halo_timeline.py: [xcc id, hw id, t_start, t_loop, t_epilogue, t_end] (s_memtime clocks)
+__device__ unsigned long long* g_halo_dbg = nullptr;
+#define CDET_HALO_STAMP(slot)                                                                                   \
+    do {                                                                                                        \
+        if (g_halo_dbg != nullptr && threadIdx.x == 0) g_halo_dbg[(size_t)blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CDET_HALO_STAMP(slot) \
+    do {                      \
+    } while (0)
+#endif
+
+// NT: taps (1 or 9). NF: 32-cout fragments per wave (5 -> 160 couts per block, 3 -> 96 for the 80-channel layers). NSW: weight ring
+// stages (2 or 3). PATCH: the pixel tile is a 16 x 16 patch (halo 18 x 18 = 324 rows; maps whose sides are multiples of 16) instead
+// of 256 consecutive pixels (halo 256 + 2W + 2 rows) -- half the halo on the 80-wide maps, and the only form that fits for 160-wide.
+// ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no epilogue
+// stores, 16 = no K loop
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
+    constexpr int HC = NF * 32;           // couts per block
+    constexpr int WTILE = HC * HROW;      // bytes per (cblk, chunk, tap) weight tile: 10240 / 6144
+    constexpr int WQ = WTILE / 4;         // bytes of the tile each wave copies: 2 (1) full 1-KiB pieces + one half piece (lanes 0-31)
+    constexpr int NWP = (WQ + 1023) / 1024;  // DMA instructions per wave per tile: 3 / 2 -- the same for every wave
+    constexpr int NM = 2 * NF;            // MFMAs per phase (one k16 half of a step)
+    constexpr int NR = NF + 2;            // fragment reads per phase
+    static_assert(NM >= NR + 1, "phase B needs a slot for the weight DMA in front of the fragment reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -122,17 +150,34 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     }
     const int cblk = L % a.n_cblk;
     const int pblk = L / a.n_cblk;
-    const int p0 = pblk * HP;
     const int c0 = cblk * HC;
     const int W = a.W;
-    const int halo0 = NT == 9 ? W + 1 : 0;
     const int XHB = a.XH * HROW;
     const int nsteps = a.nchunk * NT;
+    // geometry of the pixel tile. linear: pixels p0 .. p0+255, halo row of tile pixel i = i + W + 1, tap pitch W.
+    // patch: tile (n, ty, tx) = 16 x 16 pixels at (ty*16, tx*16); halo row of pixel (iy, ix) = (iy+1)*18 + ix+1, tap pitch 18.
+    const int tpitch = NT == 9 ? (PATCH ? PATCH_HPW : W) : 0;
+    const int halo0 = NT == 9 ? tpitch + 1 : 0;
+    const int p0 = pblk * HP;  // linear mode
+    int pn = 0, py0 = 0, px0 = 0;  // patch mode: image, top-left pixel
+    if (PATCH) {
+        pn = pblk / a.tiles_per_img;
+        const int r = pblk - pn * a.tiles_per_img;
+        py0 = (r / a.tiles_x) * PATCH_W;
+        px0 = (r % a.tiles_x) * PATCH_W;
+    }
     unsigned char* const xbase = smem + HZERO;
     constexpr int NXB = NT == 1 ? 3 : 2;  // pixel buffers
     unsigned char* const wbase = smem + HZERO + NXB * XHB;
 
     if (t < 16) reinterpret_cast<uint32_t*>(smem)[t] = 0u;  // zero row (visible after the first barrier)
+#ifdef CDET_PROFILING
+    if (g_halo_dbg != nullptr && t == 0) {
+        g_halo_dbg[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+        g_halo_dbg[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+    }
+#endif
+    CDET_HALO_STAMP(2);
 
     // ---- X DMA pieces of this wave: piece id 4*i + wave covers halo rows 16*id .. 16*id+15, 4 lanes (64 B) per row --------------
     const int nxp_total = a.XH >> 4;
@@ -141,63 +186,88 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
     for (int i = 0; i < MAXXP; ++i) {
         const int hrow = 16 * (4 * i + wave) + (lane >> 2);
-        const int g = p0 - halo0 + hrow;
+        int g;
+        bool ok;
+        if (PATCH) {
+            const int hy = hrow / PATCH_HPW, hx = hrow - hy * PATCH_HPW;
+            const int y = py0 - 1 + hy, x = px0 - 1 + hx;
+            ok = hy < PATCH_HPW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)W;  // outside the image: zeros = the padding
+            g = (pn * a.H + y) * W + x;
+        } else {
+            g = p0 - halo0 + hrow;
+            ok = g >= 0 && g < a.M;
+        }
         const unsigned off = ((unsigned)g * (unsigned)a.src_ld + (unsigned)a.src_coff) * 2u + ((unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4);
-        xvoff[i] = (g >= 0 && g < a.M) ? off : HSENT;
+        xvoff[i] = ok ? off : HSENT;
     }
-    // ---- W DMA pieces: piece id wave + 4*j (< 10), a plain linear copy of the packed tile ----------------------------------------
-    const int nwp = wave < 2 ? 3 : 2;  // wave-uniform
-    const unsigned wvoff = (unsigned)(wave * 1024 + lane * 16);
+    const bool partial = (a.Cs & 31) != 0;                   // wave-uniform
+    const int xls = (lane & 3) ^ ((lane >> 4) & 3);          // logical 16-byte slot this lane fetches (the same for every piece)
+    // ---- W DMA: a plain linear copy of the packed tile; wave w copies bytes [w*WQ, (w+1)*WQ) -----------------------------------
+    const unsigned wvoff = (unsigned)(wave * WQ + lane * 16);
     const unsigned wtile0 = (unsigned)cblk * (unsigned)nsteps * (unsigned)WTILE;
 
     // Steps / chunks beyond the end are requested through an EMPTY descriptor (every load returns zeros), so the number of DMA
     // instructions per step -- what the counted vmcnt waits rely on -- never changes.
     auto dma_w1 = [&](int step, int stage, int j) {  // piece j of this wave of the weight tile of K step `step` -> ring stage `stage`
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, step < nsteps ? (int)a.w_bytes : 0, 0x00020000);
-        unsigned char* dst = wbase + stage * WTILE + wave * 1024 + j * 4096;
+        unsigned char* dst = wbase + stage * WTILE + wave * WQ + j * 1024;
         const unsigned soff = wtile0 + (unsigned)step * (unsigned)WTILE;
-        if (j < nwp) dma16(rs, wvoff + (unsigned)j * 4096u, soff, dst);
+        if (j < NWP - 1) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);
+        else if (j == NWP - 1 && lane < 32) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);  // the 512-byte tail of the wave's share
     };
     auto dma_x = [&](int i, int chunk, int xb) {  // piece i of this wave, channels of `chunk` -> pixel buffer xb
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, chunk < a.nchunk ? (int)a.x_bytes : 0, 0x00020000);
         unsigned char* dst = xbase + xb * XHB + (4 * i + wave) * 1024;
-        dma16(rs, xvoff[i] + (unsigned)chunk * 64u, 0u, dst);
+        unsigned v = xvoff[i] + (unsigned)chunk * 64u;
+        // last partial chunk (Cs % 32 != 0, the 80-channel layers): the lanes whose 8-channel slot lies beyond Cs fetch zeros -- what
+        // sits there in memory is a neighbouring channel slice (possibly never written), and 0-weight x NaN would still be NaN
+        if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
+        dma16(rs, v, 0u, dst);
     };
 
     // ---- fragment read offsets -------------------------------------------------------------------------------------------------
     // A (weights): row f*32 + l31 of the stage, k-slot 2*s + h
     const int aoff0 = l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
-    // B (pixels): tile pixel wave*64 + g*32 + l31; validity bit per tap
-    int pix[2];
+    // B (pixels): tile pixel wave*64 + g*32 + l31: its output pixel index, the halo row of its centre, validity bit per tap
+    int pixh[2], pout[2];
     unsigned vmask[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        pix[g] = wave * 64 + g * 32 + l31;
-        const int p = p0 + pix[g];
+        const int i = wave * 64 + g * 32 + l31;
         unsigned m = 0u;
-        if (p < a.M) {
-            if (NT == 9) {
-                const int x = p % W;
-                const int y = (p / W) % a.H;
-                unsigned rb = 0u, cb = 0u;
+        if (PATCH) {
+            const int iy = i / PATCH_W, ix = i % PATCH_W;
+            pixh[g] = iy * PATCH_HPW + ix + halo0;
+            pout[g] = (pn * a.H + py0 + iy) * W + px0 + ix;
+            m = 0x1ffu;  // every halo row is the right neighbour or the zero padding
+        } else {
+            pixh[g] = i + halo0;
+            const int p = p0 + i;
+            pout[g] = p;
+            if (p < a.M) {
+                if (NT == 9) {
+                    const int x = p % W;
+                    const int y = (p / W) % a.H;
+                    unsigned rb = 0u, cb = 0u;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    if ((unsigned)(y + k - 1) < (unsigned)a.H) rb |= 1u << k;
-                    if ((unsigned)(x + k - 1) < (unsigned)W) cb |= 1u << k;
+                    for (int k = 0; k < 3; ++k) {
+                        if ((unsigned)(y + k - 1) < (unsigned)a.H) rb |= 1u << k;
+                        if ((unsigned)(x + k - 1) < (unsigned)W) cb |= 1u << k;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if ((rb >> k) & 1u) m |= cb << (3 * k);
+                } else {
+                    m = 1u;
                 }
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if ((rb >> k) & 1u) m |= cb << (3 * k);
-            } else {
-                m = 1u;
             }
         }
         vmask[g] = m;
     }
 
-    f32x16 acc[5][2];
+    f32x16 acc[NF][2];
 #pragma unroll
-    for (int f = 0; f < 5; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -208,18 +278,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     for (int i = 0; i < MAXXP; ++i)
         if (i < nxpw) dma_x(i, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) dma_w1(0, 0, j);
+    for (int j = 0; j < NWP; ++j) dma_w1(0, 0, j);
     if (NT == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_x(i, 1, 1);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) dma_w1(1, 1, j);
+    for (int j = 0; j < NWP; ++j) dma_w1(1, 1, j);
     if (NSW == 3) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) dma_w1(2, 2, j);
+        for (int j = 0; j < NWP; ++j) dma_w1(2, 2, j);
     }
-    wait_vm((NT == 1 ? 4 : 0) + (NSW - 1) * nwp);  // tile 0 and chunk 0 have landed
+    wait_vm((NT == 1 ? 4 : 0) + (NSW - 1) * NWP);  // tile 0 and chunk 0 have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -228,18 +298,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         const int dy_ = tap_ / 3 - 1, dx_ = tap_ % 3 - 1;
         // opaque copies: without them the compiler hoists the nine per-tap offset pairs (and their scalar parts) out of the chunk
         // loop as loop invariants -- 18 VGPRs + ~30 SGPRs the 256-register budget does not have (spills); recomputing costs 8 VALU
-        int Wv = W, p_[2] = {pix[0], pix[1]};
-        asm volatile("" : "+s"(Wv), "+v"(p_[0]), "+v"(p_[1]));
+        int tp = tpitch, p_[2] = {pixh[0], pixh[1]};
+        asm volatile("" : "+s"(tp), "+v"(p_[0]), "+v"(p_[1]));
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int hrow = p_[g] + halo0 + (NT == 9 ? dy_ * Wv + dx_ : 0);
+            const int hrow = p_[g] + (NT == 9 ? dy_ * tp + dx_ : 0);
             const int off = hrow * HROW + ((h ^ ((hrow >> 2) & 3)) << 4);
             const bool ok = (vmask[g] >> tap_) & 1u;
             bo[g] = ok ? off + xoff : 0;  // invalid tap / pixel: the zero row
         }
     };
     // fragment i of a k16 half: i < 2 -> pixel rows (B operand), else weight rows (A operand); read order = use order
-    auto frag = [&](const unsigned char* ws_, const int (&bo)[2], int s_, int i, u32x4 (&af)[5], u32x4 (&bf)[2]) {
+    auto frag = [&](const unsigned char* ws_, const int (&bo)[2], int s_, int i, u32x4 (&af)[NF], u32x4 (&bf)[2]) {
         if (ABL & 2) {
             if (i < 2) bf[i] = u32x4{(unsigned)lane, 1u, 2u, 3u};
             else af[i - 2] = u32x4{(unsigned)lane, 1u, 2u, 3u};
@@ -250,17 +320,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         }
     };
 
+    CDET_HALO_STAMP(3);
     int bo_cur[2], bo_nxt[2];
-    u32x4 a0[5], b0[2], a1[5], b1[2];
+    u32x4 a0[NF], b0[2], a1[NF], b1[2];
     b_offsets(HZERO, 0, bo_cur);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) frag(wbase, bo_cur, 0, i, a0, b0);
+    for (int i = 0; i < NR; ++i) frag(wbase, bo_cur, 0, i, a0, b0);
 
     // One K step. `u` is the step's position inside the unrolled group (3x3: the tap, 9 per chunk; 1x1: 3 chunks per group), a
     // compile-time constant after unrolling, so the tap offsets, the ring stage (NSW == 3) and the pixel-piece schedule fold away;
     // `chunk` is the step's channel chunk, `st` its index.
     auto step = [&](int st, int chunk, int u) {
-        const int tap = NT == 9 ? u : 0;
         const int sc = NSW == 3 ? u % 3 : (st & 1);           // ring stage of this step's tile (compile-time for NSW == 3)
         const int sn = NSW == 3 ? (u + 1) % 3 : ((st + 1) & 1);
         const unsigned char* ws = wbase + sc * WTILE;
@@ -273,17 +343,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         // ---- phase A: MFMAs of (st, k16 #0); the fragment reads of (st, k16 #1), the address arithmetic of step st+1 and the pixel
         //      pieces of the next chunk (3x3: one per step; 1x1: the whole chunk st+2 into the third buffer) in their shadow
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < NM; ++i) {
             if (!(ABL & 4)) mfma32<DT>(a0[i >> 1], b0[i & 1], acc[i >> 1][i & 1]);
-            if (i < 7) frag(ws, bo_cur, 1, i, a1, b1);
-            if (i == 7) b_offsets(HZERO + xbn * XHB, tapn, bo_nxt);
+            if (i < NR) frag(ws, bo_cur, 1, i, a1, b1);
+            if (i == NM - 1) b_offsets(HZERO + xbn * XHB, tapn, bo_nxt);
             if (!(ABL & 1)) {
                 if (NT == 9) {
-                    if (i == 8 && u < MAXXP) {
+                    if (i == NM - 2 && u < MAXXP) {
                         if (xa) dma_x(u, chunk + 1, (chunk + 1) & 1);
                     }
-                } else if ((i & 1) == 1 && i < 8) {
-                    dma_x(i >> 1, chunk + 2, (u + 2) % 3);
+                } else if (i < 4) {
+                    dma_x(i, chunk + 2, (u + 2) % 3);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -291,46 +361,32 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         // tile st+1 (and, at a chunk boundary, the next chunk's pixels) have landed -- the weight pieces issued in the previous phase B
         // and this phase's pixel pieces may stay in flight; nobody reads tile st's stage any more
         if (NT == 9) {
-            if (NSW == 3) {
-                if (nwp == 3) {
-                    if (xa) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-                } else {
-                    if (xa) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-                }
-            } else {
-                if (xa) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
+            if (xa) wait_vm_lgkm0<(NSW - 2) * NWP + 1>();
+            else wait_vm_lgkm0<(NSW - 2) * NWP>();
         } else {
-            if (NSW == 3) {
-                if (nwp == 3) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            }
+            wait_vm_lgkm0<(NSW - 2) * NWP + 4>();
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase B: MFMAs of (st, k16 #1); DMA of the tile NSW steps ahead into the stage just freed and the fragment reads of
         //      (st+1, k16 #0) in their shadow
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < NM; ++i) {
             if (!(ABL & 4)) mfma32<DT>(a1[i >> 1], b1[i & 1], acc[i >> 1][i & 1]);
             if (!(ABL & 1)) {
                 if (i == 0) dma_w1(st + NSW, sc, 0);
-                if (i == 3) dma_w1(st + NSW, sc, 1);
-                if (i == 6) dma_w1(st + NSW, sc, 2);
+                if (i == (NM >= 10 ? 3 : 2)) dma_w1(st + NSW, sc, 1);
+                if (i == (NM >= 10 ? 6 : 4)) dma_w1(st + NSW, sc, 2);
             }
-            if (i >= 1 && i < 8) frag(wsn, bo_nxt, 0, i - 1, a0, b0);
+            if (i >= 1 && i <= NR) frag(wsn, bo_nxt, 0, i - 1, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
         }
         bo_cur[0] = bo_nxt[0];
         bo_cur[1] = bo_nxt[1];
     };
 
-    if (NT == 9) {
+    if (ABL & 16) {
+    } else if (NT == 9) {
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
 #pragma unroll
             for (int u = 0; u < 9; ++u) step(chunk * 9 + u, chunk, u);
@@ -342,15 +398,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 if (c3 + u < a.nchunk) step(c3 + u, c3 + u, u);
         }
     }
+    CDET_HALO_STAMP(4);
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");  // asm MFMAs are opaque to the hazard recogniser; trailing (dead) DMA drained
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- BN statistics of the raw convolution (train mode): per (pixel block, channel) partial sums ---------------------------------
     if (a.stats != nullptr) {
-        float* stl = reinterpret_cast<float*>(smem + HZERO);  // [4 waves][2][160]
+        float* stl = reinterpret_cast<float*>(smem + HZERO);  // [4 waves][2][HC]
 #pragma unroll
-        for (int f = 0; f < 5; ++f) {
+        for (int f = 0; f < NF; ++f) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v0 = acc[f][0][r], v1 = acc[f][1][r];
@@ -380,14 +437,25 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     //      neighbouring 4. v_permlane32_swap of run q (even) against run q+1 leaves 8 consecutive couts per lane -> scale / bias /
     //      residual as 16-byte vectors and ONE 16-byte NHWC store per run pair (half the store instructions of the 8-byte form)
     uint16_t* const yp = reinterpret_cast<uint16_t*>(a.y);
+    // per-channel scale / bias of the block's couts go through LDS once: as global loads inside the unrolled epilogue they were
+    // 80 dependent L2 round trips per lane (the 160 live accumulators leave no registers to prefetch them) -- 2/3 of the epilogue's time
+    float* const sbl = reinterpret_cast<float*>(smem + HZERO + 8192);  // [2][HC], behind the statistics scratch
+    if (EPI == HEPI_FULL) {
+        if (t < HC) {
+            const int c = c0 + t < a.Cd ? c0 + t : a.Cd - 1;
+            sbl[t] = a.scale ? a.scale[c] : 1.f;
+            sbl[HC + t] = a.bias ? a.bias[c] : 0.f;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int p = p0 + wave * 64 + g * 32 + l31;
+        const int p = pout[g];
         const bool pok = p < a.M;
         const int64_t ob = (int64_t)p * a.dst_ld + a.dst_coff;
         const int64_t rb = (int64_t)p * a.res_ld + a.res_coff;
 #pragma unroll
-        for (int f = 0; f < 5; ++f) {
+        for (int f = 0; f < NF; ++f) {
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
                 float v[8];
@@ -403,20 +471,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 const int co = c0 + f * 32 + 8 * (q + h);
                 if (!pok || co >= a.Cd) continue;
                 if (EPI == HEPI_FULL) {
-                    if (a.scale) {
-                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale + co), s1 = *reinterpret_cast<const f32x4*>(a.scale + co + 4);
+                    {
+                        const int cl = f * 32 + 8 * (q + h);
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbl + cl), s1 = *reinterpret_cast<const f32x4*>(sbl + cl + 4);
+                        const f32x4 b0v = *reinterpret_cast<const f32x4*>(sbl + HC + cl), b1v = *reinterpret_cast<const f32x4*>(sbl + HC + cl + 4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            v[r] *= s0[r];
-                            v[4 + r] *= s1[r];
-                        }
-                    }
-                    if (a.bias) {
-                        const f32x4 b0v = *reinterpret_cast<const f32x4*>(a.bias + co), b1v = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v[r] += b0v[r];
-                            v[4 + r] += b1v[r];
+                            v[r] = v[r] * s0[r] + b0v[r];
+                            v[4 + r] = v[4 + r] * s1[r] + b1v[r];
                         }
                     }
                     if (a.act == CDET_ACT_SILU) {
@@ -435,23 +497,31 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 u32x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = hpack2<DT>(v[2 * r], v[2 * r + 1]);
-                *reinterpret_cast<u32x4*>(yp + ob + co) = pk;
+                if (!(ABL & 8)) *reinterpret_cast<u32x4*>(yp + ob + co) = pk;
+                else asm volatile("" ::"v"(pk));
             }
         }
     }
+#ifdef CDET_PROFILING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CDET_HALO_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Tiled weight pack: OIHW fp32 master -> [row block of 160][chunk of 32 reduction channels][tap][160 rows][32 k], 16-B slots swizzled.
+// Tiled weight pack: OIHW fp32 master -> [row block of RB][chunk of 32 reduction channels][tap][RB rows][32 k], 16-B slots swizzled;
+// RB = 160 (96 when there are at most 96 rows: the 80-channel layers run 3 instead of 5 cout fragments per wave).
 //   forward operand : rows = o, reduction = i, tap as stored
 //   DGRAD operand   : rows = i, reduction = o, taps flipped (kh, kw) -> (KH-1-kh, KW-1-kw): the stride-1 data gradient becomes a
 //                     plain forward convolution of dY with this operand
 // One workgroup transposes a [32 o][32 i][taps] tile through LDS (the master is read once, in runs of 32*taps floats).
 // ------------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t tiled_elem(int row, int chunk, int tap, int k, int nchunk, int taps) {
-    const int cb = row / HC, r = row - cb * HC;
+static __host__ __device__ __forceinline__ int row_block(int rows) { return rows <= 96 ? 96 : 160; }
+
+__device__ __forceinline__ int64_t tiled_elem(int row, int chunk, int tap, int k, int nchunk, int taps, int rb) {
+    const int cb = row / rb, r = row - cb * rb;
     const int64_t tile = ((int64_t)cb * nchunk + chunk) * taps + tap;
-    return tile * (HC * 32) + r * 32 + ((((k >> 3) ^ ((r >> 2) & 3)) << 3) | (k & 7));
+    return tile * (rb * 32) + r * 32 + ((((k >> 3) ^ ((r >> 2) & 3)) << 3) | (k & 7));
 }
 
 __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack_tiled_item* __restrict__ items, int n, cdet_pack_tiled_item single,
@@ -487,6 +557,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
     __syncthreads();
     uint16_t* wf = reinterpret_cast<uint16_t*>(p.w_fwd);
     uint16_t* wd = reinterpret_cast<uint16_t*>(p.w_dgrad);
+    const int rbf = row_block(p.O), rbd = row_block(p.I);
     // one 16-byte piece (8 k values) per work item: (row 0..31, tap, k-slot 0..3)
     for (int e = threadIdx.x; e < 32 * taps * 4; e += 256) {
         const int kq = e & 3, tap = (e >> 2) % taps, row = (e >> 2) / taps;
@@ -497,7 +568,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
                 const float f = tile[row][(kq * 8 + j) * taps + tap];
                 v[j] = dtype == CDET_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
             }
-            const int64_t at = tiled_elem(o0 + row, i0 >> 5, tap, kq * 8, p.I >> 5, taps);
+            const int64_t at = tiled_elem(o0 + row, i0 >> 5, tap, kq * 8, (p.I + 31) >> 5, taps, rbf);
             u32x4 pk = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16), (uint32_t)v[4] | ((uint32_t)v[5] << 16),
                         (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
             *reinterpret_cast<u32x4*>(wf + at) = pk;
@@ -509,7 +580,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
                 const float f = tile[kq * 8 + j][row * taps + tap];
                 v[j] = dtype == CDET_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
             }
-            const int64_t at = tiled_elem(i0 + row, o0 >> 5, taps - 1 - tap, kq * 8, (p.O + 31) >> 5, taps);
+            const int64_t at = tiled_elem(i0 + row, o0 >> 5, taps - 1 - tap, kq * 8, (p.O + 31) >> 5, taps, rbd);
             u32x4 pk = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16), (uint32_t)v[4] | ((uint32_t)v[5] << 16),
                         (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
             *reinterpret_cast<u32x4*>(wd + at) = pk;
@@ -517,87 +588,128 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
     }
 }
 
-static inline int halo_xh(int W, int k) { return ((k == 3 ? HP + 2 * (W + 1) : HP) + 15) / 16 * 16; }
+// launch geometry of a supported convolution
+struct HaloPlan {
+    bool ok, patch;
+    int nf, XH, nsw, nxb;
+    size_t lds;
+};
 
-// which ring depth fits two workgroups per CU (80 KiB each)
-static inline int halo_nxb(int k) { return k == 1 ? 3 : 2; }
-static inline int halo_nsw(int XH, int k) { return HZERO + halo_nxb(k) * XH * HROW + 3 * WTILE <= 80 * 1024 ? 3 : 2; }
-
-static bool halo_supported(const cdet_conv_desc* d) {
-    if (!(d->kh == d->kw && (d->kh == 1 || d->kh == 3))) return false;
-    if (d->stride != 1 || d->pad != d->kh / 2) return false;
-    if (d->Hs != d->Hd || d->Ws != d->Wd) return false;
-    if (d->Cs % 32 != 0 || d->src_ld % 8 != 0 || d->src_coff % 8 != 0) return false;
-    if (d->Cd % 8 != 0 || d->dst_ld % 8 != 0 || d->dst_coff % 8 != 0) return false;
-    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16) || d->out_dtype != d->dtype || d->accumulate) return false;
-    const int XH = halo_xh(d->Ws, d->kh);
-    if (XH > 16 * 4 * MAXXP) return false;
-    if (d->kh == 1 && XH != HP) return false;
+static HaloPlan halo_plan(const cdet_conv_desc* d) {
+    HaloPlan pl = {};
+    if (!(d->kh == d->kw && (d->kh == 1 || d->kh == 3))) return pl;
+    if (d->stride != 1 || d->pad != d->kh / 2) return pl;
+    if (d->Hs != d->Hd || d->Ws != d->Wd) return pl;
+    if (d->Cs % 8 != 0 || d->src_ld % 8 != 0 || d->src_coff % 8 != 0) return pl;
+    if (d->Cd % 8 != 0 || d->dst_ld % 8 != 0 || d->dst_coff % 8 != 0) return pl;
+    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16) || d->out_dtype != d->dtype || d->accumulate) return pl;
+    const int rb = row_block(d->Cd);
+    pl.nf = rb / 32;
+    if (d->kh == 1) {
+        pl.patch = false;
+        pl.XH = HP;
+    } else {
+        const int lin = (HP + 2 * (d->Ws + 1) + 15) / 16 * 16;
+        const int pat = (PATCH_HPW * PATCH_HPW + 15) / 16 * 16;  // 336
+        pl.patch = d->Hs % PATCH_W == 0 && d->Ws % PATCH_W == 0 && pat < lin;
+        pl.XH = pl.patch ? pat : lin;
+        if (pl.XH > 16 * 4 * MAXXP) return pl;
+    }
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
-    if (M >= (1ll << 31) - HP) return false;
-    if (M * d->src_ld * 2 >= 0xC0000000ll) return false;
-    const int64_t wb = (int64_t)div_up(d->Cd, HC) * (d->Cs / 32) * d->kh * d->kw * WTILE;
-    if (wb >= 0xC0000000ll) return false;
-    return true;
+    if (M >= (1ll << 31) - HP) return pl;
+    if (M * d->src_ld * 2 >= 0xC0000000ll) return pl;
+    const int64_t wb = (int64_t)div_up(d->Cd, rb) * div_up(d->Cs, 32) * d->kh * d->kw * rb * HROW;
+    if (wb >= 0xC0000000ll) return pl;
+    pl.nxb = d->kh == 1 ? 3 : 2;
+    // ring depth: three stages when two workgroups still fit a CU (80 KiB each); the patch and 1x1 forms always do
+    const size_t base = (size_t)HZERO + (size_t)pl.nxb * pl.XH * HROW;
+    pl.nsw = base + 3 * (size_t)rb * HROW <= 80 * 1024 ? 3 : 2;
+    if ((pl.patch || d->kh == 1) && pl.nsw != 3) return pl;
+    pl.lds = base + (size_t)pl.nsw * rb * HROW;
+    pl.ok = true;
+    return pl;
 }
 
-template <int DT, int NT, int EPI, int NSW>
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH>
 static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, EPI, NSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
 #ifdef CDET_PROFILING
+    {
+        static bool once = false;
+        if (!once) {
+            once = true;
+            int nb = -1;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>, 256, lds);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, (const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>);
+            fprintf(stderr, "[cdet] conv_halo_kernel<%d,%d,%d,%d,%d,%d>: lds %zu B, occupancy API %d blocks/CU (%s), regs %d\n", DT, NT, NF, EPI, NSW, (int)PATCH, lds, nb,
+                    hipGetErrorString(e), fa.numRegs);
+        }
+    }
     static int abl = -1;
     if (abl < 0) {
         const char* e = getenv("CDET_HALO_ABLATE");
         abl = e ? atoi(e) : 0;
         if (abl) fprintf(stderr, "[cdet] CDET_HALO_ABLATE=%d: conv results are WRONG by design (timing experiment)\n", abl);
     }
-    if constexpr (DT == CDET_BF16 && NT == 9 && EPI == HEPI_FULL && NSW == 3) {
-#define CDET_HABL(N)                                                                                                                         \
-    case N:                                                                                                                                   \
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, EPI, NSW, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((conv_halo_kernel<DT, NT, EPI, NSW, N>), dim3(nblocks), dim3(256), lds, s, a);                                     \
+    if constexpr (DT == CDET_BF16 && NT == 9 && NF == 5 && EPI == HEPI_FULL && NSW == 3 && !PATCH) {
+#define CDET_HABL(N)                                                                                                                                      \
+    case N:                                                                                                                                                \
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, N>), dim3(nblocks), dim3(256), lds, s, a);                                       \
         return;
         switch (abl) {
-            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(5) CDET_HABL(6) CDET_HABL(7)
+            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(7) CDET_HABL(8) CDET_HABL(15)
             default: break;
         }
 #undef CDET_HABL
     }
 #endif
-    hipLaunchKernelGGL((conv_halo_kernel<DT, NT, EPI, NSW>), dim3(nblocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>), dim3(nblocks), dim3(256), lds, s, a);
+}
+
+template <int DT, int NF, int EPI>
+static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nblocks, hipStream_t s) {
+    if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false>(a, pl.lds, nblocks, s);
+    else if (pl.patch) launch_halo<DT, 9, NF, EPI, 3, true>(a, pl.lds, nblocks, s);
+    else if (pl.nsw == 3) launch_halo<DT, 9, NF, EPI, 3, false>(a, pl.lds, nblocks, s);
+    else launch_halo<DT, 9, NF, EPI, 2, false>(a, pl.lds, nblocks, s);
 }
 
 template <int DT>
-static void dispatch_halo(const HaloArgs& a, int k, bool full, int nsw, size_t lds, int nblocks, hipStream_t s) {
-#define CDET_HALO_GO(NT, EPI)                                              \
-    do {                                                                   \
-        if (nsw == 3) launch_halo<DT, NT, EPI, 3>(a, lds, nblocks, s);      \
-        else launch_halo<DT, NT, EPI, 2>(a, lds, nblocks, s);               \
-    } while (0)
-    if (k == 3) {
-        if (full) CDET_HALO_GO(9, HEPI_FULL);
-        else CDET_HALO_GO(9, HEPI_RAW);
+static void dispatch_halo(const HaloArgs& a, int k, bool full, const HaloPlan& pl, int nblocks, hipStream_t s) {
+    if (pl.nf == 5) {
+        if (full) dispatch_halo2<DT, 5, HEPI_FULL>(a, k, pl, nblocks, s);
+        else dispatch_halo2<DT, 5, HEPI_RAW>(a, k, pl, nblocks, s);
     } else {
-        if (full) CDET_HALO_GO(1, HEPI_FULL);
-        else CDET_HALO_GO(1, HEPI_RAW);
+        if (full) dispatch_halo2<DT, 3, HEPI_FULL>(a, k, pl, nblocks, s);
+        else dispatch_halo2<DT, 3, HEPI_RAW>(a, k, pl, nblocks, s);
     }
-#undef CDET_HALO_GO
 }
 
 }  // namespace cdet
 
 using namespace cdet;
 
-extern "C" int cdet_conv2d_tiled_ok(const cdet_conv_desc* d) { return d && halo_supported(d) ? 1 : 0; }
+#ifdef CDET_PROFILING
+// profiling builds only (not part of the C-ABI): per-workgroup timeline buffer of 8 u64 per workgroup, or NULL to switch it off
+extern "C" int cdet_debug_halo_timeline(void* buf) {
+    unsigned long long* p = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_halo_dbg), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int cdet_conv2d_tiled_ok(const cdet_conv_desc* d) { return d && halo_plan(d).ok ? 1 : 0; }
 
 extern "C" int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d) { return div_up((int64_t)d->N * d->Hd * d->Wd, HP); }
 
 extern "C" int64_t cdet_tiled_weight_elems(int32_t rows, int32_t red, int32_t kh, int32_t kw) {
-    return (int64_t)div_up(rows, HC) * div_up(red, 32) * kh * kw * (HC * 32);
+    const int rb = row_block(rows);
+    return (int64_t)div_up(rows, rb) * div_up(red, 32) * kh * kw * (rb * 32);
 }
 
 extern "C" int cdet_pack_weights_tiled(const cdet_pack_tiled_item* items, int32_t n_items, int32_t n_blocks_total, int32_t dtype, void* stream) {
@@ -614,8 +726,6 @@ extern "C" int cdet_pack_weight_tiled(const float* w_oihw, void* w_fwd, void* w_
     CDET_CHECK_ARG(w_oihw && (w_fwd || w_dgrad) && O > 0 && I > 0, "cdet_pack_weight_tiled: bad arguments");
     CDET_CHECK_ARG(kh == kw && (kh == 1 || kh == 3), "cdet_pack_weight_tiled: 1x1 / 3x3 only");
     CDET_CHECK_ARG(dtype == CDET_BF16 || dtype == CDET_F16, "cdet_pack_weight_tiled: dtype must be bf16/f16");
-    CDET_CHECK_ARG(!w_fwd || I % 32 == 0, "cdet_pack_weight_tiled: forward operand needs I %% 32 == 0 (I=%d)", I);
-    CDET_CHECK_ARG(!w_dgrad || O % 32 == 0, "cdet_pack_weight_tiled: DGRAD operand needs O %% 32 == 0 (O=%d)", O);
     cdet_pack_tiled_item it = {};
     it.w_oihw = w_oihw; it.w_fwd = w_fwd; it.w_dgrad = w_dgrad;
     it.O = O; it.I = I; it.kh = kh; it.kw = kw; it.first_block = 0;
@@ -628,9 +738,12 @@ extern "C" int cdet_pack_weight_tiled(const float* w_oihw, void* w_fwd, void* w_
 extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                                  const void* residual, void* y, float* stats, void* stream) {
     CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_tiled: null pointer");
-    CDET_CHECK_ARG(halo_supported(d), "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs %% 32 == 0, 16-bit in == out, W <= 95 for 3x3)");
+    const HaloPlan pl = halo_plan(d);
+    CDET_CHECK_ARG(pl.ok, "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs/Cd/ld/coff %% 8 == 0, 16-bit in == out, "
+                          "3x3: W <= 95 or H, W multiples of 16)");
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_tiled: the data gradient is a FWD call on the DGRAD operand of cdet_pack_weights_tiled");
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_tiled: residual ld/coff must be multiples of 8");
+    const int rb = pl.nf * 32;
     HaloArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_tiled; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
     a.y = y; a.stats = stats;
@@ -638,20 +751,21 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     a.M = d->N * d->Hs * d->Ws;
     a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;
     a.res_ld = d->res_ld; a.res_coff = d->res_coff;
-    a.nchunk = d->Cs / 32;
+    a.nchunk = div_up(d->Cs, 32);
+    a.Cs = d->Cs;
     a.n_pblk = div_up(a.M, HP);
-    a.n_cblk = div_up(d->Cd, HC);
+    a.n_cblk = div_up(d->Cd, rb);
     a.act = d->act;
-    a.XH = halo_xh(d->Ws, d->kh);
+    a.XH = pl.XH;
+    a.tiles_x = d->Ws / PATCH_W;
+    a.tiles_per_img = (d->Hs / PATCH_W) * (d->Ws / PATCH_W);
     a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
-    a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * d->kh * d->kw * WTILE);
-    const int nsw = halo_nsw(a.XH, d->kh);
-    const size_t lds = (size_t)HZERO + (size_t)halo_nxb(d->kh) * a.XH * HROW + (size_t)nsw * WTILE;
+    a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * d->kh * d->kw * rb * HROW);
     const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
     const int nblocks = a.n_pblk * a.n_cblk;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == CDET_BF16) dispatch_halo<CDET_BF16>(a, d->kh, full, nsw, lds, nblocks, s);
-    else dispatch_halo<CDET_F16>(a, d->kh, full, nsw, lds, nblocks, s);
+    if (d->dtype == CDET_BF16) dispatch_halo<CDET_BF16>(a, d->kh, full, pl, nblocks, s);
+    else dispatch_halo<CDET_F16>(a, d->kh, full, pl, nblocks, s);
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -107,8 +107,9 @@ int cdet_pack_weights_batched(const cdet_pack_item* items, int32_t n_items, int3
  * Same arithmetic and epilogue as cdet_conv2d (y = act(conv * scale + bias) (+ residual), optional BN partial sums in
  * `stats` with cdet_conv2d_tiled_stat_blocks(d) pixel blocks of 256), but the weight operand is the TILED pack below and
  * the pixel tile is staged in LDS once per 32-channel chunk with its halo and reused by all nine taps.
- * Supported (cdet_conv2d_tiled_ok(d) == 1): kh == kw in {1,3}, stride 1, pad kh/2, Cs % 32 == 0, 16-bit in == out dtype,
- * no fp32 accumulate, Ws <= 95 for 3x3. The data gradient of such a convolution is a FWD call (d->mode = CDET_CONV_FWD,
+ * Supported (cdet_conv2d_tiled_ok(d) == 1): kh == kw in {1,3}, stride 1, pad kh/2, channels / ld / coff multiples of 8,
+ * 16-bit in == out dtype, no fp32 accumulate; 3x3: Ws <= 95 (256 consecutive pixels + linear halo) or Hs, Ws multiples
+ * of 16 (16 x 16 pixel patches). The data gradient of such a convolution is a FWD call (d->mode = CDET_CONV_FWD,
  * source = dY with Cs = Cout, destination = dX with Cd = Cin) on the DGRAD operand written by the packer: autograd's
  * convolution_backward(input) for a stride-1 "same" convolution is the forward convolution with the taps flipped and
  * the channel roles swapped.
@@ -117,14 +118,14 @@ int cdet_conv2d_tiled_ok(const cdet_conv_desc* d);
 int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d);
 int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                       const void* residual, void* y, float* stats, void* stream);
-/* Tiled operand: [ceil(rows/160)][red/32][kh*kw][160][32] elements of the activation dtype, 16-byte slots XOR-swizzled
- * (the LDS image of one (row block, chunk, tap) tile is a linear 10 KiB copy). rows = O, red = I for the forward
- * operand; rows = I, red = O (padded to 32), taps flipped, for the DGRAD operand. Rows beyond `rows` and reduction
- * channels beyond `red` are never written: the caller zeroes the buffers once (cdet_tiled_weight_elems elements). */
+/* Tiled operand: [ceil(rows/RB)][ceil(red/32)][kh*kw][RB][32] elements of the activation dtype, RB = 160 (96 when
+ * rows <= 96), 16-byte slots XOR-swizzled (the LDS image of one (row block, chunk, tap) tile is a linear copy).
+ * rows = O, red = I for the forward operand; rows = I, red = O, taps flipped, for the DGRAD operand. Rows beyond `rows`
+ * are never written: the caller zeroes the buffers once (cdet_tiled_weight_elems elements). */
 int64_t cdet_tiled_weight_elems(int32_t rows, int32_t red, int32_t kh, int32_t kw);
 typedef struct {
     const float* w_oihw;
-    void* w_fwd;   /* forward operand or NULL (needs I % 32 == 0) */
+    void* w_fwd;   /* forward operand or NULL */
     void* w_dgrad; /* DGRAD operand or NULL */
     int32_t O, I, kh, kw;
     int32_t first_block, n_blocks; /* n_blocks = ceil(O/32) * ceil(I/32); first_block ascending, contiguous */

@@ -41,7 +41,15 @@ CASES = [
     (2, 16, 16, 320, 160, 1, torch.bfloat16),   # 1x1
     (1, 12, 12, 416, 320, 1, torch.float16),    # fp16, 13 chunks
     (1, 13, 21, 160, 200, 3, torch.float16),    # Cout not a multiple of 160 (second cout block mostly padding)
-    (1, 33, 95, 32, 32, 3, torch.bfloat16),     # widest supported map for 3x3 (7 X pieces per wave)
+    (1, 33, 95, 32, 32, 3, torch.bfloat16),     # widest supported LINEAR map for 3x3 (7 X pieces per wave); 96-row weight blocks
+    (1, 48, 64, 64, 160, 3, torch.bfloat16),    # PATCH mode (16 x 16 pixel tiles, halo 18 x 18): 12 patches
+    (2, 32, 80, 96, 80, 3, torch.bfloat16),     # patch mode + 3 cout fragments (80 channels in a 96-row block)
+    (1, 160, 160, 32, 96, 3, torch.float16),    # 160-wide map: patch mode only (linear halo would not fit), fp16
+    (1, 40, 40, 64, 80, 3, torch.bfloat16),     # linear mode + 3 cout fragments
+    (2, 16, 16, 96, 80, 1, torch.bfloat16),     # 1x1 + 3 cout fragments
+    (1, 32, 48, 80, 80, 3, torch.bfloat16),     # Cin = 80: last 32-channel chunk half empty (zero-filled lanes), patch mode
+    (2, 20, 20, 80, 80, 3, torch.bfloat16),     # Cin = 80, linear mode
+    (1, 16, 16, 400, 160, 1, torch.bfloat16),   # 1x1, Cin = 400 = 12.5 chunks
 ]
 
 
@@ -58,7 +66,7 @@ def test_tiled_conv_fwd_epilogue_stats(case):
     bias = torch.randn(Co, generator=g) * 0.1
     ref_raw = F.conv2d(x, w, None, 1, k // 2)
     res = _rt(torch.randn(N, Co, H, W, generator=g), dtype)
-    xb = torch.full((N, H, W, Ci + 16), 3.0, dtype=dtype, device=DEV)   # neighbours of the slice are NOT zero
+    xb = torch.full((N, H, W, Ci + 16), float("nan"), dtype=dtype, device=DEV)   # neighbours of the slice are NaN: never touched
     xb[..., 8:8 + Ci] = x.permute(0, 2, 3, 1).to(dtype).to(DEV)
     src = ops.View(xb, 8, Ci)
     wf, _ = ops.pack_weight_tiled(w.to(DEV), dtype)
@@ -84,7 +92,7 @@ def test_tiled_conv_fwd_epilogue_stats(case):
     assert (yb[..., :8].float() == 7.0).all() and (yb[..., 8 + Co:].float() == 7.0).all(), "conv wrote outside its channel slice"
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[4] % 32 == 0])
+@pytest.mark.parametrize("case", CASES)
 def test_tiled_conv_dgrad_is_forward_on_flipped_operand(case):
     ops = _ops()
     N, H, W, Ci, Co, k, dtype = case
