@@ -60,9 +60,14 @@ __device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, AUX);
 }
+#ifndef CDET_HALO_X_AUX
+#define CDET_HALO_X_AUX 0  // default cache policy. Measured: non-temporal (2) on the pixel stream is SLOWER (40x40 320->320: 0.103 -> 0.112 ms) -- a halo row
+                           // is fetched by both cout blocks of its tile and by the neighbouring tiles, and those re-reads want the L2 copy
+#endif
 
 // wave-uniform counted wait
 __device__ __forceinline__ void wait_vm(int n) {
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         // last partial chunk (Cs % 32 != 0, the 80-channel layers): the lanes whose 8-channel slot lies beyond Cs fetch zeros -- what
         // sits there in memory is a neighbouring channel slice (possibly never written), and 0-weight x NaN would still be NaN
         if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
-        dma16(rs, v, 0u, dst);
+        dma16<CDET_HALO_X_AUX>(rs, v, 0u, dst);
     };
 
     // ---- fragment read offsets -------------------------------------------------------------------------------------------------
@@ -321,6 +326,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     };
 
     CDET_HALO_STAMP(3);
+#ifdef CDET_PROFILING
+    unsigned long long t_lgkm = 0;
+    unsigned long long t_wait = 0, t_bar = 0;  // clocks wave 0 spends in the mid-step counted wait / in the barrier behind it
+#endif
     int bo_cur[2], bo_nxt[2];
     u32x4 a0[NF], b0[2], a1[NF], b1[2];
     b_offsets(HZERO, 0, bo_cur);
@@ -345,7 +354,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             if (!(ABL & 4)) mfma32<DT>(a0[i >> 1], b0[i & 1], acc[i >> 1][i & 1]);
-            if (i < NR) frag(ws, bo_cur, 1, i, a1, b1);
+            // two fragment reads per MFMA slot: they are all in flight after the first half of the phase, so the lgkmcnt(0) at its
+            // end waits for LDS latency that the second half has already covered (one read per slot left ~140 clocks per step exposed)
+            if (2 * i < NR) frag(ws, bo_cur, 1, 2 * i, a1, b1);
+            if (2 * i + 1 < NR) frag(ws, bo_cur, 1, 2 * i + 1, a1, b1);
             if (i == NM - 1) b_offsets(HZERO + xbn * XHB, tapn, bo_nxt);
             if (!(ABL & 1)) {
                 if (NT == 9) {
@@ -360,14 +372,32 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         }
         // tile st+1 (and, at a chunk boundary, the next chunk's pixels) have landed -- the weight pieces issued in the previous phase B
         // and this phase's pixel pieces may stay in flight; nobody reads tile st's stage any more
+#ifdef CDET_PROFILING
+        const unsigned long long twl = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        t_lgkm += tw0 - twl;
+#endif
         if (NT == 9) {
-            if (xa) wait_vm_lgkm0<(NSW - 2) * NWP + 1>();
+            // vmcnt retires in order: what must have landed is the weight tile of step st+1 (issued two phase-Bs ago); everything
+            // issued after it may stay in flight -- the newest weight tile and the pixel pieces of this and the previous phase A
+            // (pixel pieces are only issued at taps 0..6, so at tap 8, when phase B first reads the next chunk, none is left)
+            const bool xp = u >= 1 && u - 1 < MAXXP && u - 1 < nxpw;  // wave-uniform; xa implies xp for u >= 1
+            if (xa && xp) wait_vm_lgkm0<(NSW - 2) * NWP + 2>();
+            else if (xa || xp) wait_vm_lgkm0<(NSW - 2) * NWP + 1>();
             else wait_vm_lgkm0<(NSW - 2) * NWP>();
         } else {
             wait_vm_lgkm0<(NSW - 2) * NWP + 4>();
         }
+#ifdef CDET_PROFILING
+        const unsigned long long tw1 = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef CDET_PROFILING
+        t_wait += tw1 - tw0;
+        t_bar += __builtin_readcyclecounter() - tw1;
+#endif
         // ---- phase B: MFMAs of (st, k16 #1); DMA of the tile NSW steps ahead into the stage just freed and the fragment reads of
         //      (st+1, k16 #0) in their shadow
 #pragma unroll
@@ -378,7 +408,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 if (i == (NM >= 10 ? 3 : 2)) dma_w1(st + NSW, sc, 1);
                 if (i == (NM >= 10 ? 6 : 4)) dma_w1(st + NSW, sc, 2);
             }
-            if (i >= 1 && i <= NR) frag(wsn, bo_nxt, 0, i - 1, a0, b0);
+            if (i >= 1 && 2 * (i - 1) < NR) frag(wsn, bo_nxt, 0, 2 * (i - 1), a0, b0);
+            if (i >= 1 && 2 * (i - 1) + 1 < NR) frag(wsn, bo_nxt, 0, 2 * (i - 1) + 1, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
         }
         bo_cur[0] = bo_nxt[0];
@@ -399,6 +430,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         }
     }
     CDET_HALO_STAMP(4);
+#ifdef CDET_PROFILING
+    if (g_halo_dbg != nullptr && t == 0) {
+        g_halo_dbg[(size_t)blockIdx.x * 8 + 6] = t_wait;
+        g_halo_dbg[(size_t)blockIdx.x * 8 + 1] = t_lgkm;  // (overwrites the hw id: not needed by this experiment)
+        g_halo_dbg[(size_t)blockIdx.x * 8 + 7] = t_bar;
+    }
+#endif
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");  // asm MFMAs are opaque to the hazard recogniser; trailing (dead) DMA drained
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);

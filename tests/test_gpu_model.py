@@ -63,6 +63,30 @@ def test_eval_forward_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_eval_stream_lanes_bit_identical_to_single_stream(name, monkeypatch):
+    """The eval launch list runs on several HIP stream lanes (trunk / per-task chains / head side chains, engine._build_lanes);
+    the single-stream schedule of the same plan must give the same bits, also when forwards are issued back to back."""
+    arrays, meta = load_golden(name)
+    m = _build(meta).eval()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    with torch.no_grad():
+        for _ in range(3):  # back-to-back forwards reuse the plan's buffers: the lanes must re-join before the next one starts
+            out = m(x)
+        plan = m.get_plan(meta["tasks"], x.shape, x.dtype)
+        assert plan.sched is not None and len(plan.sched["lanes"]) >= 3
+        lanes = {t: (out[t][0].clone(), [f.clone() for f in out[t][1]]) for t in meta["tasks"]}
+        monkeypatch.setenv("CDET_EVAL_LANES", "0")
+        m._plans.clear()
+        ref = m(x)
+        assert m.get_plan(meta["tasks"], x.shape, x.dtype).sched is None
+    torch.cuda.synchronize()
+    for t in meta["tasks"]:
+        assert torch.equal(lanes[t][0], ref[t][0])
+        for a, b in zip(lanes[t][1], ref[t][1]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
 def test_eval_boxes_within_1e3_of_reference_at_fp32_accuracy(name):
     """BASELINE.json's tolerance -- boxes within 1e-3 relative of the reference -- at the reference's own precision: the eval forward
     evaluated through the HIP convolution kernels with split-bf16 operands and fp32 accumulation (tests/hiprec.py; the bf16-storage

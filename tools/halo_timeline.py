@@ -53,6 +53,9 @@ def main():
     st, lo, ep, en = (t[:, i] - t0 for i in (2, 3, 4, 5))
     print(f"shape {SHAPES[a.shape]}, {nblk} workgroups on {len(set(cu.tolist()))} distinct CUs; kernel span {en.max()} clocks (s_memtime)")
     print(f"per workgroup (clocks): prologue {np.median(lo - st):.0f}  K loop {np.median(ep - lo):.0f}  epilogue {np.median(en - ep):.0f}   (min/max loop {(ep - lo).min()}/{(ep - lo).max()})")
+    lp = (ep - lo).astype(np.float64)
+    print(f"inside the K loop (wave 0): counted vmcnt/lgkmcnt wait {np.median(t[:, 6] / lp):.3f} of the loop, barrier behind it {np.median(t[:, 7] / lp):.3f}"
+          f"  (absolute medians {np.median(t[:, 6]):.0f} / {np.median(t[:, 7]):.0f} clocks); lgkmcnt(0) alone {np.median(t[:, 1] / lp):.3f}")
     per = defaultdict(list)
     for i in range(nblk):
         per[int(cu[i])].append((int(st[i]), int(en[i])))
