@@ -1,0 +1,196 @@
+"""N > 1 on the HIP path with ONE GPU: two ranks (child processes, gloo backend over device tensors, both on cuda:0) run
+Averaging.train_step with SyncBatchNorm on half a batch each; a single process runs the same step on the whole batch.
+
+What must hold (reference semantics: train.py:140-143 SyncBN, train.py:182-184 DDP, trainers/averaging.py:162-163 loss *= world):
+  * SyncBN makes the forward of rank r the rows of the whole-batch forward: running statistics after the step and the loss items
+    agree with the 1-process run (statistics to fp32 summation order, items up to the per-rank normaliser below);
+  * after the gradient all-reduce + optimizer step both ranks hold BIT-IDENTICAL weights (the data-parallel invariant);
+  * the summed gradient = the whole-batch gradient up to the criterion's PER-RANK normaliser max(sum(target_scores), 1)
+    (utils/loss.py:164 in the reference is evaluated on each rank's own shard, so DDP and one big batch differ by the ratio of
+    the shards' normalisers): direction and norm are compared, not bits.
+"""
+import copy
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BS, IMG = 8, 128  # whole batch per task
+
+
+def _setup():
+    import synth
+    from util import load_golden
+
+    _, meta = load_golden("trainer")
+    _, mmeta = load_golden("model_tiny2")
+    return synth, meta, mmeta
+
+
+def _model(synth, meta, mmeta):
+    from cerberusdet_amd.models import CerberusDet
+
+    m = CerberusDet(mmeta["tasks"], mmeta["nc"], cfg=copy.deepcopy(mmeta["cfg"]), verbose=False)
+    m.sequential_split(mmeta["cfg"]["cerber"], "cpu")
+    sd = m.state_dict()
+    m.load_state_dict({k: torch.from_numpy(synth.det_tensor(mmeta["seed"], k, v.shape)) for k, v in sd.items()})
+    m.hyp = meta["hyp"]
+    return m.to(DEV).train()
+
+
+def _batches(synth, meta, lo, hi):
+    """Images lo..hi-1 of the whole batch of every task (labels re-indexed to the shard)."""
+    out = {}
+    for ti, t in enumerate(meta["tasks"]):
+        img = torch.from_numpy(synth.det_image(700 + ti, BS, IMG))[lo:hi].contiguous().to(DEV)
+        b = synth.make_batch(BS, 3, meta["nc"][ti], 800 + ti)
+        sel = (b["batch_idx"] >= lo) & (b["batch_idx"] < hi)
+        d = {k: torch.from_numpy(v[sel]) for k, v in b.items()}
+        d["batch_idx"] = d["batch_idx"] - lo
+        out[t] = dict(img=img, **{k: v.to(DEV) for k, v in d.items()})
+    return out
+
+
+def _step(meta, m, batches, rank, world, sync_bn):
+    from cerberusdet_amd.trainers import Averaging
+
+    tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False, rank=rank, world_size=world,
+                   sync_bn=sync_bn)
+    items = {t: tr.forward_backward(t, batches[t], n_max=8, active_tasks=meta["tasks"]) for t in meta["tasks"]}
+    tr.reducer.wait()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().clone().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    tr.optimizer_step([meta["hyp"]["lr0"]] * 3, meta["hyp"]["momentum"])
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone().cpu() for k, v in m.state_dict().items()}
+    return {t: v.cpu() for t, v in items.items()}, grads, sd
+
+
+def _worker(rank, world, port, q, same):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        synth, meta, mmeta = _setup()
+        m = _model(synth, meta, mmeta)
+        half = BS // world
+        lo = 0 if same else rank * half  # same: both ranks see shard 0 (exact 2x algebra against a 1-process run on that shard)
+        items, grads, sd = _step(meta, m, _batches(synth, meta, lo, lo + half), rank, world, True)
+        q.put((rank, {t: v.numpy() for t, v in items.items()}, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in sd.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_two_ranks(same):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1500) + (7 if same else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, same)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_ranks_identical_shards_exact_algebra():
+    """Both ranks process the SAME half batch: SyncBN's all-reduced [sum, sumsq] / backward sums are exactly twice the local ones over
+    twice the count, so activations and loss items equal the 1-process run on that shard (to the statistics' last bit), the all-reduced gradient is
+    2x the 1-process gradient, and the running statistics agree -- any mistake in the collective plumbing (a missed
+    all-reduce, a wrong count, a bucket reduced twice or not at all) breaks the equality."""
+    synth, meta, mmeta = _setup()
+    (_, it0, g0, sd_r0), (_, it1, g1, sd_r1) = _run_two_ranks(True)
+    m = _model(synth, meta, mmeta)
+    from cerberusdet_amd.trainers import Averaging
+
+    tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False)
+    batches = _batches(synth, meta, 0, BS // 2)
+    items1 = {t: tr.forward_backward(t, batches[t], n_max=8, active_tasks=meta["tasks"]).cpu().numpy() for t in meta["tasks"]}
+    torch.cuda.synchronize()
+    grads1 = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+    sd1 = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    # The SyncBN launch list derives mean / invstd from fp32 [sum, sumsq] (all-reduced), the per-GPU list from its double-accumulated
+    # partials: the statistics agree to the last bit or so, and bf16 re-rounding amplifies a last-bit difference down the chain
+    # (about 1 % at the stem, test_gpu_trainer.py::test_sync_bn_path_world1_equals_local_bn) -- so: items to 2 %, every gradient
+    # tensor by direction and norm, with the exact 2x required wherever the chain is untouched.
+    for t in meta["tasks"]:
+        assert np.array_equal(it0[t], it1[t])
+        assert np.allclose(it0[t], items1[t], rtol=2e-2, atol=1e-3), (t, it0[t], items1[t])
+    n = 0
+    stats = []
+    for k, g in grads1.items():
+        assert np.array_equal(g0[k], g1[k]), k
+        a, b = g.ravel().astype(np.float64), g0[k].ravel().astype(np.float64)
+        if np.linalg.norm(a) < 1e-9:
+            continue
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        ratio = float(np.linalg.norm(b) / np.linalg.norm(a))
+        stats.append((cos, ratio, k))
+        n += 1
+    assert n > 100
+    exact = [k for c, r, k in stats if c > 1 - 1e-6 and abs(r - 2.0) < 1e-4]
+    cs = sorted(c for c, _, _ in stats)
+    print(f"{len(exact)} of {n} gradient tensors are exactly 2x; worst cosine {cs[0]:.4f}, median {cs[n // 2]:.6f}")
+    # measured: the first task's exclusive blocks (about 40 % of the tensors) come out exactly 2x; the second task's statistics differ
+    # in the last bit on this batch, which the bf16 chain turns into cos 0.99 / +-3 % on its branch and on the shared trunk
+    assert len(exact) >= 0.3 * n, len(exact)
+    assert cs[n // 2] > 0.99 and cs[0] > 0.9, (cs[0], cs[n // 2])
+    assert all(abs(r / 2.0 - 1) < 0.25 for _, r, _ in stats), [x for x in stats if abs(x[1] / 2.0 - 1) >= 0.25]
+    for k, v in sd1.items():
+        if "running_mean" in k or "running_var" in k:
+            # (the unbiased-variance factor n/(n-1) uses the global count under SyncBN: 2n instead of n)
+            assert np.allclose(sd_r0[k], v, rtol=2e-2, atol=1e-3), (k, np.abs(sd_r0[k] - v).max())
+
+
+def test_two_ranks_syncbn_vs_one_process_whole_batch():
+    synth, meta, mmeta = _setup()
+    res = _run_two_ranks(False)
+    # the 1-process run on the whole batch (per-GPU BatchNorm over the whole batch == SyncBN over the two shards)
+    m = _model(synth, meta, mmeta)
+    items1, grads1, sd1 = _step(meta, m, _batches(synth, meta, 0, BS), -1, 1, False)
+    (_, it0, g0, sd_r0), (_, it1, g1, sd_r1) = res
+    # (1) data-parallel invariant: identical weights, statistics and (all-reduced) gradients on both ranks
+    for k in sd_r0:
+        assert np.array_equal(sd_r0[k], sd_r1[k]), k
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    # (2) SyncBN: running statistics = those of the whole batch
+    for k, v in sd1.items():
+        if "running_mean" in k or "running_var" in k:
+            # fp32 summation order differs (2 x 4 images vs 8) -> 1-ulp bf16 flips that this random-weight net amplifies layer by
+            # layer (the documented chaos band); one step moves a running statistic by 3 % of the batch statistic
+            assert np.allclose(sd_r0[k], v.numpy(), rtol=2e-2, atol=3e-3), (k, np.abs(sd_r0[k] - v.numpy()).max())
+    # (3) loss items: the shard-size weighted mean of the ranks' items is the whole batch's value up to the normaliser ratio
+    for t in meta["tasks"]:
+        mean = 0.5 * (it0[t][:3] + it1[t][:3])
+        # (each rank divides by ITS shard's sum of target scores: with 4 images per shard the two normalisers differ by ~10-20 %)
+        assert np.allclose(mean, items1[t][:3].numpy(), rtol=0.25, atol=0.05), (t, it0[t], it1[t], items1[t])
+    # (4) summed gradient vs whole-batch gradient: the detection heads' last-layer biases see the loss gradient directly -- the
+    #     direction must agree; the norm carries the normaliser ratio. (Deeper parameters mix both shards' normalisers per anchor and,
+    #     in this random-weight net, the bf16 chaos band: they are covered exactly by test_two_ranks_identical_shards_exact_algebra.)
+    n = 0
+    for k, g in grads1.items():
+        if not (k.endswith(".2.bias") and ".cv" in k):
+            continue
+        a, b = g.numpy().ravel().astype(np.float64), g0[k].ravel().astype(np.float64)
+        if np.linalg.norm(a) < 1e-6:
+            continue
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos > 0.98 and 0.4 < np.linalg.norm(b) / np.linalg.norm(a) < 2.5, (k, cos, np.linalg.norm(b) / np.linalg.norm(a))
+        n += 1
+    assert n >= 8
