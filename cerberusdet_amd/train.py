@@ -44,15 +44,15 @@ def parse_opt(known=False):
     p.add_argument("--imgsz", "--img", "--img-size", type=int, default=640)
     p.add_argument("--resume", nargs="?", const=True, default=False)
     p.add_argument("--nosave", action="store_true")
-    p.add_argument("--noval", action="store_true")
+    p.add_argument("--noval", action="store_true", help="accepted for CLI compatibility: this entry point never runs validation (use cerberusdet_amd.val)")
     p.add_argument("--device", default="")
     p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm: per-layer statistics all-reduced over the ranks")
-    p.add_argument("--workers", type=int, default=8)
+    p.add_argument("--workers", type=int, default=8, help="accepted for CLI compatibility: batches come from the caller's iterables / the synthetic generator")
     p.add_argument("--project", default="runs/train")
     p.add_argument("--name", default="exp")
     p.add_argument("--exist-ok", action="store_true")
     p.add_argument("--linear-lr", action="store_true")
-    p.add_argument("--patience", type=int, default=30)
+    p.add_argument("--patience", type=int, default=30, help="accepted for CLI compatibility: early stopping needs the validation loop, which this entry point does not run")
     p.add_argument("--local_rank", "--local-rank", type=int, default=-1)
     p.add_argument("--single-cls", action="store_true")
     p.add_argument("--freeze-shared-till-epoch", type=int, default=0)
@@ -117,8 +117,29 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
     trainer = Averaging(device, model, hyp, tasks, epochs=max(opt.epochs, 2), nb=nb, linear_lr=opt.linear_lr, rank=RANK, world_size=WORLD_SIZE,
                         sync_bn=opt.sync_bn and WORLD_SIZE > 1)
     iters = {t: iter(d) for t, d in train_dataset.items()}
-    results = {}
-    for epoch in range(opt.epochs):
+    # --skip-batches (reference trainers/averaging.py:50-54,144-146): a task with a shorter dataset is visited every
+    # max_len // len iterations only; the optimizer step then divides by the number of tasks that really ran
+    iters_per_task = [1] * len(tasks)
+    if opt.skip_batches:
+        lens = [len(d) if hasattr(d, "__len__") else nb for d in train_dataset.values()]
+        iters_per_task = [max(max(lens) // max(n, 1), 1) for n in lens]
+        if RANK in (-1, 0):
+            print(f"viewing tasks iteration frequency: {iters_per_task}")
+    out_dir = Path(opt.project) / opt.name
+    start_epoch = 0
+    if opt.resume:  # reference train.py:359-372 + utils/models_manager.py:296-308: weights, optimizer, EMA, epoch
+        ck_path = Path(opt.resume) if isinstance(opt.resume, str) else out_dir / "last.pt"
+        ck = torch.load(str(ck_path), map_location="cpu", weights_only=False)
+        if "trainer" not in ck:
+            raise ValueError(f"{ck_path} holds weights only: it cannot resume a run (use --weights)")
+        model.load_state_dict(ck["model_state_dict"])
+        model.mark_weights_changed()
+        trainer.load_state_dict(ck["trainer"])
+        start_epoch = trainer.epoch + 1
+        if RANK in (-1, 0):
+            print(f"resuming {ck_path} at epoch {start_epoch} (iteration {trainer.steps})")
+    results, items = {}, {}
+    for epoch in range(start_epoch, opt.epochs):
         trainer.epoch = epoch
         if epoch < opt.freeze_shared_till_epoch:  # reference trainers/averaging.py:100-103
             trainer.set_shared_frozen(True)
@@ -127,26 +148,38 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         t0 = time.time()
         for i in range(nb):
             batches = {}
-            for t in tasks:
+            for ti, t in enumerate(tasks):
+                if i % iters_per_task[ti] != 0:
+                    continue
                 try:
                     batches[t] = next(iters[t])
                 except StopIteration:
                     iters[t] = iter(train_dataset[t])
                     batches[t] = next(iters[t])
                 batches[t] = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batches[t].items()}
-            items = trainer.train_step(batches, ni=i + nb * epoch)
+            items.update(trainer.train_step(batches, ni=i + nb * epoch))
         torch.cuda.synchronize()
-        results = {t: [float(v) for v in items[t].tolist()] for t in tasks}
+        results = {t: [float(v) for v in items[t].tolist()] for t in tasks if t in items}
         if RANK in (-1, 0):
             ips = nb * sum(bs) * WORLD_SIZE / (time.time() - t0)
             print(f"epoch {epoch}: " + "  ".join(f"{t}: box {r[0]:.4f} cls {r[1]:.4f} dfl {r[2]:.4f}" for t, r in results.items()) + f"  [{ips:.1f} img/s]")
-    if RANK in (-1, 0) and not opt.nosave:
-        from cerberusdet_amd.cerberusdet_inference import save_checkpoint
-
-        out = Path(opt.project) / opt.name
-        out.mkdir(parents=True, exist_ok=True)
-        save_checkpoint(out / "last.pt", trainer.ema.ema if trainer.ema else model, getattr(model, "names", None))
+        if RANK in (-1, 0) and not opt.nosave:
+            save_training_checkpoint(out_dir / "last.pt", model, trainer)
     return results, opt.epochs - 1
+
+
+def save_training_checkpoint(path, model, trainer):
+    """last.pt: the inference checkpoint of cerberusdet_inference.save_checkpoint (EMA weights when there is an EMA, like the
+    reference's models_manager.py:262-290) plus what --resume needs: the raw model weights and the trainer state."""
+    from cerberusdet_amd.cerberusdet_inference import save_checkpoint
+
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    save_checkpoint(path, trainer.ema.ema if trainer.ema else model, getattr(model, "names", None))
+    ck = torch.load(str(path), map_location="cpu", weights_only=False)
+    ck["model_state_dict"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ck["trainer"] = trainer.state_dict()
+    torch.save(ck, str(path))
 
 
 def main(opt):

@@ -238,9 +238,13 @@ class Averaging:
         self.reducer.skip_blocks = {i for i, b in enumerate(self.model.blocks)
                                     if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters())}
 
-    def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None):
+    def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None, idle_blocks=()):
+        """idle_blocks: blocks none of whose serving tasks ran this iteration (--skip-batches). The reference's zero_grad() leaves
+        their gradients None (torch >= 2.0 default set_to_none), so torch's SGD skips them entirely -- no weight decay, no momentum
+        coasting, no momentum-buffer initialisation; here their slots become EMA-only for this step and are not marked stepped."""
         self.reducer.wait()
-        live = [m["g"] is not None and m["p"].requires_grad for m in self.slots_meta]
+        idle = set(idle_blocks)
+        live = [m["g"] is not None and m["p"].requires_grad and int(m["key"].split(".")[1]) not in idle for m in self.slots_meta]
         fresh = sum(1 for m, a in zip(self.slots_meta, live) if a and not m.get("stepped", True))
         key = (tuple(lrs), fresh, tuple(sorted(n_serving.items())) if n_serving else None, hash(tuple(live)))
         if key != self._slot_key:
@@ -285,8 +289,33 @@ class Averaging:
         else:
             for t in active:
                 out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
-        n_serving = None
+        n_serving, idle = None, ()
         if len(active) != len(self.task_ids):
             n_serving = {i: max(len([t for t in ts if t in active]), 1) for i, ts in self.serving.items()}
-        self.optimizer_step(lrs, mom, n_serving)
+            idle = [i for i, ts in self.serving.items() if ts and not any(t in active for t in ts)]
+        self.optimizer_step(lrs, mom, n_serving, idle)
         return out
+
+    # ---------------------------------------------------------------------------------------------------- resume
+    def state_dict(self):
+        """Everything `--resume` needs besides the model weights (reference utils/models_manager.py:262-308 saves optimizer, EMA +
+        updates, epoch, best fitness): momentum buffers and their first-step flags per parameter, EMA weights and update count,
+        iteration counters."""
+        return dict(format="cerberusdet_amd/trainer/1", epoch=self.epoch, steps=self.steps,
+                    momentum={m["key"]: m["mom"].detach().cpu() for m in self.slots_meta if m.get("mom") is not None},
+                    stepped={m["key"]: bool(m.get("stepped", True)) for m in self.slots_meta if m.get("mom") is not None},
+                    ema=({k: v.detach().cpu() for k, v in self.ema.ema.state_dict().items()} if self.ema else None),
+                    ema_updates=(self.ema.updates if self.ema else 0))
+
+    def load_state_dict(self, sd):
+        assert sd.get("format") == "cerberusdet_amd/trainer/1", "not a cerberusdet_amd trainer state"
+        self.epoch, self.steps = int(sd["epoch"]), int(sd["steps"])
+        with torch.no_grad():
+            for m in self.slots_meta:
+                if m.get("mom") is not None and m["key"] in sd["momentum"]:
+                    m["mom"].copy_(sd["momentum"][m["key"]])
+                    m["stepped"] = bool(sd["stepped"][m["key"]])
+            if self.ema and sd.get("ema") is not None:
+                self.ema.ema.load_state_dict(sd["ema"])
+                self.ema.updates = int(sd["ema_updates"])
+        self._slot_key = None
