@@ -46,6 +46,10 @@ class PackTiledItem(C.Structure):
                 ("first_block", i32), ("n_blocks", i32)]
 
 
+class LetterboxItem(C.Structure):
+    _fields_ = [("img", vp), ("h", i32), ("w", i32), ("pitch", i32), ("new_w", i32), ("new_h", i32), ("top", i32), ("left", i32)]
+
+
 class MergeDesc(C.Structure):
     _fields_ = [("N", i32), ("T", i32), ("max_det", i32), ("iou_thres", f32), ("rows", vp * 8), ("counts", vp * 8), ("cls_offset", i32 * 8)]
 
@@ -80,6 +84,7 @@ _SIGS = {
     "cdet_image_to_nhwc8": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_stem_conv_stat_blocks": (i32, [i32, i32, i32]),
     "cdet_stem_conv_wgrad": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "cdet_letterbox_batch": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_bn_finalize": (i32, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),
     "cdet_bn_silu_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, i32, vp]),
     "cdet_bn_bwd_blocks": (i32, [i64]),

@@ -160,6 +160,21 @@ int cdet_stem_conv_wgrad(const void* img_nchw, int32_t img_dtype, const void* dy
                          int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Inference pre-processing (cerberusdet_preprocessor.py:42-74, data/augmentations.py:59-89): letterbox of a list of
+ * uint8 BGR HWC images into ONE [B,3,H,W] RGB tensor scaled by 1/255 (out_dtype F32 / F16 / BF16) or kept as U8.
+ * Per image the host passes the source (device pointer, h, w, row pitch in bytes) and the letterbox geometry computed
+ * exactly like augmentations.py:65-86: the resized size (new_w, new_h) and the top / left border; everything outside
+ * the resized image is pad_value (114). Resize arithmetic: OpenCV's 8-bit INTER_LINEAR. `items` is a DEVICE array.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* img;
+    int32_t h, w, pitch;
+    int32_t new_w, new_h, top, left;
+} cdet_letterbox_item;
+int cdet_letterbox_batch(const cdet_letterbox_item* items, int32_t B, void* out_nchw, int32_t H, int32_t W, int32_t out_dtype,
+                         int32_t pad_value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Train-mode BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU around the conv (common.py:61, torch_utils.py:184-186)
  * ---------------------------------------------------------------------------------------------- */
 /* Reduce the conv kernel's partial sums -> mean, invstd (biased var), update running stats (unbiased var). */

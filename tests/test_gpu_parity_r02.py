@@ -188,3 +188,29 @@ def test_nms_more_than_4096_candidates_per_image_bit_exact(settings):
     assert cnt.tolist() == [w_.shape[0] for w_ in want], (cnt.tolist(), [w_.shape[0] for w_ in want])
     for i, w_ in enumerate(want):
         assert np.array_equal(rows[i, :cnt[i]].cpu().numpy(), w_), (settings, i)
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_gpu_letterbox_preprocess_bit_exact_vs_oracle(half):
+    """cdet_letterbox_batch (csrc/preprocess.hip) through the reference-shaped CerberusPreprocessor.preprocess: a batch of differently
+    sized BGR images (shrink, enlarge, exact 2x shrink, no resize, portrait) -> [B,3,640,640]; every value must equal the oracle's
+    (OpenCV 8-bit bilinear restated, oracle/preprocess.py) exactly -- integer pixel arithmetic, one division by 255."""
+    from cerberusdet_amd.cerberusdet_preprocessor import CerberusPreprocessor
+    from oracle import preprocess as op
+
+    rng = np.random.default_rng(3)
+    shapes = [(720, 1280), (480, 640), (1280, 1280), (640, 640), (333, 777), (1281, 641), (64, 48), (1080, 1920)]
+    images = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    pre = CerberusPreprocessor(img_size=640, stride=32, half=half, auto=False)
+    got = pre.preprocess(images, torch.device(DEV))
+    torch.cuda.synchronize()
+    want = op.preprocess(images, 640, 32, half=half, auto=False)
+    assert got.shape == want.shape and got.dtype == (torch.float16 if half else torch.float32)
+    g = got.cpu().numpy()
+    for i in range(len(images)):
+        assert np.array_equal(g[i], want[i]), (shapes[i], float(np.abs(g[i].astype(np.float32) - want[i].astype(np.float32)).max()))
+    # auto=True (minimum rectangle): same-shape images give a non-square batch
+    pre2 = CerberusPreprocessor(img_size=640, stride=32, half=half, auto=True)
+    a = pre2.preprocess(images[:1] * 2, torch.device(DEV))
+    w2 = op.preprocess(images[:1] * 2, 640, 32, half=half, auto=True)
+    assert tuple(a.shape) == w2.shape == (2, 3, 384, 640) and np.array_equal(a.cpu().numpy(), w2)
