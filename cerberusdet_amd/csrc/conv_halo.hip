@@ -47,7 +47,7 @@ struct HaloArgs {
     unsigned x_bytes, w_bytes;
 };
 
-constexpr int HP = 256;             // pixels per block
+constexpr int HP = 256;             // pixels per block (128 in the half-tile form, template parameter NG = 1)
 constexpr int HROW = 64;            // bytes per LDS row (32 channels)
 constexpr int HZERO = 256;          // LDS bytes reserved in front (zero row)
 constexpr int MAXXP = 7;            // X DMA pieces (16 rows each) per wave per chunk: XH <= 448
@@ -131,15 +131,19 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // of 256 consecutive pixels (halo 256 + 2W + 2 rows) -- half the halo on the 80-wide maps, and the only form that fits for 160-wide.
 // ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no epilogue
 // stores, 16 = no K loop
-template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int ABL = 0>
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
+    constexpr int HPB = 128 * NG;         // pixels per block: a wave owns NG 32-pixel fragments (NG = 1: half tiles for layers whose
+                                          // 256-pixel tiles would leave most CUs idle, e.g. the 20 x 20 maps at batch 32)
+    static_assert(NG == 2 || !PATCH, "the 16 x 16 patch form is a 256-pixel tile");
     constexpr int HC = NF * 32;           // couts per block
     constexpr int WTILE = HC * HROW;      // bytes per (cblk, chunk, tap) weight tile: 10240 / 6144
     constexpr int WQ = WTILE / 4;         // bytes of the tile each wave copies: 2 (1) full 1-KiB pieces + one half piece (lanes 0-31)
     constexpr int NWP = (WQ + 1023) / 1024;  // DMA instructions per wave per tile: 3 / 2 -- the same for every wave
-    constexpr int NM = 2 * NF;            // MFMAs per phase (one k16 half of a step)
-    constexpr int NR = NF + 2;            // fragment reads per phase
-    static_assert(NM >= NR + 1, "phase B needs a slot for the weight DMA in front of the fragment reads");
+    constexpr int NXP1 = 2 * NG;          // 1x1: pixel DMA pieces per wave per chunk (HPB rows / 16 / 4 waves)
+    constexpr int NM = NG * NF;           // MFMAs per phase (one k16 half of a step)
+    constexpr int NR = NF + NG;           // fragment reads per phase (two per MFMA slot)
+    static_assert(NM >= (NR + 1) / 2 + 1, "phase B needs a slot for the weight DMA in front of the fragment reads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     // patch: tile (n, ty, tx) = 16 x 16 pixels at (ty*16, tx*16); halo row of pixel (iy, ix) = (iy+1)*18 + ix+1, tap pitch 18.
     const int tpitch = NT == 9 ? (PATCH ? PATCH_HPW : W) : 0;
     const int halo0 = NT == 9 ? tpitch + 1 : 0;
-    const int p0 = pblk * HP;  // linear mode
+    const int p0 = pblk * HPB;  // linear mode
     int pn = 0, py0 = 0, px0 = 0;  // patch mode: image, top-left pixel
     if (PATCH) {
         pn = pblk / a.tiles_per_img;
@@ -234,11 +238,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     // A (weights): row f*32 + l31 of the stage, k-slot 2*s + h
     const int aoff0 = l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
     // B (pixels): tile pixel wave*64 + g*32 + l31: its output pixel index, the halo row of its centre, validity bit per tap
-    int pixh[2], pout[2];
-    unsigned vmask[2];
+    int pixh[NG], pout[NG];
+    unsigned vmask[NG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int i = wave * 64 + g * 32 + l31;
+    for (int g = 0; g < NG; ++g) {
+        const int i = wave * (32 * NG) + g * 32 + l31;
         unsigned m = 0u;
         if (PATCH) {
             const int iy = i / PATCH_W, ix = i % PATCH_W;
@@ -270,11 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         vmask[g] = m;
     }
 
-    f32x16 acc[NF][2];
+    f32x16 acc[NF][NG];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
 
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     for (int j = 0; j < NWP; ++j) dma_w1(0, 0, j);
     if (NT == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma_x(i, 1, 1);
+        for (int i = 0; i < NXP1; ++i) dma_x(i, 1, 1);
     }
 #pragma unroll
     for (int j = 0; j < NWP; ++j) dma_w1(1, 1, j);
@@ -294,19 +298,24 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
         for (int j = 0; j < NWP; ++j) dma_w1(2, 2, j);
     }
-    wait_vm((NT == 1 ? 4 : 0) + (NSW - 1) * NWP);  // tile 0 and chunk 0 have landed
+    wait_vm((NT == 1 ? NXP1 : 0) + (NSW - 1) * NWP);  // tile 0 and chunk 0 have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     // B-fragment byte offsets (relative to smem) of a K step: halo row of each of the lane's two pixels for the step's tap
-    auto b_offsets = [&](int xoff, int tap_, int (&bo)[2]) {
+    auto b_offsets = [&](int xoff, int tap_, int (&bo)[NG]) {
         const int dy_ = tap_ / 3 - 1, dx_ = tap_ % 3 - 1;
         // opaque copies: without them the compiler hoists the nine per-tap offset pairs (and their scalar parts) out of the chunk
         // loop as loop invariants -- 18 VGPRs + ~30 SGPRs the 256-register budget does not have (spills); recomputing costs 8 VALU
-        int tp = tpitch, p_[2] = {pixh[0], pixh[1]};
-        asm volatile("" : "+s"(tp), "+v"(p_[0]), "+v"(p_[1]));
+        int tp = tpitch, p_[NG];
+        asm volatile("" : "+s"(tp));
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < NG; ++g) {
+            p_[g] = pixh[g];
+            asm volatile("" : "+v"(p_[g]));
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
             const int hrow = p_[g] + (NT == 9 ? dy_ * tp + dx_ : 0);
             const int off = hrow * HROW + ((h ^ ((hrow >> 2) & 3)) << 4);
             const bool ok = (vmask[g] >> tap_) & 1u;
@@ -314,14 +323,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         }
     };
     // fragment i of a k16 half: i < 2 -> pixel rows (B operand), else weight rows (A operand); read order = use order
-    auto frag = [&](const unsigned char* ws_, const int (&bo)[2], int s_, int i, u32x4 (&af)[NF], u32x4 (&bf)[2]) {
+    auto frag = [&](const unsigned char* ws_, const int (&bo)[NG], int s_, int i, u32x4 (&af)[NF], u32x4 (&bf)[NG]) {
         if (ABL & 2) {
-            if (i < 2) bf[i] = u32x4{(unsigned)lane, 1u, 2u, 3u};
-            else af[i - 2] = u32x4{(unsigned)lane, 1u, 2u, 3u};
-        } else if (i < 2) {
+            if (i < NG) bf[i] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+            else af[i - NG] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+        } else if (i < NG) {
             bf[i] = *reinterpret_cast<const u32x4*>(smem + (bo[i] ^ (s_ << 5)));
         } else {
-            af[i - 2] = *reinterpret_cast<const u32x4*>(ws_ + ((aoff0 ^ (s_ << 5)) + (i - 2) * 32 * HROW));
+            af[i - NG] = *reinterpret_cast<const u32x4*>(ws_ + ((aoff0 ^ (s_ << 5)) + (i - NG) * 32 * HROW));
         }
     };
 
@@ -330,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     unsigned long long t_lgkm = 0;
     unsigned long long t_wait = 0, t_bar = 0;  // clocks wave 0 spends in the mid-step counted wait / in the barrier behind it
 #endif
-    int bo_cur[2], bo_nxt[2];
-    u32x4 a0[NF], b0[2], a1[NF], b1[2];
+    int bo_cur[NG], bo_nxt[NG];
+    u32x4 a0[NF], b0[NG], a1[NF], b1[NG];
     b_offsets(HZERO, 0, bo_cur);
 #pragma unroll
     for (int i = 0; i < NR; ++i) frag(wbase, bo_cur, 0, i, a0, b0);
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         //      pieces of the next chunk (3x3: one per step; 1x1: the whole chunk st+2 into the third buffer) in their shadow
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (!(ABL & 4)) mfma32<DT>(a0[i >> 1], b0[i & 1], acc[i >> 1][i & 1]);
+            if (!(ABL & 4)) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
             // two fragment reads per MFMA slot: they are all in flight after the first half of the phase, so the lgkmcnt(0) at its
             // end waits for LDS latency that the second half has already covered (one read per slot left ~140 clocks per step exposed)
             if (2 * i < NR) frag(ws, bo_cur, 1, 2 * i, a1, b1);
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                     if (i == NM - 2 && u < MAXXP) {
                         if (xa) dma_x(u, chunk + 1, (chunk + 1) & 1);
                     }
-                } else if (i < 4) {
+                } else if (i < NXP1) {
                     dma_x(i, chunk + 2, (u + 2) % 3);
                 }
             }
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             else if (xa || xp) wait_vm_lgkm0<(NSW - 2) * NWP + 1>();
             else wait_vm_lgkm0<(NSW - 2) * NWP>();
         } else {
-            wait_vm_lgkm0<(NSW - 2) * NWP + 4>();
+            wait_vm_lgkm0<(NSW - 2) * NWP + NXP1>();
         }
 #ifdef CDET_PROFILING
         const unsigned long long tw1 = __builtin_readcyclecounter();
@@ -402,18 +411,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         //      (st+1, k16 #0) in their shadow
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (!(ABL & 4)) mfma32<DT>(a1[i >> 1], b1[i & 1], acc[i >> 1][i & 1]);
+            if (!(ABL & 4)) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
             if (!(ABL & 1)) {
                 if (i == 0) dma_w1(st + NSW, sc, 0);
-                if (i == (NM >= 10 ? 3 : 2)) dma_w1(st + NSW, sc, 1);
-                if (i == (NM >= 10 ? 6 : 4)) dma_w1(st + NSW, sc, 2);
+                if (i == (NM >= 10 ? 3 : (NM >= 6 ? 2 : 1))) dma_w1(st + NSW, sc, 1);
+                if (i == (NM >= 10 ? 6 : (NM >= 6 ? 4 : 2))) dma_w1(st + NSW, sc, 2);
             }
             if (i >= 1 && 2 * (i - 1) < NR) frag(wsn, bo_nxt, 0, 2 * (i - 1), a0, b0);
             if (i >= 1 && 2 * (i - 1) + 1 < NR) frag(wsn, bo_nxt, 0, 2 * (i - 1) + 1, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        bo_cur[0] = bo_nxt[0];
-        bo_cur[1] = bo_nxt[1];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) bo_cur[g] = bo_nxt[g];
     };
 
     if (ABL & 16) {
@@ -448,9 +457,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         for (int f = 0; f < NF; ++f) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v0 = acc[f][0][r], v1 = acc[f][1][r];
-                const float sv = half_sum32(v0 + v1);
-                const float qv = half_sum32(v0 * v0 + v1 * v1);
+                float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float v0 = acc[f][g][r];
+                    s_ += v0;
+                    q_ += v0 * v0;
+                }
+                const float sv = half_sum32(s_);
+                const float qv = half_sum32(q_);
                 if (l31 == 0) {
                     const int cl = f * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                     stl[(wave * 2 + 0) * HC + cl] = sv;
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         __syncthreads();
     }
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
         const int p = pout[g];
         const bool pok = p < a.M;
         const int64_t ob = (int64_t)p * a.dst_ld + a.dst_coff;
@@ -629,7 +644,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
 // launch geometry of a supported convolution
 struct HaloPlan {
     bool ok, patch;
-    int nf, XH, nsw, nxb;
+    int nf, ng, hp, XH, nsw, nxb;
     size_t lds;
 };
 
@@ -643,36 +658,47 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16) || d->out_dtype != d->dtype || d->accumulate) return pl;
     const int rb = row_block(d->Cd);
     pl.nf = rb / 32;
+    const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
+    // half tiles (128 pixels, one 32-pixel fragment per wave) when 256-pixel tiles would not even give every CU one workgroup
+    pl.ng = (div_up(M, HP) * div_up(d->Cd, rb) < 256 && M > 128) ? 1 : 2;
+    if (const char* e = getenv("CDET_HALO_NG")) {  // CDET_HALO_NG=1|2 pins the tile size (tests cover both forms on the same shapes; A/B timing)
+        const int force = atoi(e);
+        if (force == 1 || force == 2) pl.ng = force;
+    }
+    pl.hp = 128 * pl.ng;
     if (d->kh == 1) {
         pl.patch = false;
-        pl.XH = HP;
+        pl.XH = pl.hp;
     } else {
-        const int lin = (HP + 2 * (d->Ws + 1) + 15) / 16 * 16;
+        const int lin = (pl.hp + 2 * (d->Ws + 1) + 15) / 16 * 16;
         const int pat = (PATCH_HPW * PATCH_HPW + 15) / 16 * 16;  // 336
-        pl.patch = d->Hs % PATCH_W == 0 && d->Ws % PATCH_W == 0 && pat < lin;
-        pl.XH = pl.patch ? pat : lin;
+        pl.patch = d->Hs % PATCH_W == 0 && d->Ws % PATCH_W == 0 && pat < (HP + 2 * (d->Ws + 1) + 15) / 16 * 16;
+        if (pl.patch) {  // 16 x 16 patches are 256-pixel tiles
+            pl.ng = 2;
+            pl.hp = HP;
+        }
+        pl.XH = pl.patch ? pat : (pl.ng == 2 ? (HP + 2 * (d->Ws + 1) + 15) / 16 * 16 : lin);
         if (pl.XH > 16 * 4 * MAXXP) return pl;
     }
-    const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
     if (M >= (1ll << 31) - HP) return pl;
     if (M * d->src_ld * 2 >= 0xC0000000ll) return pl;
     const int64_t wb = (int64_t)div_up(d->Cd, rb) * div_up(d->Cs, 32) * d->kh * d->kw * rb * HROW;
     if (wb >= 0xC0000000ll) return pl;
     pl.nxb = d->kh == 1 ? 3 : 2;
-    // ring depth: three stages when two workgroups still fit a CU (80 KiB each); the patch and 1x1 forms always do
+    // ring depth: three stages when two workgroups still fit a CU (80 KiB each); the patch, 1x1 and half-tile forms always do
     const size_t base = (size_t)HZERO + (size_t)pl.nxb * pl.XH * HROW;
     pl.nsw = base + 3 * (size_t)rb * HROW <= 80 * 1024 ? 3 : 2;
-    if ((pl.patch || d->kh == 1) && pl.nsw != 3) return pl;
+    if ((pl.patch || d->kh == 1 || pl.ng == 1) && pl.nsw != 3) return pl;
     pl.lds = base + (size_t)pl.nsw * rb * HROW;
     pl.ok = true;
     return pl;
 }
 
-template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH>
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG>
 static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
 #ifdef CDET_PROFILING
@@ -681,10 +707,10 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
         if (!once) {
             once = true;
             int nb = -1;
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>, 256, lds);
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG>, 256, lds);
             hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, (const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>);
-            fprintf(stderr, "[cdet] conv_halo_kernel<%d,%d,%d,%d,%d,%d>: lds %zu B, occupancy API %d blocks/CU (%s), regs %d\n", DT, NT, NF, EPI, NSW, (int)PATCH, lds, nb,
+            (void)hipFuncGetAttributes(&fa, (const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG>);
+            fprintf(stderr, "[cdet] conv_halo_kernel<%d,%d,%d,%d,%d,%d,%d>: lds %zu B, occupancy API %d blocks/CU (%s), regs %d\n", DT, NT, NF, EPI, NSW, (int)PATCH, NG, lds, nb,
                     hipGetErrorString(e), fa.numRegs);
         }
     }
@@ -694,11 +720,11 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
         abl = e ? atoi(e) : 0;
         if (abl) fprintf(stderr, "[cdet] CDET_HALO_ABLATE=%d: conv results are WRONG by design (timing experiment)\n", abl);
     }
-    if constexpr (DT == CDET_BF16 && NT == 9 && NF == 5 && EPI == HEPI_FULL && NSW == 3 && !PATCH) {
+    if constexpr (DT == CDET_BF16 && NT == 9 && NF == 5 && EPI == HEPI_FULL && NSW == 3 && !PATCH && NG == 2) {
 #define CDET_HABL(N)                                                                                                                                      \
     case N:                                                                                                                                                \
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, N>), dim3(nblocks), dim3(256), lds, s, a);                                       \
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG, N>), dim3(nblocks), dim3(256), lds, s, a);                                       \
         return;
         switch (abl) {
             CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(7) CDET_HABL(8) CDET_HABL(15)
@@ -707,15 +733,18 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
 #undef CDET_HABL
     }
 #endif
-    hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH>), dim3(nblocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG>), dim3(nblocks), dim3(256), lds, s, a);
 }
 
 template <int DT, int NF, int EPI>
 static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nblocks, hipStream_t s) {
-    if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false>(a, pl.lds, nblocks, s);
-    else if (pl.patch) launch_halo<DT, 9, NF, EPI, 3, true>(a, pl.lds, nblocks, s);
-    else if (pl.nsw == 3) launch_halo<DT, 9, NF, EPI, 3, false>(a, pl.lds, nblocks, s);
-    else launch_halo<DT, 9, NF, EPI, 2, false>(a, pl.lds, nblocks, s);
+    if (pl.ng == 1) {
+        if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
+        else launch_halo<DT, 9, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
+    } else if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 2>(a, pl.lds, nblocks, s);
+    else if (pl.patch) launch_halo<DT, 9, NF, EPI, 3, true, 2>(a, pl.lds, nblocks, s);
+    else if (pl.nsw == 3) launch_halo<DT, 9, NF, EPI, 3, false, 2>(a, pl.lds, nblocks, s);
+    else launch_halo<DT, 9, NF, EPI, 2, false, 2>(a, pl.lds, nblocks, s);
 }
 
 template <int DT>
@@ -743,7 +772,10 @@ extern "C" int cdet_debug_halo_timeline(void* buf) {
 
 extern "C" int cdet_conv2d_tiled_ok(const cdet_conv_desc* d) { return d && halo_plan(d).ok ? 1 : 0; }
 
-extern "C" int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d) { return div_up((int64_t)d->N * d->Hd * d->Wd, HP); }
+extern "C" int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d) {
+    const HaloPlan pl = halo_plan(d);
+    return div_up((int64_t)d->N * d->Hd * d->Wd, pl.ok ? pl.hp : HP);
+}
 
 extern "C" int64_t cdet_tiled_weight_elems(int32_t rows, int32_t red, int32_t kh, int32_t kw) {
     const int rb = row_block(rows);
@@ -791,7 +823,7 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     a.res_ld = d->res_ld; a.res_coff = d->res_coff;
     a.nchunk = div_up(d->Cs, 32);
     a.Cs = d->Cs;
-    a.n_pblk = div_up(a.M, HP);
+    a.n_pblk = div_up(a.M, pl.hp);
     a.n_cblk = div_up(d->Cd, rb);
     a.act = d->act;
     a.XH = pl.XH;

@@ -105,7 +105,7 @@ int cdet_pack_weights_batched(const cdet_pack_item* items, int32_t n_items, int3
  * Tap-resident convolution (csrc/conv_halo.hip): the fast path for the stride-1 3x3 and 1x1 Conv modules
  * (models/common.py:57-68 -- 80 % of the FLOPs of the YOLOv8x path) and for their data gradient.
  * Same arithmetic and epilogue as cdet_conv2d (y = act(conv * scale + bias) (+ residual), optional BN partial sums in
- * `stats` with cdet_conv2d_tiled_stat_blocks(d) pixel blocks of 256), but the weight operand is the TILED pack below and
+ * `stats` with cdet_conv2d_tiled_stat_blocks(d) pixel blocks of 256 or 128), but the weight operand is the TILED pack below and
  * the pixel tile is staged in LDS once per 32-channel chunk with its halo and reused by all nine taps.
  * Supported (cdet_conv2d_tiled_ok(d) == 1): kh == kw in {1,3}, stride 1, pad kh/2, channels / ld / coff multiples of 8,
  * 16-bit in == out dtype, no fp32 accumulate; 3x3: Ws <= 95 (256 consecutive pixels + linear halo) or Hs, Ws multiples

@@ -53,10 +53,17 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("ng", [0, 1, 2])
 @pytest.mark.parametrize("case", CASES)
-def test_tiled_conv_fwd_epilogue_stats(case):
+def test_tiled_conv_fwd_epilogue_stats(case, ng, monkeypatch):
+    """ng: 0 = the library's own choice of tile (half tiles when 256-pixel tiles would under-fill the chip), 1 / 2 = pinned."""
     ops = _ops()
     from cerberusdet_amd import _lib as L
+
+    if ng:
+        monkeypatch.setenv("CDET_HALO_NG", str(ng))
+    else:
+        monkeypatch.delenv("CDET_HALO_NG", raising=False)
 
     N, H, W, Ci, Co, k, dtype = case
     g = torch.Generator().manual_seed(11)
