@@ -112,6 +112,7 @@ __device__ __forceinline__ float half_sum32(float v) {
 }
 
 constexpr int HEPI_RAW = 0, HEPI_FULL = 1;
+constexpr int HEPI_STAGE_OFF = 6912;  // epilogue LDS map (after HZERO): statistics scratch [4][2][HC] fp32, scale/bias [2][HC] fp32, then the store staging
 
 #ifdef CDET_PROFILING
 // per-workgroup timeline for tools/halo_timeline.py: [xcc id, hw id, t_start, t_loop, t_epilogue, t_end] (s_memtime clocks)
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     uint16_t* const yp = reinterpret_cast<uint16_t*>(a.y);
     // per-channel scale / bias of the block's couts go through LDS once: as global loads inside the unrolled epilogue they were
     // 80 dependent L2 round trips per lane (the 160 live accumulators leave no registers to prefetch them) -- 2/3 of the epilogue's time
-    float* const sbl = reinterpret_cast<float*>(smem + HZERO + 8192);  // [2][HC], behind the statistics scratch
+    float* const sbl = reinterpret_cast<float*>(smem + HZERO + 5120);  // [2][HC], behind the statistics scratch
     if (EPI == HEPI_FULL) {
         if (t < HC) {
             const int c = c0 + t < a.Cd ? c0 + t : a.Cd - 1;
@@ -501,11 +502,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         }
         __syncthreads();
     }
+    // The packed 16-byte pieces (8 couts of one pixel) go through a per-wave LDS staging tile [32 pixels][HC couts] and leave as whole
+    // NHWC rows: a store instruction then covers 3.2 consecutive pixel rows (64 x 16 B contiguous when the block spans all couts)
+    // instead of 32 pixels x 32 B -- the scattered form cost 4.6 - 7.7 us per launch (timeline ablation, profiles/r02_*).
+    constexpr int RS = HC * 2 + 16;               // staging row stride (bytes): +16 spreads the 8-lane ds_write_b128 groups over all banks
+    constexpr int CH = HC / 8;                    // 16-byte chunks per pixel row
+    unsigned char* const stg = smem + HZERO + HEPI_STAGE_OFF + wave * (32 * RS);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int p = pout[g];
         const bool pok = p < a.M;
-        const int64_t ob = (int64_t)p * a.dst_ld + a.dst_coff;
         const int64_t rb = (int64_t)p * a.res_ld + a.res_coff;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -521,11 +527,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                     v[r] = __uint_as_float(s0);
                     v[4 + r] = __uint_as_float(s1);
                 }
-                const int co = c0 + f * 32 + 8 * (q + h);
-                if (!pok || co >= a.Cd) continue;
+                const int cl = f * 32 + 8 * (q + h);
+                const int co = c0 + cl;
                 if (EPI == HEPI_FULL) {
                     {
-                        const int cl = f * 32 + 8 * (q + h);
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbl + cl), s1 = *reinterpret_cast<const f32x4*>(sbl + cl + 4);
                         const f32x4 b0v = *reinterpret_cast<const f32x4*>(sbl + HC + cl), b1v = *reinterpret_cast<const f32x4*>(sbl + HC + cl + 4);
 #pragma unroll
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
                     }
-                    if (a.res) {
+                    if (a.res && pok && co < a.Cd) {
                         const u32x4 rv = *reinterpret_cast<const u32x4*>(a.res + rb + co);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -550,10 +555,31 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 u32x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = hpack2<DT>(v[2 * r], v[2 * r + 1]);
-                if (!(ABL & 8)) *reinterpret_cast<u32x4*>(yp + ob + co) = pk;
-                else asm volatile("" ::"v"(pk));
+                *reinterpret_cast<u32x4*>(stg + l31 * RS + cl * 2) = pk;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // whole rows out: chunk id -> (pixel of this fragment, 16-byte chunk of its row)
+#pragma unroll
+        for (int it = 0; it < (32 * CH + 63) / 64; ++it) {
+            const int id = it * 64 + lane;
+            const int px = id / CH, c = id - px * CH;
+            if (id < 32 * CH) {
+                const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + px * RS + c * 16);
+                const int i = wave * (32 * NG) + g * 32 + px;
+                int po;
+                if (PATCH) po = (pn * a.H + py0 + i / PATCH_W) * W + px0 + i % PATCH_W;
+                else po = p0 + i;
+                const int co = c0 + 8 * c;
+                if (po < a.M && co < a.Cd) {
+                    if (!(ABL & 8)) *reinterpret_cast<u32x4*>(yp + (int64_t)po * a.dst_ld + a.dst_coff + co) = pk;
+                    else asm volatile("" ::"v"(pk));
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();  // the next fragment overwrites the staging tile
     }
 #ifdef CDET_PROFILING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -690,6 +716,8 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     pl.nsw = base + 3 * (size_t)rb * HROW <= 80 * 1024 ? 3 : 2;
     if ((pl.patch || d->kh == 1 || pl.ng == 1) && pl.nsw != 3) return pl;
     pl.lds = base + (size_t)pl.nsw * rb * HROW;
+    const size_t epi = (size_t)HZERO + HEPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16);  // the epilogue's store staging
+    if (pl.lds < epi) pl.lds = epi;
     pl.ok = true;
     return pl;
 }
