@@ -1,4 +1,4 @@
-// Stem convolution (Cin = 3: K = 27, HBM-bound, direct VALU kernel reading the reference's NCHW image) and the
+// Stem weight gradient (Cin = 3, direct kernel reading the reference's NCHW image; the forward lives in stem_mfma.hip) and the
 // Detect head's eval-mode decode (DFL softmax-expectation + dist2bbox + sigmoid, writes the reference's [N,4+nc,A]).
 #include "common.h"
 
@@ -10,101 +10,6 @@ constexpr int STEM_MAX_COUT = 128;
 __device__ __forceinline__ float load_img(const void* img, int64_t i, int dtype) {
     if (dtype == CDET_U8) return (float)((const uint8_t*)img)[i] * (1.0f / 255.0f);
     return load_elem(img, i, dtype);
-}
-
-// One thread = one output pixel, all Cout channels (8 at a time). Weights live in LDS as [27][Cout] fp32 (broadcast reads).
-__global__ __launch_bounds__(STEM_TPB) void stem_conv_kernel(const void* __restrict__ img, int img_dtype, const float* __restrict__ w,
-                                                            const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            void* __restrict__ y, int N, int H, int W, int Cout, int out_dtype, int act,
-                                                            float* __restrict__ stats) {
-    __shared__ float ws[27 * STEM_MAX_COUT];
-    __shared__ float red[2][4][STEM_MAX_COUT];
-    for (int i = threadIdx.x; i < 27 * Cout; i += STEM_TPB) {
-        const int k = i / Cout, co = i - k * Cout;  // k = (c*3 + kh)*3 + kw  (OIHW inner order)
-        ws[i] = w[co * 27 + k];
-    }
-    __syncthreads();
-    const int Ho = H / 2, Wo = W / 2;
-    const int64_t M = (int64_t)N * Ho * Wo;
-    const int64_t p = (int64_t)blockIdx.x * STEM_TPB + threadIdx.x;
-    const bool valid = p < M;
-    float in[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) in[k] = 0.f;
-    if (valid) {
-        const int ox = (int)(p % Wo);
-        const int64_t t = p / Wo;
-        const int oy = (int)(t % Ho);
-        const int n = (int)(t / Ho);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iy = oy * 2 - 1 + kh, ix = ox * 2 - 1 + kw;
-                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                        in[(c * 3 + kh) * 3 + kw] = load_img(img, (((int64_t)n * 3 + c) * H + iy) * W + ix, img_dtype);
-                }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int cb = 0; cb < Cout; cb += 8) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(in[k], ws[k * Cout + cb + j], acc[j]);
-        }
-        if (stats) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float s = acc[j], q = acc[j] * acc[j];  // invalid threads hold zeros
-#pragma unroll
-                for (int m = 1; m < 64; m <<= 1) {
-                    s += __shfl_xor(s, m);
-                    q += __shfl_xor(q, m);
-                }
-                if (lane == 0) {
-                    red[0][wave][cb + j] = s;
-                    red[1][wave][cb + j] = q;
-                }
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = acc[j];
-                if (scale) v *= scale[cb + j];
-                if (bias) v += bias[cb + j];
-                if (act == CDET_ACT_SILU) v = silu_f(v);
-                acc[j] = v;
-            }
-            const int64_t o = p * Cout + cb;
-            if (out_dtype == CDET_F32) {
-                float* yp = (float*)y + o;
-                *reinterpret_cast<f32x4*>(yp) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-                *reinterpret_cast<f32x4*>(yp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-            } else {
-                u32x4 pk;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint16_t lo = out_dtype == CDET_BF16 ? f32_to_bf16_bits(acc[2 * j]) : f32_to_f16_bits(acc[2 * j]);
-                    const uint16_t hi = out_dtype == CDET_BF16 ? f32_to_bf16_bits(acc[2 * j + 1]) : f32_to_f16_bits(acc[2 * j + 1]);
-                    pk[j] = (uint32_t)lo | ((uint32_t)hi << 16);
-                }
-                *reinterpret_cast<u32x4*>((uint16_t*)y + o) = pk;
-            }
-        }
-    }
-    if (stats) {
-        __syncthreads();
-        for (int c = threadIdx.x; c < Cout; c += STEM_TPB) {
-            stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-            stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        }
-    }
 }
 
 // dW[co][c][kh][kw] += sum_p dy[p][co] * in[p][c,kh,kw]; thread (co, c) owns the 9 taps of one input channel.
@@ -234,20 +139,6 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N,
 }  // namespace cdet
 
 using namespace cdet;
-
-extern "C" int cdet_stem_conv_stat_blocks(int32_t N, int32_t H, int32_t W) { return div_up((int64_t)N * (H / 2) * (W / 2), STEM_TPB); }
-
-extern "C" int cdet_stem_conv(const void* img, int32_t img_dtype, const float* w, const float* scale, const float* bias, void* y, int32_t N,
-                              int32_t H, int32_t W, int32_t Cout, int32_t out_dtype, int32_t act, float* stats, void* stream) {
-    CDET_CHECK_ARG(img && w && y, "cdet_stem_conv: null pointer");
-    CDET_CHECK_ARG(Cout % 8 == 0 && Cout <= STEM_MAX_COUT, "cdet_stem_conv: Cout must be a multiple of 8 and <= %d (got %d)", STEM_MAX_COUT, Cout);
-    CDET_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "cdet_stem_conv: H and W must be even");
-    const int blocks = cdet_stem_conv_stat_blocks(N, H, W);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(blocks), dim3(STEM_TPB), 0, (hipStream_t)stream, img, img_dtype, w, scale, bias, y, N, H, W, Cout,
-                       out_dtype, act, stats);
-    CDET_LAUNCH_CHECK();
-    return 0;
-}
 
 extern "C" int cdet_stem_conv_wgrad(const void* img, int32_t img_dtype, const void* dy, int32_t dtype, float* dw, int32_t N, int32_t H, int32_t W,
                                     int32_t Cout, int32_t accumulate, void* stream) {

