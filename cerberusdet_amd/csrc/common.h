@@ -79,6 +79,14 @@ __device__ __forceinline__ float silu_f(float a) { return a / (1.0f + __expf(-a)
 __device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + __expf(-a)); }
 
 static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// tap-resident weight gradient (conv_wgrad_halo.hip), used by cdet_conv2d_wgrad (conv_wgrad.hip) for the stride-1 3x3 layers
+struct WgradHaloPlan {
+    int S, chunk, Kp, Cd_pad, n_cblk, n_iblk, XH, nci;
+    size_t lds;
+};
+bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out);
+int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s);
 static inline int elem_size(int dtype) { return dtype == CDET_F32 ? 4 : (dtype == CDET_U8 ? 1 : 2); }
 
 }  // namespace cdet

@@ -641,6 +641,8 @@ using namespace cdet;
 
 extern "C" int64_t cdet_conv2d_wgrad_ws_elems(const cdet_conv_desc* d) {
     if (!d) return -1;
+    WgradHaloPlan hp;
+    if (wgrad_halo_plan(d, &hp)) return (int64_t)hp.S * hp.Cd_pad * hp.Kp;
     const WgradPlan p = plan_wgrad(d);
     return (int64_t)p.S * p.Cd_pad * p.Kp;
 }
@@ -651,7 +653,16 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     CDET_CHECK_ARG(d->Cs % 8 == 0 && d->src_ld % 8 == 0 && d->src_coff % 8 == 0, "cdet_conv2d_wgrad: x channels/ld/coff must be multiples of 8");
     CDET_CHECK_ARG(d->dst_ld % 8 == 0 && d->dst_coff % 8 == 0, "cdet_conv2d_wgrad: dy ld/coff must be multiples of 8");
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_wgrad: descriptor must describe the forward convolution");
-    const WgradPlan p = plan_wgrad(d);
+    WgradPlan p = plan_wgrad(d);
+    WgradHaloPlan hp;
+    const bool halo = wgrad_halo_plan(d, &hp);
+    if (halo) {  // stride-1 3x3: tap-resident kernel, same slab layout / reduction as below
+        const int e = wgrad_halo_launch(d, hp, x, dy, ws, (hipStream_t)stream);
+        if (e) return e;
+        p.S = hp.S;
+        p.Cd_pad = hp.Cd_pad;
+        p.Kp = hp.Kp;
+    }
     WgradArgs a;
     a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.ws = ws;
     a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Cs = d->Cs; a.Hd = d->Hd; a.Wd = d->Wd;
@@ -664,7 +675,8 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     int e;
     const bool fits32 = (int64_t)d->N * d->Hs * d->Ws * d->src_ld < (1ll << 31);
     CDET_CHECK_ARG(fits32, "cdet_conv2d_wgrad: tensor too large for 32-bit gather offsets");
-    if (d->dtype == CDET_BF16) e = p.wide ? launch_wgrad<CDET_BF16, 2, 2>(a, s) : launch_wgrad<CDET_BF16, 4, 1>(a, s);
+    if (halo) e = 0;
+    else if (d->dtype == CDET_BF16) e = p.wide ? launch_wgrad<CDET_BF16, 2, 2>(a, s) : launch_wgrad<CDET_BF16, 4, 1>(a, s);
     else e = p.wide ? launch_wgrad<CDET_F16, 2, 2>(a, s) : launch_wgrad<CDET_F16, 4, 1>(a, s);
     if (e) return e;
     const int taps = d->kh * d->kw;

@@ -1,0 +1,367 @@
+// Tap-resident weight gradient of the stride-1 3x3 convolution (gfx950, bf16 / f16 in, fp32 accumulate):
+//
+//   dW[co][tap][ci] = sum_p dY[p][co] * X[p + off(tap)][ci]          (autograd's convolution_backward(weight), models/common.py:57)
+//
+// The im2col form in conv_wgrad.hip gathers every pixel's 9 taps separately (a 128 x 160 output tile re-fetches X once per k-block:
+// 36 KB of L2 -> LDS traffic per 64-pixel step, 56 B/clk per workgroup against the ~40 B/clk/CU the DMA path delivers -> 600 TF/s).
+// Here, as in conv_halo.hip, the pixel tile is staged ONCE with its halo and serves all nine taps:
+//   * a workgroup (8 waves, one per CU) owns the output tile [160 couts] x [16*NCI cins] x [9 taps] for one split of the pixel range.
+//     Per stage of 128 consecutive pixels it stages dY [128][160] (40 KB) and the X halo [128 + 2W + 2][16*NCI] (LDS-DMA, double
+//     buffered). NCI = 4 (64 cins): every wave runs all 128 pixels for its own [80 couts] x [16 cins] x [9 taps] = 45 accumulator
+//     tiles of v_mfma_f32_16x16x32 (180 fp32 registers per lane). NCI = 2 (32 cins, for Cs % 64 != 0 or wide rows whose halo does not
+//     fit): waves 0-3 take pixels 0..63 of a stage and waves 4-7 pixels 64..127 of the same tiles; the halves are summed through LDS
+//     at the end, so a workgroup always writes ONE fp32 slab;
+//   * both operands are reduction-major in LDS ([pixel][channel] rows); ds_read_b64_tr_b16 transposes them on the way to the registers
+//     (semantics probed in profiles/r01_probe_ds_read_tr_b16.txt). A lane's 8 reduction indices are pixels {4q..4q+3, 16+4q..16+4q+3}
+//     of a 32-pixel step for BOTH operands. Every transpose read of the kernel is the pattern "lane l reads 8 bytes at base + 8*l":
+//     dY sits as 1 KiB images [16-pixel block][cout pair][2 cout groups][16 px][32 B], X as NCI planes of 32-byte rows
+//     [16-cin plane][halo row][32 B] -- 512 contiguous bytes per instruction, conflict-free (profiles/r02_tr_bank_probe.txt);
+//   * the addresses are affine: one base register per operand and stage, everything else is an instruction immediate. Taps that leave
+//     the image are redirected per lane to a zero region with ONE v_cndmask on a precomputed 64-lane mask (top / bottom / left /
+//     right validity of the lane's pixel; corner taps AND two masks on the scalar unit). The transpose reads are inline asm with
+//     explicit lgkmcnt accounting: the compiler would otherwise drain vmcnt(0) -- the next stage's DMA -- in front of every LDS read.
+// Output: partial slab ws[split][co][tap*Cs + ci] (fp32) -- the layout wgrad_reduce_kernel<3,3> of conv_wgrad.hip reduces.
+#include "common.h"
+
+#include <utility>
+
+namespace cdet {
+
+struct WHArgs {
+    const uint16_t* x;
+    const uint16_t* dy;
+    float* ws;
+    int H, W, M;
+    int Cs, Cd;
+    int src_ld, src_coff, dy_ld, dy_coff;
+    int Kp, Cd_pad;
+    int chunk, S;
+    int n_cblk, n_iblk;
+    int XH;  // halo rows per stage (multiple of 32)
+    unsigned magicW, magicH;  // 2^32 / W + 1, 2^32 / H + 1: exact quotients by v_mul_hi for every pixel index of the path
+    unsigned x_bytes, dy_bytes;
+};
+
+constexpr int WH_P = 128;            // pixels per stage
+constexpr int WH_DYB = 40 * 1024;    // dY bytes per stage: 8 pixel blocks of 16 x 5 cout pairs, 1 KiB each
+constexpr int WH_ZERO = 4608;        // zero region: 512 lane bytes + the largest X immediate (114 rows of 32 B)
+constexpr unsigned WH_SENT = 0xE0000000u;
+
+template <int... I, class F>
+__device__ __forceinline__ void wh_static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+template <int OFF>
+__device__ __forceinline__ u32x2 wh_tr(int addr) {  // asynchronous: the result is valid after wh_wait<>() on it
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// the waits take the registers they make valid as in/out operands: every use the compiler schedules comes after the wait
+template <int N>
+__device__ __forceinline__ void wh_wait(u32x2& a, u32x2& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wh_wait_b(u32x2 (&lo)[5], u32x2 (&hi)[5], u32x2& a, u32x2& b) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]),
+                   "+v"(hi[4]), "+v"(a), "+v"(b)
+                 : "n"(N));
+}
+__device__ __forceinline__ int wh_sel(uint64_t m, int a_valid, int a_zero) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a_zero), "v"(a_valid), "s"(m));
+    return r;
+}
+
+template <int DT>
+__device__ __forceinline__ void wh_mfma(const u32x4& a, const u32x4& b, f32x4& c) {
+    if (DT == CDET_BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+__device__ __forceinline__ void wh_dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
+template <int DT, int NCI>
+__global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
+    constexpr int KSL = NCI == 4 ? 4 : 2;  // 32-pixel reduction steps a wave runs per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = NCI == 4 ? 0 : wave >> 2;
+    const int wco = NCI == 4 ? wave >> 2 : (wave >> 1) & 1;
+    const int wci = NCI == 4 ? wave & 3 : wave & 1;
+    const int q = lane >> 4, li = lane & 15;
+
+    // workgroup -> (split, tile): consecutive logical ids = the tiles of ONE split, on one XCD (they share the split's X / dY rows)
+    int L;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, qq = nwg >> 3, rr = nwg & 7, j = b >> 3;
+        L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + j;
+    }
+    const int ntiles = a.n_cblk * a.n_iblk;
+    const int split = L / ntiles;
+    const int tile = L - split * ntiles;
+    const int cblk = tile / a.n_iblk, iblk = tile - cblk * a.n_iblk;
+    const int c0 = cblk * 160, i0 = iblk * 16 * NCI;
+    const int pbeg = split * a.chunk;
+    const int pend = min(pbeg + a.chunk, a.M);
+    const int nst = pbeg < pend ? (pend - pbeg + WH_P - 1) / WH_P : 0;
+    const int W = a.W;
+    const int XP = a.XH * 32;  // bytes of one 16-cin plane
+    const int STAGE = WH_DYB + NCI * XP;
+    const int ZOFF = 2 * STAGE;
+    for (int i = t; i < WH_ZERO / 4; i += 512) reinterpret_cast<uint32_t*>(smem + ZOFF)[i] = 0u;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+
+    // ---- DMA duties of this wave (1 KiB = one instruction each; out-of-range offsets fetch zeros, which covers the rows above the
+    //      first and below the last pixel of the tensor, and every pixel >= M of a ragged last stage):
+    //   dY image di = wave + 8*idx (idx 0..4) = (16-pixel block di/5, cout pair di%5); lane -> (cout group lane>>5, pixel (lane>>1)&15,
+    //      16-byte half lane&1): 64 contiguous bytes per pixel;
+    //   X piece xi = wave + 8*idx = (32-row block xi / NCI, plane xi % NCI); lane -> (row lane>>1, half lane&1).
+    const int ldyB = a.dy_ld * 2, ldxB = a.src_ld * 2;
+    const int nxp = NCI * (a.XH >> 5);
+    const int yco_l = (lane >> 5) * 16 + (lane & 1) * 8;
+    const unsigned ydl = (unsigned)(((lane >> 1) & 15) * ldyB + yco_l * 2);
+    const unsigned xdl = (unsigned)((lane >> 1) * ldxB + (lane & 1) * 16);
+    auto issue_dma = [&](int idx, int st, int buf) {  // idx 0..4: dY images, 5..9: X pieces, of stage st -> buffer buf
+        if (st >= nst) return;
+        unsigned char* base = smem + buf * STAGE;
+        const int pb0 = pbeg + st * WH_P;
+        if (idx < 5) {
+            const int di = wave + 8 * idx;  // wave-uniform
+            const int pb = di / 5, cp = di - pb * 5;
+            const int cobase = c0 + cp * 32;
+            const unsigned sc = (unsigned)((pb0 + pb * 16) * ldyB + (a.dy_coff + cobase) * 2);
+            const unsigned v = yco_l < a.Cd - cobase ? ydl + sc : WH_SENT;
+            wh_dma16(rs_y, v, base + di * 1024);
+        } else {
+            const int xi = wave + 8 * (idx - 5);  // wave-uniform
+            if (xi < nxp) {
+                const int blk = xi / NCI, pl = xi - blk * NCI;
+                // (rows above the tensor give a negative pixel: the 32-bit offset wraps far beyond the buffer -> zeros)
+                const unsigned sc = (unsigned)((pb0 + blk * 32 - (W + 1)) * ldxB + (a.src_coff + i0 + pl * 16) * 2);
+                wh_dma16(rs_x, xdl + sc, base + WH_DYB + pl * XP + blk * 1024);
+            }
+        }
+    };
+
+    // ---- transpose-read bases: every read is "8 bytes at base + 8*lane" (+ immediate)
+    //   dY: K-step ks (32 px), 16-pixel block 2*ks + hh, cout group cog = wco*5 + j -> image (2*ks + hh)*5 + cog/2, half cog&1
+    //       = byte (2*ks + hh)*5120 + cog*512
+    //   X : halo row of pixel px and tap (ky, kx) = px + ky*W + kx, plane wci
+    const int yb0 = wco * 2560 + lane * 8 + half * 20480;
+    const int xb0 = WH_DYB + wci * XP + half * 64 * 32 + lane * 8;
+    const int zaddr = ZOFF + lane * 8;
+    const int pix_l = half * 64 + (lane >> 2);  // the lane's pixel inside a 16-pixel block, + the wave's pixel half
+
+    f32x4 acc[9][5];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[tp][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: stage 0
+#pragma unroll
+    for (int i = 0; i < 10; ++i) issue_dma(i, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        int vy = yb0 + cur * STAGE;
+        int vx[3];
+        vx[0] = xb0 + cur * STAGE;
+        vx[1] = vx[0] + W * 32;
+        vx[2] = vx[1] + W * 32;
+        asm volatile("" : "+v"(vy), "+v"(vx[0]), "+v"(vx[1]), "+v"(vx[2]));
+        const int pst = pbeg + st * WH_P + pix_l;
+        wh_static_for(std::make_integer_sequence<int, KSL>{}, [&](auto KS) {
+            constexpr int ksl = decltype(KS)::value;
+            // validity of the lane's two pixels of this step: top / bottom / left / right neighbours inside the image
+            uint64_t mt[2], mb[2], ml[2], mr[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const unsigned p = (unsigned)(pst + ksl * 32 + hh * 16);
+                const unsigned r = __umulhi(p, a.magicW);
+                const int xx = (int)(p - r * (unsigned)W);
+                const int yy = (int)(r - __umulhi(r, a.magicH) * (unsigned)a.H);
+                mt[hh] = __builtin_amdgcn_ballot_w64(yy > 0);
+                mb[hh] = __builtin_amdgcn_ballot_w64(yy < a.H - 1);
+                ml[hh] = __builtin_amdgcn_ballot_w64(xx > 0);
+                mr[hh] = __builtin_amdgcn_ballot_w64(xx < W - 1);
+            }
+            auto x_addr = [&](auto TP, int hh) -> int {
+                constexpr int tp = decltype(TP)::value;
+                constexpr int ky = tp / 3, kx = tp % 3;
+                if (tp == 4) return vx[1];
+                uint64_t m = ky == 0 ? mt[hh] : (ky == 2 ? mb[hh] : ~0ull);
+                if (kx == 0) m = ky == 1 ? ml[hh] : (m & ml[hh]);
+                if (kx == 2) m = ky == 1 ? mr[hh] : (m & mr[hh]);
+                return wh_sel(m, vx[ky], zaddr);
+            };
+            // B fragments: 5 cout groups x this step's 32 pixels
+            u32x2 blo[5], bhi[5];
+            wh_static_for(std::make_integer_sequence<int, 5>{}, [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                blo[j] = wh_tr<(2 * ksl) * 5120 + j * 512>(vy);
+                bhi[j] = wh_tr<(2 * ksl + 1) * 5120 + j * 512>(vy);
+            });
+            u32x2 alo[2], ahi[2];
+            {
+                const int a0 = x_addr(std::integral_constant<int, 0>{}, 0), a1 = x_addr(std::integral_constant<int, 0>{}, 1);
+                alo[0] = wh_tr<(ksl * 32) * 32>(a0);
+                ahi[0] = wh_tr<(ksl * 32 + 16) * 32>(a1);
+            }
+            wh_static_for(std::make_integer_sequence<int, 9>{}, [&](auto TP) {
+                constexpr int tp = decltype(TP)::value;
+                constexpr int cs = tp & 1, ns = cs ^ 1;
+                if constexpr (tp + 1 < 9) {
+                    constexpr int kx = (tp + 1) % 3;
+                    const int a0 = x_addr(std::integral_constant<int, tp + 1>{}, 0);
+                    const int a1 = x_addr(std::integral_constant<int, tp + 1>{}, 1);
+                    alo[ns] = wh_tr<(ksl * 32 + kx) * 32>(a0);
+                    ahi[ns] = wh_tr<(ksl * 32 + 16 + kx) * 32>(a1);
+                }
+                // the next stage's operands, one DMA instruction per tap of the first two steps
+                if constexpr (ksl == 0) issue_dma(tp, st + 1, cur ^ 1);
+                if constexpr (ksl == 1 && tp == 0) issue_dma(9, st + 1, cur ^ 1);
+                if constexpr (tp == 0) wh_wait_b<2>(blo, bhi, alo[0], ahi[0]);
+                else if constexpr (tp + 1 < 9) wh_wait<2>(alo[cs], ahi[cs]);
+                else wh_wait<0>(alo[cs], ahi[cs]);
+                const u32x4 av{alo[cs][0], alo[cs][1], ahi[cs][0], ahi[cs][1]};
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const u32x4 bv{blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]};
+                    wh_mfma<DT>(av, bv, acc[tp][j]);
+                }
+            });
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (NCI == 2) {
+        // ---- waves 4..7 hand their partial tiles to waves 0..3 through LDS (two rounds: 23 + 22 tiles of 1 KiB per wave pair)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int t0 = rd * 23, t1 = rd ? 45 : 23;
+            unsigned char* slot = smem + ((wave & 3) * 23) * 1024 + lane * 16;
+            if (half == 1) {
+#pragma unroll
+                for (int tl = 0; tl < 45; ++tl)
+                    if (tl >= t0 && tl < t1) *reinterpret_cast<f32x4*>(slot + (tl - t0) * 1024) = acc[tl / 5][tl % 5];
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int tl = 0; tl < 45; ++tl)
+                    if (tl >= t0 && tl < t1) acc[tl / 5][tl % 5] += *reinterpret_cast<const f32x4*>(slot + (tl - t0) * 1024);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- partial slab: C[ci][co] tiles -> ws[split][co][tap*Cs + ci], 4 consecutive cins per lane
+    if (half == 0) {
+        float* wsp = a.ws + (int64_t)split * a.Cd_pad * a.Kp;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int co = c0 + (wco * 5 + j) * 16 + li;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int k = tp * a.Cs + i0 + wci * 16 + 4 * q;
+                *reinterpret_cast<f32x4*>(wsp + (int64_t)co * a.Kp + k) = acc[tp][j];
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
+    if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1)) return false;
+    if (d->Hs != d->Hd || d->Ws != d->Wd) return false;
+    if (d->Cs % 32 != 0 || d->Cd < 128) return false;  // an 80-cout layer would leave half of the 160-cout tile empty
+    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
+    int force_nci = 0;
+    if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel; 2 / 4: force the cin tile (profiling)
+        force_nci = atoi(e);
+        if (force_nci == 0) return false;
+    }
+    const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
+    const int XH = (WH_P + 2 * (d->Ws + 1) + 31) / 32 * 32;
+    auto lds_of = [&](int nci) { return 2 * (size_t)(WH_DYB + nci * XH * 32) + WH_ZERO; };
+    int nci = (d->Cs % 64 == 0 && lds_of(4) <= 160 * 1024) ? 4 : 2;
+    if (force_nci == 2) nci = 2;
+    if (lds_of(nci) > 160 * 1024) return false;
+    if (nci * (XH / 32) > 40) return false;  // 5 X pieces per wave
+    if (M * d->src_ld * 2 >= 0xC0000000ll || M * d->dst_ld * 2 >= 0xC0000000ll) return false;
+    if (M >= (1 << 24)) return false;  // the magic-multiply quotients are exact far beyond this; keep a wide margin
+    const int n_cblk = div_up(d->Cd, 160), n_iblk = d->Cs / (16 * nci);
+    const int tiles = n_cblk * n_iblk;
+    if (tiles > 256) return false;
+    // one workgroup per CU: the largest split count that keeps the grid within one round; every split costs a slab write + re-read
+    int S = 256 / tiles;
+    const int maxS = (int)((M + 511) / 512);  // at least 512 pixels (4 stages) per split
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    int chunk = (int)((M + S - 1) / S);
+    chunk = (chunk + WH_P - 1) / WH_P * WH_P;
+    S = (int)((M + chunk - 1) / chunk);
+    out->S = S;
+    out->chunk = chunk;
+    out->Kp = 9 * d->Cs;
+    out->Cd_pad = n_cblk * 160;
+    out->n_cblk = n_cblk;
+    out->n_iblk = n_iblk;
+    out->XH = XH;
+    out->nci = nci;
+    out->lds = lds_of(nci);
+    return true;
+}
+
+template <int DT, int NCI>
+static void wgrad_halo_launch_t(const WHArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<DT, NCI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_halo_kernel<DT, NCI>), dim3(grid), dim3(512), lds, s, a);
+}
+
+int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s) {
+    WHArgs a;
+    a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.ws = ws;
+    a.H = d->Hs; a.W = d->Ws; a.M = d->N * d->Hs * d->Ws;
+    a.Cs = d->Cs; a.Cd = (d->Cd + 7) / 8 * 8;
+    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dy_ld = d->dst_ld; a.dy_coff = d->dst_coff;
+    a.Kp = p.Kp; a.Cd_pad = p.Cd_pad; a.chunk = p.chunk; a.S = p.S; a.n_cblk = p.n_cblk; a.n_iblk = p.n_iblk; a.XH = p.XH;
+    a.magicW = (unsigned)((1ull << 32) / (unsigned)a.W + 1);
+    a.magicH = (unsigned)((1ull << 32) / (unsigned)a.H + 1);
+    a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
+    a.dy_bytes = (unsigned)((int64_t)a.M * d->dst_ld * 2);
+    const int grid = p.S * p.n_cblk * p.n_iblk;
+    if (d->dtype == CDET_BF16) {
+        if (p.nci == 4) wgrad_halo_launch_t<CDET_BF16, 4>(a, grid, p.lds, s);
+        else wgrad_halo_launch_t<CDET_BF16, 2>(a, grid, p.lds, s);
+    } else {
+        if (p.nci == 4) wgrad_halo_launch_t<CDET_F16, 4>(a, grid, p.lds, s);
+        else wgrad_halo_launch_t<CDET_F16, 2>(a, grid, p.lds, s);
+    }
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cdet

@@ -128,6 +128,51 @@ def test_conv_dgrad_and_wgrad(case):
     _close(dw, 2 * w.grad, 2e-3, 4e-3 * float(w.grad.abs().max()))
 
 
+WGRAD_HALO_CASES = [
+    # N, H, W, Cin, Cout, dtype -- 3x3 stride-1 shapes the tap-resident weight-gradient kernel (csrc/conv_wgrad_halo.hip) takes
+    (2, 40, 40, 64, 160, torch.bfloat16),    # 4 pixel splits, the last one partial
+    (1, 80, 80, 32, 136, torch.bfloat16),    # Cout not a multiple of 16: the last cout group is half empty
+    (3, 24, 56, 96, 320, torch.float16),     # non-square map, two cout blocks, fp16
+    (1, 16, 16, 32, 128, torch.bfloat16),    # one split, two stages
+    (2, 20, 100, 32, 192, torch.bfloat16),   # wide rows: the halo is 330 rows
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_HALO_CASES)
+def test_conv_wgrad_tap_resident(case, monkeypatch):
+    """The tap-resident weight gradient against autograd AND against the im2col kernel it replaces on the same operands (channel
+    slices of wider buffers on both sides)."""
+    ops = _ops()
+    N, H, W, Ci, Co, dtype = case
+    Cop = (Co + 7) // 8 * 8
+    g = torch.Generator().manual_seed(5)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype).requires_grad_(True)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = _rt(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    xb = torch.randn(N, H, W, Ci + 24, generator=g).to(dtype).to(DEV)
+    xb[..., 16:16 + Ci] = x.detach().permute(0, 2, 3, 1).to(dtype).to(DEV)
+    xv = ops.View(xb, 16, Ci)
+    yb = torch.randn(N, H, W, Cop + 8, generator=g).to(dtype).to(DEV)
+    yb[..., 8:8 + Cop] = 0
+    yb[..., 8:8 + Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    dyv = ops.View(yb, 8, Cop)
+    dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    ops.conv2d_wgrad(xv, dyv, dw, 3, 1)
+    torch.cuda.synchronize()
+    _close(dw, w.grad, 2e-3, 2e-3 * float(w.grad.abs().max()))
+    monkeypatch.setenv("CDET_WGRAD_HALO", "0")
+    dw0 = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    ops.conv2d_wgrad(xv, dyv, dw0, 3, 1)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("CDET_WGRAD_HALO")
+    _close(dw, dw0, 1e-4, 1e-4 * float(w.grad.abs().max()))  # same bf16 products, fp32 sums in a different order
+    ops.conv2d_wgrad(xv, dyv, dw, 3, 1, accumulate=True)
+    torch.cuda.synchronize()
+    _close(dw, 2 * w.grad, 2e-3, 4e-3 * float(w.grad.abs().max()))
+
+
 @pytest.mark.parametrize("img_dtype", [torch.float32, torch.uint8])
 def test_stem_conv_and_wgrad(img_dtype):
     ops = _ops()
