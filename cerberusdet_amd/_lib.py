@@ -9,7 +9,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libcerberus_hip.so"
+LIB_PATH = Path(os.environ.get("CDET_LIB_PATH", _HERE / "libcerberus_hip.so"))  # override: profiling builds (tools/)
 
 BF16, F16, F32, U8 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU = 0, 1

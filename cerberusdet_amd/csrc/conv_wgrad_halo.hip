@@ -46,6 +46,9 @@ constexpr int WH_P = 128;            // pixels per stage
 constexpr int WH_DYB = 40 * 1024;    // dY bytes per stage: 8 pixel blocks of 16 x 5 cout pairs, 1 KiB each
 constexpr int WH_ZERO = 4608;        // zero region: 512 lane bytes + the largest X immediate (114 rows of 32 B)
 constexpr unsigned WH_SENT = 0xE0000000u;
+#ifndef WH_ABL  // profiling builds only (make EXTRA="-DWH_ABL=n"): 1 no DMA in the loop, 2 no stage barrier, 4 no MFMA, 8 no A reads, 16 no B reads
+#define WH_ABL 0
+#endif
 
 template <int... I, class F>
 __device__ __forceinline__ void wh_static_for(std::integer_sequence<int, I...>, F&& f) {
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     const unsigned xdl = (unsigned)((lane >> 1) * ldxB + (lane & 1) * 16);
     auto issue_dma = [&](int idx, int st, int buf) {  // idx 0..4: dY images, 5..9: X pieces, of stage st -> buffer buf
         if (st >= nst) return;
+        if ((WH_ABL & 1) && st > 0) return;
         unsigned char* base = smem + buf * STAGE;
         const int pb0 = pbeg + st * WH_P;
         if (idx < 5) {
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             u32x2 blo[5], bhi[5];
             wh_static_for(std::make_integer_sequence<int, 5>{}, [&](auto J) {
                 constexpr int j = decltype(J)::value;
+                if ((WH_ABL & 16) && (st > 0 || ksl > 0)) return;
                 blo[j] = wh_tr<(2 * ksl) * 5120 + j * 512>(vy);
                 bhi[j] = wh_tr<(2 * ksl + 1) * 5120 + j * 512>(vy);
             });
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             wh_static_for(std::make_integer_sequence<int, 9>{}, [&](auto TP) {
                 constexpr int tp = decltype(TP)::value;
                 constexpr int cs = tp & 1, ns = cs ^ 1;
-                if constexpr (tp + 1 < 9) {
+                if constexpr (tp + 1 < 9 && !(WH_ABL & 8)) {
                     constexpr int kx = (tp + 1) % 3;
                     const int a0 = x_addr(std::integral_constant<int, tp + 1>{}, 0);
                     const int a1 = x_addr(std::integral_constant<int, tp + 1>{}, 1);
@@ -242,12 +247,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     const u32x4 bv{blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]};
-                    wh_mfma<DT>(av, bv, acc[tp][j]);
+                    if (!(WH_ABL & 4)) wh_mfma<DT>(av, bv, acc[tp][j]);
+                    else asm volatile("" : "+v"(acc[tp][j]) : "v"(av), "v"(bv));
                 }
             });
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(WH_ABL & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -295,15 +301,19 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     if (d->Cs % 32 != 0 || d->Cd < 128) return false;  // an 80-cout layer would leave half of the 160-cout tile empty
     if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
     int force_nci = 0;
-    if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel; 2 / 4: force the cin tile (profiling)
+    if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel (the tests compare the two); 4: 64-cin tile where it fits
         force_nci = atoi(e);
         if (force_nci == 0) return false;
     }
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
     const int XH = (WH_P + 2 * (d->Ws + 1) + 31) / 32 * 32;
     auto lds_of = [&](int nci) { return 2 * (size_t)(WH_DYB + nci * XH * 32) + WH_ZERO; };
-    int nci = (d->Cs % 64 == 0 && lds_of(4) <= 160 * 1024) ? 4 : 2;
-    if (force_nci == 2) nci = 2;
+    // The 64-cin tile halves the L2 -> LDS traffic per flop and needs no half-sum (main loop 4 % faster on 40x40x320), but every
+    // workgroup then writes a slab twice the size: with one workgroup per CU the split-K workspace is 256 x (tile bytes) whatever
+    // the layer, 47 MB at 32 cins against 94 MB -- measured 0.096 vs 0.105 ms per launch (profiles/r02_wgrad_kstats.txt). The
+    // 64-cin form is kept for CDET_WGRAD_HALO=4 (parity-tested): it is the right tile once launches are grouped and S drops to 1.
+    int nci = 2;
+    if (force_nci == 4 && d->Cs % 64 == 0 && lds_of(4) <= 160 * 1024) nci = 4;
     if (lds_of(nci) > 160 * 1024) return false;
     if (nci * (XH / 32) > 40) return false;  // 5 X pieces per wave
     if (M * d->src_ld * 2 >= 0xC0000000ll || M * d->dst_ld * 2 >= 0xC0000000ll) return false;

@@ -134,12 +134,15 @@ WGRAD_HALO_CASES = [
     (1, 80, 80, 32, 136, torch.bfloat16),    # Cout not a multiple of 16: the last cout group is half empty
     (3, 24, 56, 96, 320, torch.float16),     # non-square map, two cout blocks, fp16
     (1, 16, 16, 32, 128, torch.bfloat16),    # one split, two stages
+    (2, 20, 20, 128, 160, torch.bfloat16),   # Cin % 64 == 0: also runs on the 64-cin tile
+    (1, 40, 40, 64, 200, torch.float16),     # 64-cin tile, two cout blocks, the second 40 wide
     (2, 20, 100, 32, 192, torch.bfloat16),   # wide rows: the halo is 330 rows
 ]
 
 
+@pytest.mark.parametrize("tile", ["32", "64"])
 @pytest.mark.parametrize("case", WGRAD_HALO_CASES)
-def test_conv_wgrad_tap_resident(case, monkeypatch):
+def test_conv_wgrad_tap_resident(case, tile, monkeypatch):
     """The tap-resident weight gradient against autograd AND against the im2col kernel it replaces on the same operands (channel
     slices of wider buffers on both sides)."""
     ops = _ops()
@@ -158,6 +161,10 @@ def test_conv_wgrad_tap_resident(case, monkeypatch):
     yb[..., 8:8 + Cop] = 0
     yb[..., 8:8 + Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
     dyv = ops.View(yb, 8, Cop)
+    if tile == "64":
+        if Ci % 64:
+            pytest.skip("the 64-cin tile needs Cin % 64 == 0")
+        monkeypatch.setenv("CDET_WGRAD_HALO", "4")
     dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
     ops.conv2d_wgrad(xv, dyv, dw, 3, 1)
     torch.cuda.synchronize()
@@ -166,7 +173,7 @@ def test_conv_wgrad_tap_resident(case, monkeypatch):
     dw0 = torch.zeros(Co, Ci, 3, 3, device=DEV)
     ops.conv2d_wgrad(xv, dyv, dw0, 3, 1)
     torch.cuda.synchronize()
-    monkeypatch.delenv("CDET_WGRAD_HALO")
+    monkeypatch.setenv("CDET_WGRAD_HALO", "4" if tile == "64" else "1")
     _close(dw, dw0, 1e-4, 1e-4 * float(w.grad.abs().max()))  # same bf16 products, fp32 sums in a different order
     ops.conv2d_wgrad(xv, dyv, dw, 3, 1, accumulate=True)
     torch.cuda.synchronize()
