@@ -449,13 +449,15 @@ class CerberusDet(nn.Module):
     def half(self):
         """Reference inference calls model.half() (cerberusdet_inference.py:39-40): parameters stay fp32 masters here,
         only the compute/storage dtype of activations and packed weights switches to fp16."""
-        self.compute_dtype = torch.float16
-        self._plans = {}
+        if self.compute_dtype != torch.float16:
+            self.compute_dtype = torch.float16
+            self._plans = {}
         return self
 
     def bfloat16(self):
-        self.compute_dtype = torch.bfloat16
-        self._plans = {}
+        if self.compute_dtype != torch.bfloat16:
+            self.compute_dtype = torch.bfloat16
+            self._plans = {}
         return self
 
     def float(self):

@@ -192,13 +192,13 @@ class Averaging:
         there a per-block event chain keeps the reference's task order, so the results are bit-identical to the sequential
         schedule. What the overlap buys: one pass's latency-bound launches (BN partial-sum kernels, ~400 per pass) and the
         partly filled last round of its convolution grids run under the other pass's kernels (measured 113.8 -> 101.9 ms)."""
-        from ..engine import BlockSync
+        from ..engine import BlockSync, lane_stream
 
         cur = torch.cuda.current_stream()
         key = tuple(active)
         cache = self.__dict__.setdefault("_stream_sync", {})
         if key not in cache:
-            streams = [torch.cuda.Stream() for _ in active]
+            streams = [lane_stream(self.device, k + 1) for k in range(len(active))]  # the process-wide lane streams (engine.py)
             syncs = {t: BlockSync() for t in active}
             for idx, ts in self.serving.items():
                 chain = [t for t in active if t in ts]
