@@ -59,7 +59,7 @@ class MatchDesc(C.Structure):
 
 
 class ParamSlot(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("lr", f32), ("weight_decay", f32),
+    _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("group", i32), ("weight_decay", f32),
                 ("inv_div", f32), ("first_step", i32)]
 
 
@@ -100,6 +100,7 @@ _SIGS = {
     "cdet_sppf_pool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_sppf_pool_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_detect_decode": (i32, [vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i32, i32, i32, vp, i32, vp]),
+    "cdet_pad_targets": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),
     "cdet_det_loss_ws_bytes": (i64, [C.POINTER(LossDesc)]),
     "cdet_det_loss": (i32, [C.POINTER(LossDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_nms_ws_bytes": (i64, [C.POINTER(NmsDesc)]),
@@ -107,7 +108,7 @@ _SIGS = {
     "cdet_merge_tasks": (i32, [C.POINTER(MergeDesc), vp, vp, vp, vp]),
     "cdet_nms_batched": (i32, [C.POINTER(NmsDesc), vp, vp, vp, vp, vp]),
     "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp]),
-    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, f32, f32, vp]),
+    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, C.POINTER(f32), i32, f32, f32, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

@@ -87,6 +87,17 @@ struct WgradHaloPlan {
 };
 bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out);
 int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s);
+// Tuning / ablation switches exist in profiling builds only (make EXTRA=-DCDET_PROFILING): several of them change results (dropped
+// statistics, skipped MFMAs), so the shipped library ignores the environment and always takes the default.
+static inline int tune_env(const char* name, int dflt) {
+#ifdef CDET_PROFILING
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 static inline int elem_size(int dtype) { return dtype == CDET_F32 ? 4 : (dtype == CDET_U8 ? 1 : 2); }
 
 }  // namespace cdet

@@ -1065,8 +1065,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const cdet_pa
 static int conv_impl() {
     static int impl = -1;
     if (impl < 0) {
-        const char* e = getenv("CDET_CONV_IMPL");
-        impl = e ? atoi(e) : 3;  // 1 = register-staged v1, 2 = global_load_lds v2, 3 = v2 tiles + software-pipelined K loop (v3)
+        impl = tune_env("CDET_CONV_IMPL", 3);  // 1 = register-staged v1, 2 = global_load_lds v2, 3 = v2 tiles + software-pipelined K loop (v3)
     }
     return impl;
 }
@@ -1087,8 +1086,7 @@ static void launch_glds(const ConvArgs& a, hipStream_t s) {
         if constexpr (DT == CDET_BF16 && WM == 2 && WN == 2 && DG == 0 && EPI == EPI_RAW && !F32) {
             static int abl = -1;
             if (abl < 0) {
-                const char* e = getenv("CDET_CONV_ABLATE");
-                abl = e ? atoi(e) : 0;
+                abl = tune_env("CDET_CONV_ABLATE", 0);
             }
             if (abl) {
 #define CDET_ABL_CASE(N)                                                                                                                       \
@@ -1138,8 +1136,7 @@ static int pick_cfg(int Cd, int64_t M) {
     if (Cd <= 80) return 0;
     static int deep = -1;
     if (deep < 0) {
-        const char* e = getenv("CDET_CONV_DEEP");
-        deep = e ? atoi(e) : 0;  // measured on MI355X: 0.129 vs 0.127 ms (40x40 320->320), 0.163 vs 0.144 ms (80x80 160->160): off by default
+        deep = tune_env("CDET_CONV_DEEP", 0);  // measured on MI355X: 0.129 vs 0.127 ms (40x40 320->320), 0.163 vs 0.144 ms (80x80 160->160): off by default
     }
     return (deep && conv_impl() >= 2 && M >= 4096) ? 2 : 1;
 }
@@ -1236,7 +1233,7 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
     a.y = y; a.stats = stats;
     {  // timing experiment only: CDET_CONV_NOSTATS=1 drops the BN partial statistics (results of the BN that follows are wrong)
         static int nostats = -1;
-        if (nostats < 0) { const char* e = getenv("CDET_CONV_NOSTATS"); nostats = e ? atoi(e) : 0; }
+        if (nostats < 0) nostats = tune_env("CDET_CONV_NOSTATS", 0);
         if (nostats) a.stats = nullptr;
     }
     a.N = d->N; a.Hs = d->Hs; a.Ws = d->Ws; a.Cs = d->Cs; a.Hd = d->Hd; a.Wd = d->Wd; a.Cd = d->Cd;

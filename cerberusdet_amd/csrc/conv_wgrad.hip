@@ -554,8 +554,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int wgrad_impl() {
     static int impl = -1;
     if (impl < 0) {
-        const char* e = getenv("CDET_WGRAD_IMPL");
-        impl = e ? atoi(e) : 3;  // 2 = register-staged single LDS stage, 3 = LDS-DMA + software-pipelined (default)
+        impl = tune_env("CDET_WGRAD_IMPL", 3);  // 2 = register-staged single LDS stage, 3 = LDS-DMA + software-pipelined (default)
     }
     return impl;
 }
@@ -583,8 +582,7 @@ static WgradPlan plan_wgrad(const cdet_conv_desc* d) {
     // round on the 12-tile layers), 512 14.4, 448 14.0, 256 20.9.
     static int target = -1;
     if (target < 0) {
-        const char* e = getenv("CDET_WGRAD_TARGET");
-        target = e ? atoi(e) : 512;
+        target = tune_env("CDET_WGRAD_TARGET", 512);
     }
     int S = target / tiles;
     const int maxS = (int)((P + 511) / 512);  // at least 512 pixels per split
@@ -608,7 +606,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     constexpr int YROW = BCO * 2 + ((BCO * 2) % 256 == 0 ? 32 : 0);
     const size_t lds = (size_t)WKP * (XROW + YROW);
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("CDET_WGRAD_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = tune_env("CDET_WGRAD_ABLATE", 0);
     const int ntiles = a.n_kblk * a.n_cblk;
     const dim3 grid(a.S >= 8 ? ntiles * ((a.S + 7) / 8 * 8) : 8 * ((ntiles + 8 / a.S - 1) / (8 / a.S)));
     const int64_t xb = (int64_t)a.N * a.Hs * a.Ws * a.src_ld * 2, yb = (int64_t)a.P * a.dy_ld * 2;

@@ -490,9 +490,49 @@ static WsLayout ws_layout(int N, int A, int n_max) {
     return L;
 }
 
+// Loss.preprocess (reference utils/loss.py:111-124): label rows (image index, class, normalised cx cy w h) -> gt[N][n_max][5]
+// (class, x1, y1, x2, y2 in pixels). A label's slot is the number of labels of the same image in front of it (the reference's
+// boolean-mask gather keeps file order). One thread per label; the label count of a batch is a few hundred.
+__global__ void pad_targets_kernel(const float* __restrict__ bidx, const float* __restrict__ cls, const float* __restrict__ box, int n, int N,
+                                   int n_max, float w, float h, float* __restrict__ gt, int* __restrict__ dropped) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float b = bidx[i];
+    const int img = (int)b;
+    if (img < 0 || img >= N) return;
+    int pos = 0;
+    for (int j = 0; j < i; ++j) pos += bidx[j] == b ? 1 : 0;
+    if (pos >= n_max) {  // the caller's n_max was too small: never overwrite another label silently
+        if (dropped) atomicAdd(dropped, 1);
+        return;
+    }
+    const float cx = box[4 * i] * w, cy = box[4 * i + 1] * h, bw = box[4 * i + 2] * w, bh = box[4 * i + 3] * h;
+    float* o = gt + ((int64_t)img * n_max + pos) * 5;
+    o[0] = cls[i];
+    o[1] = cx - bw / 2;
+    o[2] = cy - bh / 2;
+    o[3] = cx + bw / 2;
+    o[4] = cy + bh / 2;
+}
+
 }  // namespace cdet
 
 using namespace cdet;
+
+extern "C" int cdet_pad_targets(const float* batch_idx, const float* cls, const float* bboxes, int32_t n, int32_t N, int32_t n_max, float img_w,
+                                float img_h, float* gt, int32_t* dropped, void* stream) {
+    CDET_CHECK_ARG(gt && N > 0 && n_max > 0 && n >= 0, "cdet_pad_targets: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const hipError_t e = hipMemsetAsync(gt, 0, (size_t)N * n_max * 5 * sizeof(float), s);
+        CDET_CHECK_ARG(e == hipSuccess, "cdet_pad_targets: memset failed: %s", hipGetErrorString(e));
+    }
+    if (n == 0) return 0;
+    CDET_CHECK_ARG(batch_idx && cls && bboxes, "cdet_pad_targets: null label arrays");
+    hipLaunchKernelGGL(pad_targets_kernel, dim3((n + 127) / 128), dim3(128), 0, s, batch_idx, cls, bboxes, n, N, n_max, img_w, img_h, gt, dropped);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int64_t cdet_det_loss_ws_bytes(const cdet_loss_desc* d) {
     if (!d) return -1;

@@ -652,8 +652,7 @@ __global__ __launch_bounds__(256) void image_to_nhwc8_kernel(const void* __restr
 static int bn_rev() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("CDET_BN_REV");
-        v = e ? atoi(e) : 0;
+        v = tune_env("CDET_BN_REV", 0);
     }
     return v;
 }
@@ -708,10 +707,8 @@ extern "C" int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, con
 extern "C" int cdet_bn_bwd_blocks(int64_t M) {
     static int div = -1, cap = -1;
     if (div < 0) {
-        const char* e = getenv("CDET_BN_BWD_DIV");
-        const char* c = getenv("CDET_BN_BWD_CAP");
-        div = e ? atoi(e) : 64;  // measured per task pass (reduce + sums ms): 32/1024 3.16, 64/1024 3.15, 64/512 2.78, 128/512 2.90, 100/384 3.16
-        cap = c ? atoi(c) : 512;
+        div = tune_env("CDET_BN_BWD_DIV", 64);  // measured per task pass (reduce + sums ms): 32/1024 3.16, 64/1024 3.15, 64/512 2.78, 128/512 2.90, 100/384 3.16
+        cap = tune_env("CDET_BN_BWD_CAP", 512);
     }
     int64_t b = (M + div - 1) / div;  // >= `div` pixel rows per block, at most cap / 256 blocks per CU
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));

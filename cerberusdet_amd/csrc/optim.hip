@@ -38,9 +38,14 @@ __global__ __launch_bounds__(256) void sqnorm_finish_kernel(float* out, int n) {
     if (threadIdx.x == 0) out[0] = (float)sh[0];
 }
 
+struct GroupLr {
+    float v[4];
+};
+
 __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __restrict__ slots, const float* __restrict__ sqnorm, float max_norm,
-                                                      float momentum, float ema_decay) {
+                                                      GroupLr lrs, float momentum, float ema_decay) {
     const cdet_param_slot sl = slots[blockIdx.y];
+    const float lr = lrs.v[sl.group & 3];
     float coef = 1.f;
     if (sqnorm) {
         const float total = sqrtf(sqnorm[0]);
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __r
                 const f32x4 buf = sl.first_step ? g : momentum * Mo[i] + g;
                 Mo[i] = buf;
                 g += momentum * buf;
-                p -= sl.lr * g;
+                p -= lr * g;
                 P[i] = p;
                 G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __r
             float buf = sl.first_step ? g : momentum * sl.mom[i] + g;
             sl.mom[i] = buf;
             g += momentum * buf;  // nesterov
-            p -= sl.lr * g;
+            p -= lr * g;
             sl.p[i] = p;
             sl.g[i] = 0.f;        // optimizer.zero_grad()
         }
@@ -101,10 +106,12 @@ extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slot
     return 0;
 }
 
-extern "C" int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm, float momentum,
-                                 float ema_decay, void* stream) {
-    CDET_CHECK_ARG(slots_dev && n_slots > 0, "cdet_sgd_ema_step: bad arguments");
-    hipLaunchKernelGGL(sgd_ema_kernel, dim3(OPT_BLOCKS_PER_SLOT, n_slots), dim3(256), 0, (hipStream_t)stream, slots_dev, sqnorm, max_norm, momentum,
+extern "C" int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm, const float* lrs,
+                                 int32_t n_groups, float momentum, float ema_decay, void* stream) {
+    CDET_CHECK_ARG(slots_dev && n_slots > 0 && lrs && n_groups >= 1 && n_groups <= 4, "cdet_sgd_ema_step: bad arguments");
+    GroupLr gl{{0.f, 0.f, 0.f, 0.f}};
+    for (int i = 0; i < n_groups; ++i) gl.v[i] = lrs[i];
+    hipLaunchKernelGGL(sgd_ema_kernel, dim3(OPT_BLOCKS_PER_SLOT, n_slots), dim3(256), 0, (hipStream_t)stream, slots_dev, sqnorm, max_norm, gl, momentum,
                        ema_decay);
     CDET_LAUNCH_CHECK();
     return 0;

@@ -388,8 +388,8 @@ class CerberusDet(nn.Module):
         self._flush_bn_counters()
         return super().state_dict(*a, **k)
 
-    _RUNTIME_ATTRS = ("_plan_slots", "_stem_slots", "_pack_key", "_stem_key", "_wp", "_wpt", "_scale", "_bias", "_bias_pad",
-                      "_stem_scale", "_stem_bias", "_w8", "_gw8", "_stem8", "_wp_zeroed")
+    _RUNTIME_ATTRS = ("_plan_slots", "_pack_key", "_wp", "_wpt", "_scale", "_bias", "_bias_pad", "_w8", "_gw8", "_stem8", "_wp_zeroed",
+                      "_wt_f", "_wt_d")
 
     def _grad_buffer(self, p):
         g = self._pgrad.get(id(p))
@@ -493,7 +493,10 @@ class CerberusDet(nn.Module):
 
     def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False):
         """Same contract as the reference (cerberus.py:804-882): a `str` task -> that head's output, otherwise a dict.
-        train mode -> list of 3 raw maps [N, 64+nc, h, w]; eval mode -> (y [N, 4+nc, A], maps)."""
+        train mode -> list of 3 raw maps [N, 64+nc, h, w]; eval mode -> (y [N, 4+nc, A], maps).
+        Unlike the reference, which allocates fresh outputs per call, the returned tensors are VIEWS of the compiled plan's buffers:
+        the next forward of the same (tasks, shape, dtype, mode) overwrites them. Consume them (NMS, loss) or `.clone()` them before
+        calling the model again with the same configuration; CerberusDetInference and the trainer do the former."""
         if task_ids is None and hasattr(self, "cur_task"):
             task_ids = self.cur_task
         elif task_ids is None:

@@ -159,6 +159,7 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
                 batches[t] = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batches[t].items()}
             items.update(trainer.train_step(batches, ni=i + nb * epoch))
         torch.cuda.synchronize()
+        trainer.check_targets()
         results = {t: [float(v) for v in items[t].tolist()] for t in tasks if t in items}
         if RANK in (-1, 0):
             ips = nb * sum(bs) * WORLD_SIZE / (time.time() - t0)

@@ -98,6 +98,7 @@ class Averaging:
     def __init__(self, device, model, hyp: dict, task_ids: Sequence[str], epochs: int = 100, nb: int = 1000, loss_weights=None,
                  linear_lr=False, use_ema=True, rank=-1, world_size=1, sync_bn=False, task_streams: Optional[bool] = None):
         self.device, self.model, self.hyp, self.task_ids = device, model, hyp, list(task_ids)
+        self._gt_dropped = None
         # one HIP stream per task pass (see _run_tasks_on_streams); off under SyncBatchNorm, whose per-layer collectives must be
         # enqueued in one order on every rank
         if task_streams is None:
@@ -181,7 +182,9 @@ class Averaging:
         self._active = active_tasks
         plan.run_forward(img)
         head = self.model.get_head(task)
-        gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max)
+        if self._gt_dropped is None:
+            self._gt_dropped = torch.zeros(1, dtype=torch.int32, device=img.device)
+        gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max, dropped=self._gt_dropped)
         loss5 = plan.loss(task, gt, self.gains[task], grad_scale=float(self.loss_weights[task]))
         plan.run_backward()
         return loss5
@@ -246,7 +249,8 @@ class Averaging:
         idle = set(idle_blocks)
         live = [m["g"] is not None and m["p"].requires_grad and int(m["key"].split(".")[1]) not in idle for m in self.slots_meta]
         fresh = sum(1 for m, a in zip(self.slots_meta, live) if a and not m.get("stepped", True))
-        key = (tuple(lrs), fresh, tuple(sorted(n_serving.items())) if n_serving else None, hash(tuple(live)))
+        # (the learning rates are launch arguments, not table entries: the table is rebuilt only when its structure changes)
+        key = (fresh, tuple(sorted(n_serving.items())) if n_serving else None, hash(tuple(live)))
         if key != self._slot_key:
             for i, m in enumerate(self.slots_meta):
                 s = self._slots_host[i]
@@ -255,7 +259,7 @@ class Averaging:
                 s.mom = m["mom"].data_ptr() if m["mom"] is not None else None
                 s.ema = m["ema"].data_ptr() if m["ema"] is not None else None
                 if m["group"] >= 0:
-                    s.lr = lrs[m["group"]]
+                    s.group = m["group"]
                     s.weight_decay = self.weight_decay if m["group"] == 0 else 0.0
                     div = m["div"] if n_serving is None else max(n_serving.get(int(m["key"].split(".")[1]), 1), 1)
                     s.inv_div = 1.0 / div
@@ -268,8 +272,9 @@ class Averaging:
         if self.ema:
             self.ema.updates += 1
             d = self.ema.decay(self.ema.updates)
-        L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), 10.0, float(momentum), float(d), st),
-                "cdet_sgd_ema_step")
+        lr_arr = (C.c_float * len(lrs))(*[float(v) for v in lrs])
+        L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs),
+                                           float(momentum), float(d), st), "cdet_sgd_ema_step")
         if fresh:
             for m, a in zip(self.slots_meta, live):
                 if a:
@@ -295,6 +300,15 @@ class Averaging:
             idle = [i for i, ts in self.serving.items() if ts and not any(t in active for t in ts)]
         self.optimizer_step(lrs, mom, n_serving, idle)
         return out
+
+    def check_targets(self):
+        """Call where the training loop synchronises anyway (loss read-back): raises if a label did not fit the `n_max` given to
+        train_step() -- the sync-free target padding drops such labels (and counts them) instead of overwriting others."""
+        if self._gt_dropped is not None:
+            n = int(self._gt_dropped.item())
+            if n:
+                self._gt_dropped.zero_()
+                raise RuntimeError(f"{n} label(s) exceeded n_max in train_step(): pass a larger n_max (or None to size it per batch)")
 
     # ---------------------------------------------------------------------------------------------------- resume
     def state_dict(self):

@@ -12,48 +12,56 @@ import torch
 
 
 def make_divisible(x, divisor):
-    return math.ceil(x / divisor) * divisor
+    """Smallest multiple of `divisor` that is >= x (reference general.py:206-208)."""
+    q, r = divmod(x, divisor)
+    return int(q + (1 if r else 0)) * divisor
 
 
 def check_img_size(img_size, s=32):
-    new_size = make_divisible(img_size, int(s))
-    return new_size
+    """Image side rounded up to the model stride (reference general.py:122-127; the warning print is left out)."""
+    return make_divisible(img_size, int(s))
 
 
 def one_cycle(y1=0.0, y2=1.0, steps=100):
-    return lambda x: ((1 - math.cos(x * math.pi / steps)) / 2) * (y2 - y1) + y1
+    """Cosine ramp from y1 (x = 0) to y2 (x = steps), the reference's lr schedule factor (general.py:211-213)."""
+    span = y2 - y1
+
+    def ramp(x):
+        return y1 + span * 0.5 * (1.0 - math.cos(math.pi * x / steps))
+
+    return ramp
+
+
+def _cat(parts, like):
+    return torch.cat(parts, dim=-1) if isinstance(like, torch.Tensor) else np.concatenate(parts, axis=-1)
 
 
 def xywh2xyxy(x):
-    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
-    y[..., 0] = x[..., 0] - x[..., 2] / 2
-    y[..., 1] = x[..., 1] - x[..., 3] / 2
-    y[..., 2] = x[..., 0] + x[..., 2] / 2
-    y[..., 3] = x[..., 1] + x[..., 3] / 2
-    return y
+    """[..., (cx, cy, w, h, extra...)] -> [..., (x1, y1, x2, y2, extra...)] as a new array (reference general.py:272-288)."""
+    centre, half = x[..., 0:2], x[..., 2:4] / 2
+    return _cat([centre - half, centre + half, x[..., 4:]], x)
 
 
 def clip_boxes(boxes, shape):
-    if isinstance(boxes, torch.Tensor):
-        boxes[..., 0].clamp_(0, shape[1])
-        boxes[..., 1].clamp_(0, shape[0])
-        boxes[..., 2].clamp_(0, shape[1])
-        boxes[..., 3].clamp_(0, shape[0])
-    else:
-        boxes[..., [0, 2]] = boxes[..., [0, 2]].clip(0, shape[1])
-        boxes[..., [1, 3]] = boxes[..., [1, 3]].clip(0, shape[0])
+    """Clamp xyxy boxes in place to an image of shape (h, w) (reference general.py:345-357)."""
+    h, w = shape[0], shape[1]
+    for col, hi in ((0, w), (1, h), (2, w), (3, h)):
+        if isinstance(boxes, torch.Tensor):
+            boxes[..., col].clamp_(0, hi)
+        else:
+            np.clip(boxes[..., col], 0, hi, out=boxes[..., col])
 
 
 def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
-    if ratio_pad is None:
-        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
-        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    """Map xyxy boxes (in place) from the letterboxed frame img1_shape back to the original frame img0_shape: remove the padding,
+    divide by the resize gain, clamp (reference general.py:313-342)."""
+    if ratio_pad is not None:
+        gain, (pad_x, pad_y) = ratio_pad[0][0], ratio_pad[1]
     else:
-        gain = ratio_pad[0][0]
-        pad = ratio_pad[1]
-    boxes[..., [0, 2]] -= pad[0]
-    boxes[..., [1, 3]] -= pad[1]
-    boxes[..., :4] /= gain
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad_x, pad_y = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    for col, pad in ((0, pad_x), (1, pad_y), (2, pad_x), (3, pad_y)):
+        boxes[..., col] = (boxes[..., col] - pad) / gain
     clip_boxes(boxes, img0_shape)
     return boxes
 
@@ -79,9 +87,14 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
 
 
 def box_iou(box1, box2, eps=1e-7):
-    (a1, a2), (b1, b2) = box1.unsqueeze(1).chunk(2, 2), box2.unsqueeze(0).chunk(2, 2)
-    inter = (torch.min(a2, b2) - torch.max(a1, b1)).clamp(0).prod(2)
-    return inter / ((a2 - a1).prod(2) + (b2 - b1).prod(2) - inter + eps)
+    """Pairwise IoU of xyxy boxes: [n,4] x [m,4] -> [n,m]."""
+    lt = torch.maximum(box1[:, None, :2], box2[None, :, :2])
+    rb = torch.minimum(box1[:, None, 2:4], box2[None, :, 2:4])
+    wh = (rb - lt).clamp_(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area1 = (box1[:, 2] - box1[:, 0]) * (box1[:, 3] - box1[:, 1])
+    area2 = (box2[:, 2] - box2[:, 0]) * (box2[:, 3] - box2[:, 1])
+    return inter / (area1[:, None] + area2[None, :] - inter + eps)
 
 
 def nms_between_tasks(bboxes: torch.Tensor, categories_map_per_task: Dict[str, Dict[int, int]], iou_thres: float) -> torch.Tensor:

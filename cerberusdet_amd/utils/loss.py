@@ -9,33 +9,32 @@ import torch
 from .torch_utils import get_hyperparameter
 
 
-def pad_targets(batch, batch_size, imgsz_hw, device, n_max=None):
-    """Loss.preprocess (reference loss.py:111-124) without the python loop over images:
-    labels [n] -> [bs, n_max, 5] (cls, x1, y1, x2, y2 in pixels), zero rows = padding."""
-    bi = batch["batch_idx"].to(device).view(-1).long()
+def pad_targets(batch, batch_size, imgsz_hw, device, n_max=None, dropped=None):
+    """Loss.preprocess (reference loss.py:111-124) as ONE kernel (csrc/det_loss.hip, cdet_pad_targets):
+    labels [n] -> gt [bs, n_max, 5] (cls, x1, y1, x2, y2 in pixels), zero rows = padding, file order kept inside an image.
+    n_max=None: sized from the batch like the reference (`counts.max()`, loss.py:117 -- one host sync). With n_max given there is
+    no sync; a label that does not fit is dropped and counted in `dropped` (device int32[1]) -- the trainer checks it at its
+    once-per-iteration sync, so an undersized n_max fails loudly instead of corrupting targets."""
+    import ctypes as C
+
+    from .. import _lib as L
+    from ..ops import ptr, stream
+
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("cerberusdet_amd.pad_targets runs on the MI355X only (there is no CPU path)")
+    bi = batch["batch_idx"].to(device=device, dtype=torch.float32).reshape(-1).contiguous()
     n = bi.numel()
-    if n == 0:
-        return torch.zeros(batch_size, 1, 5, device=device)
-    cls = batch["cls"].to(device).view(-1).float()
-    box = batch["bboxes"].to(device).float()
-    order = torch.argsort(bi, stable=True)
-    bi, cls, box = bi[order], cls[order], box[order]
-    counts = torch.zeros(batch_size, dtype=torch.int64, device=device).index_add_(0, bi, torch.ones_like(bi))
-    sync_free = n_max is not None  # caller guarantees n_max >= labels per image: no device->host sync at all
     if n_max is None:
-        n_max = int(counts.max())  # one host sync (the reference has `counts.max()` as well, loss.py:117)
-    start = torch.cumsum(counts, 0) - counts
-    pos = torch.arange(n, device=device) - start[bi]
+        n_max = int(torch.bincount(bi.long(), minlength=batch_size).max()) if n else 0
+    n_max = max(int(n_max), 1)
+    cls = batch["cls"].to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    box = batch["bboxes"].to(device=device, dtype=torch.float32).reshape(-1, 4).contiguous()
+    out = torch.empty(batch_size, n_max, 5, device=device)
     h, w = imgsz_hw
-    scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=device)
-    xywh = box * scale
-    xyxy = torch.stack((xywh[:, 0] - xywh[:, 2] / 2, xywh[:, 1] - xywh[:, 3] / 2, xywh[:, 0] + xywh[:, 2] / 2, xywh[:, 1] + xywh[:, 3] / 2), 1)
-    out = torch.zeros(batch_size, max(n_max, 1), 5, device=device)
-    vals = torch.cat((cls[:, None], xyxy), 1)
-    if sync_free:
-        out.index_put_((bi, pos.clamp(max=max(n_max, 1) - 1)), vals)
-    else:
-        out[bi, pos] = vals
+    lib = L.load()
+    L.check(lib.cdet_pad_targets(ptr(bi), ptr(cls), ptr(box), n, batch_size, n_max, float(w), float(h), ptr(out), ptr(dropped), stream()),
+            "cdet_pad_targets")
     return out
 
 

@@ -255,6 +255,11 @@ typedef struct {
     int32_t topk;                  /* 10                                                             */
     float alpha, beta;             /* 0.5, 6.0                                                       */
 } cdet_loss_desc;
+/* Loss.preprocess (utils/loss.py:111-124): n label rows -> gt [N, n_max, 5] fp32 (cls, x1, y1, x2, y2 px), zero rows = padding.
+ * batch_idx / cls: [n] fp32, bboxes: [n, 4] fp32 normalised (cx, cy, w, h). Labels keep their order inside an image. A label
+ * that does not fit n_max is dropped and counted in *dropped (device int32, may be NULL; never reset here). */
+int cdet_pad_targets(const float* batch_idx, const float* cls, const float* bboxes, int32_t n, int32_t N, int32_t n_max,
+                     float img_w, float img_h, float* gt, int32_t* dropped, void* stream);
 int64_t cdet_det_loss_ws_bytes(const cdet_loss_desc* d);
 /* gt: [N, n_max, 5] fp32 (cls, x1, y1, x2, y2 in pixels; rows with box sum <= 0 are padding, loss.py:155);
  * n_max >= 1 (pass one all-zero row per image when the batch has no labels).
@@ -319,15 +324,18 @@ int cdet_match_predictions(const cdet_match_desc* d, const float* det_rows, cons
 typedef struct {
     float* p; float* g; float* mom; float* ema;   /* ema may be NULL */
     int64_t n;
-    float lr, weight_decay, inv_div;              /* inv_div = 1 / #tasks served by the block */
+    int32_t group;                                /* index into the step's lr array (the reference's 3 param groups) */
+    float weight_decay, inv_div;                  /* inv_div = 1 / #tasks served by the block */
     int32_t first_step;                           /* momentum buffer uninitialised            */
 } cdet_param_slot;
 /* sum of squares of all gradients -> out[0]; `out` must hold 1 + 32*n_slots floats (block partials, fixed-order reduce).
  * A slot with g == NULL takes part in the EMA only (BatchNorm running statistics). */
 int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, void* stream);
-/* clip by global norm (coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))), per-block division, SGD-nesterov, EMA, zero grad */
+/* clip by global norm (coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))), per-block division, SGD-nesterov, EMA, zero grad.
+ * lrs: HOST array of n_groups (<= 4) learning rates, passed by value with the launch -- the slot table does not change while the
+ * warm-up / schedule moves the rates (trainers/averaging.py:160-180 of the reference recomputes them every iteration). */
 int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm,
-                      float momentum, float ema_decay, void* stream);
+                      const float* lrs, int32_t n_groups, float momentum, float ema_decay, void* stream);
 
 #ifdef __cplusplus
 }

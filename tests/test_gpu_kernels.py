@@ -4,6 +4,7 @@ Inputs are made exactly representable in the storage dtype first, so the only di
 order and the single output rounding: tolerance 2^-8 relative (one bf16 ulp) for bf16 outputs, 1e-4 for fp32 outputs.
 Integer outputs (label assignment, NMS rows) are compared bit-exactly.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -397,14 +398,15 @@ def test_sgd_ema_step_matches_oracle():
         for i, k in enumerate(keys):
             grp = oo.param_group(k)
             slots[i].p, slots[i].g, slots[i].mom, slots[i].ema = wd[k].data_ptr(), gd[k].data_ptr(), md[k].data_ptr(), ed[k].data_ptr()
-            slots[i].n, slots[i].lr = wd[k].numel(), lrs[grp]
+            slots[i].n, slots[i].group = wd[k].numel(), grp
             slots[i].weight_decay = 0.00037 if grp == 0 else 0.0
             slots[i].inv_div, slots[i].first_step = 1.0 / serving[oo.block_of(k)], int(step == 0)
         sdev = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(DEV)
         out = torch.zeros(1 + 32 * len(keys), device=DEV)
         L.check(lib.cdet_grad_sqnorm(sdev.data_ptr(), len(keys), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
         d = oo.ema_decay(upd + 1)
-        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, 0.952, d, torch.cuda.current_stream().cuda_stream))
+        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d,
+                                      torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         total = oo.optimizer_step(wref, {k: v.clone() for k, v in gr.items()}, mom_ref, serving, lr=lrs, momentum=0.952, weight_decay=0.00037)
         upd = oo.ema_update(eref, wref, upd)

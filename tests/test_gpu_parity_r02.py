@@ -214,3 +214,26 @@ def test_gpu_letterbox_preprocess_bit_exact_vs_oracle(half):
     a = pre2.preprocess(images[:1] * 2, torch.device(DEV))
     w2 = op.preprocess(images[:1] * 2, 640, 32, half=half, auto=True)
     assert tuple(a.shape) == w2.shape == (2, 3, 384, 640) and np.array_equal(a.cpu().numpy(), w2)
+
+
+def test_pad_targets_kernel_matches_oracle_and_counts_overflow():
+    """cdet_pad_targets (one kernel, no host sync with n_max given) against the oracle's Loss.preprocess restatement: order inside an
+    image, empty images, empty batch; a label beyond n_max is dropped and counted, never written over another one."""
+    from cerberusdet_amd.utils.loss import pad_targets
+
+    dev = torch.device("cuda", 0)
+    b = synth.make_batch(6, 3, 20, 7, empty_images=(2, 5))
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    want = ol.pad_targets(tb["batch_idx"], tb["cls"], tb["prob"], tb["bboxes"], 6, torch.tensor([128.0, 96.0, 128.0, 96.0]))
+    want = torch.cat((want[..., :1], want[..., 2:]), -1)
+    got = pad_targets(tb, 6, (96, 128), dev)
+    assert got.shape == want.shape and torch.allclose(got.cpu(), want, rtol=0, atol=1e-4)
+    dropped = torch.zeros(1, dtype=torch.int32, device=dev)
+    wide = pad_targets(tb, 6, (96, 128), dev, n_max=want.shape[1] + 3, dropped=dropped)
+    assert torch.equal(wide[:, :want.shape[1]].cpu(), got.cpu()) and float(wide[:, want.shape[1]:].abs().sum()) == 0 and int(dropped) == 0
+    counts = np.bincount(b["batch_idx"].astype(np.int64).ravel(), minlength=6)
+    cut = int(counts.max()) - 1
+    short = pad_targets(tb, 6, (96, 128), dev, n_max=cut, dropped=dropped)
+    assert torch.equal(short.cpu(), got[:, :cut].cpu())
+    assert int(dropped) == int(np.maximum(counts - cut, 0).sum())
+    assert pad_targets({k: v[:0] for k, v in tb.items()}, 6, (96, 128), dev).shape == (6, 1, 5)

@@ -106,17 +106,12 @@ def test_split_clones_weights_and_rewires(which):
     assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["state_shapes"]
 
 
-def test_pad_targets_matches_oracle():
+def test_pad_targets_has_no_cpu_path():
     from cerberusdet_amd.utils.loss import pad_targets
-    from oracle import loss as ol
 
-    b = synth.make_batch(4, 3, 20, 5, empty_images=(2,))
-    tb = {k: torch.from_numpy(v) for k, v in b.items()}
-    got = pad_targets(tb, 4, (96, 128), "cpu")
-    want = ol.pad_targets(tb["batch_idx"], tb["cls"], tb["prob"], tb["bboxes"], 4, torch.tensor([128.0, 96.0, 128.0, 96.0]))
-    assert torch.allclose(got, torch.cat((want[..., :1], want[..., 2:]), -1))
-    assert torch.equal(pad_targets(tb, 4, (96, 128), "cpu", n_max=3), got)
-    assert pad_targets({k: v[:0] for k, v in tb.items()}, 4, (96, 128), "cpu").shape == (4, 1, 5)
+    b = synth.make_batch(2, 3, 20, 5)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        pad_targets({k: torch.from_numpy(v) for k, v in b.items()}, 2, (96, 128), "cpu")
 
 
 def test_lr_schedule_and_param_groups_match_oracle():
