@@ -440,10 +440,21 @@ def main():
             tot = sum(a["ms"] for a in agg.values())
             out["kernel_ms"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
             out["kernel_ms_total"] = round(tot, 3)
-            dom = max((k for k in agg if agg[k]["flops"] > 0), key=lambda k: agg[k]["ms"])
-            a = agg[dom]
+            # the dominant GPU kernel: the two tiled entry points (forward and stride-1 data gradient) launch the same
+            # conv_halo_kernel, so they are one row here
+            kern_of = {"cdet_conv2d_tiled[fwd]": "conv_halo_kernel", "cdet_conv2d_tiled[dgrad]": "conv_halo_kernel"}
+            merged = {}
+            for k, v in agg.items():
+                if v["flops"] > 0:
+                    m = merged.setdefault(kern_of.get(k, k), {"ms": 0.0, "flops": 0.0, "n": 0, "entries": []})
+                    m["ms"] += v["ms"]
+                    m["flops"] += v["flops"]
+                    m["n"] += v["n"]
+                    m["entries"].append(k)
+            dom = max(merged, key=lambda k: merged[k]["ms"])
+            a = merged[dom]
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            out["roofline"] = {"kernel": dom, "entry_points": a["entries"], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": a["n"],
                                "avg_launch_ms": round(a["ms"] / a["n"], 4), "algorithmic_gflop_per_launch": round(a["flops"] / a["n"] / 1e9, 3),
                                "measured": "HIP events around every call of a sequential replay of one iteration (task streams off)"}
@@ -453,8 +464,8 @@ def main():
             if tf:
                 kern = json.load(open(tf[-1]))["kernels"]
                 fam = [f"conv_igemm_{v}_kernel<0, {t}" for v in ("pipe", "glds") for t in ("2, 2", "3, 1", "4, 2")]
-                main, extra = {"cdet_conv2d_tiled[fwd]": (("conv_halo_kernel",), ()), "cdet_conv2d_tiled[dgrad]": (("conv_halo_kernel",), ()),
-                               "cdet_conv2d_wgrad": (("conv_wgrad_pipe_kernel", "conv_wgrad_kernel"), ("wgrad_reduce",)),
+                main, extra = {"conv_halo_kernel": (("conv_halo_kernel",), ()),
+                               "cdet_conv2d_wgrad": (("wgrad_halo_kernel", "conv_wgrad_pipe_kernel", "conv_wgrad_kernel"), ("wgrad_reduce",)),
                                "cdet_conv2d[fwd]": (tuple(f"{f}, 0," for f in fam), ()),
                                "cdet_conv2d[dgrad]": (tuple(f"{f}, {m}," for f in fam for m in (1, 2)), ())}[dom]
                 sel = [v for k, v in kern.items() if k.startswith(main + extra)]
