@@ -58,6 +58,10 @@ class MatchDesc(C.Structure):
     _fields_ = [("N", i32), ("max_det", i32), ("T", i32), ("max_labels", i32)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("dw", vp), ("src_ld", i32), ("src_coff", i32)]
+
+
 class ParamSlot(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("group", i32), ("weight_decay", f32),
                 ("inv_div", f32), ("first_step", i32)]
@@ -80,6 +84,9 @@ _SIGS = {
     "cdet_pack_weight_tiled": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cdet_conv2d_wgrad_ws_elems": (i64, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_wgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp]),
+    "cdet_conv2d_wgrad_groupable": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_wgrad_grouped_ws_elems": (i64, [C.POINTER(ConvDesc), i32]),
+    "cdet_conv2d_wgrad_grouped": (i32, [C.POINTER(ConvDesc), vp, i32, vp, i32, vp]),
     "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "cdet_image_to_nhwc8": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_stem_conv_stat_blocks": (i32, [i32, i32, i32]),

@@ -85,8 +85,10 @@ struct WgradHaloPlan {
     int S, chunk, Kp, Cd_pad, n_cblk, n_iblk, XH, nci;
     size_t lds;
 };
-bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out);
-int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s);
+bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items = 1);
+// items == nullptr: one layer (x, dy); else n_items layers of the same geometry, tensors from the device table
+int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s,
+                      const cdet_wgrad_item* items_dev = nullptr, int n_items = 1);
 // Tuning / ablation switches exist in profiling builds only (make EXTRA=-DCDET_PROFILING): several of them change results (dropped
 // statistics, skipped MFMAs), so the shipped library ignores the environment and always takes the default.
 static inline int tune_env(const char* name, int dflt) {

@@ -519,9 +519,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_elem_kernel(const float* __r
 // KH*KW floats apart: 4x write amplification in the PMC counters).
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int S, int O, int Cd_pad, int I,
-                                                          int Kp, int accumulate) {
+                                                          int Kp, int accumulate, const cdet_wgrad_item* __restrict__ items) {
     const int64_t total = (int64_t)O * I * KH;
     const int64_t slab = (int64_t)Cd_pad * Kp;
+    if (items != nullptr) {  // grouped launch: blockIdx.y = layer, its S slabs are consecutive
+        ws += (int64_t)blockIdx.y * S * slab;
+        dw = items[blockIdx.y].dw;
+    }
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int kh = (int)(idx % KH);
         const int64_t oi = idx / KH;
@@ -688,9 +692,41 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     } else {
         int blocks = (int)((rows + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<3, 3>), dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, p.Kp, accumulate);
-        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, p.Kp, accumulate);
+        if (taps == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<3, 3>), dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, p.Kp, accumulate,
+                                          (const cdet_wgrad_item*)nullptr);
+        else hipLaunchKernelGGL((wgrad_reduce_kernel<1, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, p.S, d->Cd, p.Cd_pad, d->Cs, p.Kp, accumulate,
+                                (const cdet_wgrad_item*)nullptr);
     }
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t cdet_conv2d_wgrad_groupable(const cdet_conv_desc* d) {
+    WgradHaloPlan hp;
+    return d && d->mode == CDET_CONV_FWD && wgrad_halo_plan(d, &hp) ? 1 : 0;
+}
+
+extern "C" int64_t cdet_conv2d_wgrad_grouped_ws_elems(const cdet_conv_desc* d, int32_t n_items) {
+    WgradHaloPlan hp;
+    if (!d || n_items < 1 || !wgrad_halo_plan(d, &hp, n_items)) return -1;
+    return (int64_t)n_items * hp.S * hp.Cd_pad * hp.Kp;
+}
+
+extern "C" int cdet_conv2d_wgrad_grouped(const cdet_conv_desc* d, const cdet_wgrad_item* items_dev, int32_t n_items, float* ws, int32_t accumulate,
+                                         void* stream) {
+    CDET_CHECK_ARG(d && items_dev && ws && n_items >= 1, "cdet_conv2d_wgrad_grouped: bad arguments");
+    CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_wgrad_grouped: descriptor must describe the forward convolution");
+    CDET_CHECK_ARG(d->dst_ld % 8 == 0 && d->dst_coff % 8 == 0, "cdet_conv2d_wgrad_grouped: dy ld/coff must be multiples of 8");
+    WgradHaloPlan hp;
+    CDET_CHECK_ARG(wgrad_halo_plan(d, &hp, n_items), "cdet_conv2d_wgrad_grouped: geometry not groupable (see cdet_conv2d_wgrad_groupable)");
+    hipStream_t s = (hipStream_t)stream;
+    const int e = wgrad_halo_launch(d, hp, nullptr, nullptr, ws, s, items_dev, n_items);
+    if (e) return e;
+    const int64_t rows = (int64_t)d->Cd * d->Cs * 3;
+    int blocks = (int)((rows + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<3, 3>), dim3(blocks, n_items), dim3(256), 0, s, ws, (float*)nullptr, hp.S, d->Cd, hp.Cd_pad, d->Cs, hp.Kp, accumulate,
+                       items_dev);
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -38,6 +38,7 @@ struct WHArgs {
     int chunk, S;
     int n_cblk, n_iblk;
     int XH;  // halo rows per stage (multiple of 32)
+    const cdet_wgrad_item* items;  // grouped launch: per-layer tensors (nullptr: the single layer above)
     unsigned magicW, magicH;  // 2^32 / W + 1, 2^32 / H + 1: exact quotients by v_mul_hi for every pixel index of the path
     unsigned x_bytes, dy_bytes;
 };
@@ -109,8 +110,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
         L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + j;
     }
     const int ntiles = a.n_cblk * a.n_iblk;
-    const int split = L / ntiles;
-    const int tile = L - split * ntiles;
+    const int slab_id = L / ntiles;  // (layer, split): the slab this workgroup writes
+    const int tile = L - slab_id * ntiles;
+    const int layer = slab_id / a.S;
+    const int split = slab_id - layer * a.S;
+    const uint16_t* xptr = a.x;
+    const uint16_t* dyptr = a.dy;
+    int src_ld = a.src_ld, src_coff = a.src_coff;
+    unsigned x_bytes = a.x_bytes;
+    if (a.items != nullptr) {  // wave-uniform index: scalar loads
+        const cdet_wgrad_item it = a.items[layer];
+        xptr = (const uint16_t*)it.x;
+        dyptr = (const uint16_t*)it.dy;
+        src_ld = it.src_ld;
+        src_coff = it.src_coff;
+        x_bytes = (unsigned)a.M * (unsigned)src_ld * 2u;
+    }
     const int cblk = tile / a.n_iblk, iblk = tile - cblk * a.n_iblk;
     const int c0 = cblk * 160, i0 = iblk * 16 * NCI;
     const int pbeg = split * a.chunk;
@@ -122,15 +137,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     const int ZOFF = 2 * STAGE;
     for (int i = t; i < WH_ZERO / 4; i += 512) reinterpret_cast<uint32_t*>(smem + ZOFF)[i] = 0u;
 
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xptr, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)dyptr, 0, (int)a.dy_bytes, 0x00020000);
 
     // ---- DMA duties of this wave (1 KiB = one instruction each; out-of-range offsets fetch zeros, which covers the rows above the
     //      first and below the last pixel of the tensor, and every pixel >= M of a ragged last stage):
     //   dY image di = wave + 8*idx (idx 0..4) = (16-pixel block di/5, cout pair di%5); lane -> (cout group lane>>5, pixel (lane>>1)&15,
     //      16-byte half lane&1): 64 contiguous bytes per pixel;
     //   X piece xi = wave + 8*idx = (32-row block xi / NCI, plane xi % NCI); lane -> (row lane>>1, half lane&1).
-    const int ldyB = a.dy_ld * 2, ldxB = a.src_ld * 2;
+    const int ldyB = a.dy_ld * 2, ldxB = src_ld * 2;
     const int nxp = NCI * (a.XH >> 5);
     const int yco_l = (lane >> 5) * 16 + (lane & 1) * 8;
     const unsigned ydl = (unsigned)(((lane >> 1) & 15) * ldyB + yco_l * 2);
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             if (xi < nxp) {
                 const int blk = xi / NCI, pl = xi - blk * NCI;
                 // (rows above the tensor give a negative pixel: the 32-bit offset wraps far beyond the buffer -> zeros)
-                const unsigned sc = (unsigned)((pb0 + blk * 32 - (W + 1)) * ldxB + (a.src_coff + i0 + pl * 16) * 2);
+                const unsigned sc = (unsigned)((pb0 + blk * 32 - (W + 1)) * ldxB + (src_coff + i0 + pl * 16) * 2);
                 wh_dma16(rs_x, xdl + sc, base + WH_DYB + pl * XP + blk * 1024);
             }
         }
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     }
     // ---- partial slab: C[ci][co] tiles -> ws[split][co][tap*Cs + ci], 4 consecutive cins per lane
     if (half == 0) {
-        float* wsp = a.ws + (int64_t)split * a.Cd_pad * a.Kp;
+        float* wsp = a.ws + (int64_t)slab_id * a.Cd_pad * a.Kp;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int co = c0 + (wco * 5 + j) * 16 + li;
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
+bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1)) return false;
     if (d->Hs != d->Hd || d->Ws != d->Wd) return false;
     if (d->Cs % 32 != 0 || d->Cd < 128) return false;  // an 80-cout layer would leave half of the 160-cout tile empty
@@ -319,8 +334,8 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     if (M * d->src_ld * 2 >= 0xC0000000ll || M * d->dst_ld * 2 >= 0xC0000000ll) return false;
     if (M >= (1 << 24)) return false;  // the magic-multiply quotients are exact far beyond this; keep a wide margin
     const int n_cblk = div_up(d->Cd, 160), n_iblk = d->Cs / (16 * nci);
-    const int tiles = n_cblk * n_iblk;
-    if (tiles > 256) return false;
+    const int tiles = n_cblk * n_iblk * (n_items < 1 ? 1 : n_items);  // a grouped launch spreads the CUs over all its layers
+    if (n_cblk * n_iblk > 256) return false;
     // one workgroup per CU: the largest split count that keeps the grid within one round; every split costs a slab write + re-read
     int S = 256 / tiles;
     const int maxS = (int)((M + 511) / 512);  // at least 512 pixels (4 stages) per split
@@ -351,9 +366,11 @@ static void wgrad_halo_launch_t(const WHArgs& a, int grid, size_t lds, hipStream
     hipLaunchKernelGGL((wgrad_halo_kernel<DT, NCI>), dim3(grid), dim3(512), lds, s, a);
 }
 
-int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s) {
+int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s,
+                      const cdet_wgrad_item* items_dev, int n_items) {
     WHArgs a;
     a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.ws = ws;
+    a.items = items_dev;
     a.H = d->Hs; a.W = d->Ws; a.M = d->N * d->Hs * d->Ws;
     a.Cs = d->Cs; a.Cd = (d->Cd + 7) / 8 * 8;
     a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dy_ld = d->dst_ld; a.dy_coff = d->dst_coff;
@@ -362,7 +379,7 @@ int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const voi
     a.magicH = (unsigned)((1ull << 32) / (unsigned)a.H + 1);
     a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
     a.dy_bytes = (unsigned)((int64_t)a.M * d->dst_ld * 2);
-    const int grid = p.S * p.n_cblk * p.n_iblk;
+    const int grid = (items_dev ? n_items : 1) * p.S * p.n_cblk * p.n_iblk;
     if (d->dtype == CDET_BF16) {
         if (p.nci == 4) wgrad_halo_launch_t<CDET_BF16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_BF16, 2>(a, grid, p.lds, s);

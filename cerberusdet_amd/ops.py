@@ -151,6 +151,26 @@ def conv2d_wgrad(src: View, dy: View, dw: torch.Tensor, k, s, accumulate=False, 
     return dw
 
 
+def conv2d_wgrad_grouped(items, k, s, accumulate=False):
+    """items: [(src View, dy View, dw fp32 OIHW)] of identical geometry -> one launch (cdet_conv2d_wgrad_grouped)."""
+    lib = L.load()
+    src0, dy0, dw0 = items[0]
+    d = conv_desc(src0, dy0, k, s)
+    d.Cd = dw0.shape[0]
+    d.src_ld = max(it[0].ld for it in items)  # bounds check of the 32-bit DMA offsets uses the widest view
+    assert lib.cdet_conv2d_wgrad_groupable(C.byref(d)), "geometry is not taken by the tap-resident weight-gradient kernel"
+    tab = (L.WgradItem * len(items))()
+    for i, (src, dy, dw) in enumerate(items):
+        assert (src.N, src.H, src.W, src.C) == (src0.N, src0.H, src0.W, src0.C) and (dy.ld, dy.coff, dy.C) == (dy0.ld, dy0.coff, dy0.C)
+        assert dw.shape == dw0.shape and dw.dtype == torch.float32 and dw.is_contiguous()
+        tab[i].x, tab[i].dy, tab[i].dw, tab[i].src_ld, tab[i].src_coff = ptr(src), ptr(dy), dw.data_ptr(), src.ld, src.coff
+    tab_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dw0.device)
+    n = lib.cdet_conv2d_wgrad_grouped_ws_elems(C.byref(d), len(items))
+    ws = torch.empty(n, dtype=torch.float32, device=dw0.device)
+    L.check(lib.cdet_conv2d_wgrad_grouped(C.byref(d), tab_dev.data_ptr(), len(items), ptr(ws), int(accumulate), stream()), "cdet_conv2d_wgrad_grouped")
+    return [it[2] for it in items]
+
+
 def stem_conv(img: torch.Tensor, w: torch.Tensor, dst: View, scale=None, bias=None, act=L.ACT_NONE, stats=None):
     lib = L.load()
     N, c, H, W = img.shape

@@ -144,6 +144,22 @@ int64_t cdet_conv2d_wgrad_ws_elems(const cdet_conv_desc* d);
 int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const void* dy, float* dw_oihw, float* ws,
                       int32_t accumulate, void* stream);
 
+/* Weight gradients of n layers of IDENTICAL geometry in one launch (the 2n Bottleneck convolutions of a C2f block: each is its own
+ * autograd convolution_backward(weight) in the reference, models/common.py:107-117). One workgroup per CU over ALL layers, so the
+ * pixel split per layer -- and with it the fp32 partial-slab round trip -- shrinks by n. `d` carries the shared geometry (N, H, W, Cs,
+ * Cd, dtype, dst_ld/dst_coff of dy); each item its own tensors and the channel stride / offset of its x view.
+ * cdet_conv2d_wgrad_groupable(d): 1 when the tap-resident kernel takes the geometry (stride-1 3x3, Cs % 32 == 0, Cd >= 128). */
+typedef struct {
+    const void* x;      /* source activation view (NHWC), channel stride src_ld, first channel src_coff */
+    const void* dy;     /* gradient of the convolution output, layout d->dst_ld / d->dst_coff             */
+    float* dw;          /* fp32 OIHW [Cd, Cs, 3, 3]                                                       */
+    int32_t src_ld, src_coff;
+} cdet_wgrad_item;
+int32_t cdet_conv2d_wgrad_groupable(const cdet_conv_desc* d);
+int64_t cdet_conv2d_wgrad_grouped_ws_elems(const cdet_conv_desc* d, int32_t n_items);
+int cdet_conv2d_wgrad_grouped(const cdet_conv_desc* d, const cdet_wgrad_item* items_dev, int32_t n_items, float* ws,
+                              int32_t accumulate, void* stream);
+
 /* Stem convolution (models/common.py:57 for the first backbone row, Cin = 3): reads the image in the
  * reference's NCHW layout (uint8 scaled by 1/255 -- trainers/base_trainer.py:61-63 -- or float), 3x3 stride 2 pad 1,
  * writes NHWC. Direct (non-MFMA) kernel: K = 27, HBM-bound. Same epilogue/stat semantics as cdet_conv2d. */

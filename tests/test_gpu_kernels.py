@@ -181,6 +181,46 @@ def test_conv_wgrad_tap_resident(case, tile, monkeypatch):
     _close(dw, 2 * w.grad, 2e-3, 4e-3 * float(w.grad.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 20, 20, 64, 160, 5, torch.bfloat16), (1, 40, 40, 32, 136, 3, torch.float16), (1, 24, 24, 96, 320, 14, torch.bfloat16)])
+def test_conv_wgrad_grouped_launch(case):
+    """cdet_conv2d_wgrad_grouped: G layers of one geometry (x views at different channel offsets of wider buffers, like the Bottleneck
+    inputs inside a C2f concat buffer) in one launch == G single launches, and == autograd; accumulate doubles."""
+    ops = _ops()
+    N, H, W, Ci, Co, G, dtype = case
+    Cop = (Co + 7) // 8 * 8
+    g = torch.Generator().manual_seed(11)
+    wide = torch.randn(N, H, W, Ci * 3 + 8, generator=g).to(dtype).to(DEV)   # several layers read slices of this one
+    items, refs = [], []
+    for i in range(G):
+        x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype)
+        w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dtype).requires_grad_(True)
+        y = F.conv2d(x, w, None, 1, 1)
+        dy = _rt(torch.randn(y.shape, generator=g), dtype)
+        y.backward(dy)
+        if i % 2 == 0 and i < 6:
+            off = 8 + (i // 2) * Ci
+            wide[..., off:off + Ci] = x.permute(0, 2, 3, 1).to(dtype).to(DEV)
+            xv = ops.View(wide, off, Ci)
+        else:
+            xv = ops.from_nchw(x.to(DEV), dtype)
+        dyv = ops.new_act(N, H, W, Cop, dtype, zero=True)
+        dyv.buf[..., :Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
+        items.append((xv, dyv, torch.zeros(Co, Ci, 3, 3, device=DEV)))
+        refs.append(w.grad)
+    ops.conv2d_wgrad_grouped(items, 3, 1)
+    torch.cuda.synchronize()
+    for (xv, dyv, dw), ref in zip(items, refs):
+        _close(dw, ref, 2e-3, 2e-3 * float(ref.abs().max()))
+        single = torch.zeros_like(dw)
+        ops.conv2d_wgrad(xv, dyv, single, 3, 1)
+        torch.cuda.synchronize()
+        _close(dw, single, 1e-4, 1e-4 * float(ref.abs().max()))
+    ops.conv2d_wgrad_grouped(items, 3, 1, accumulate=True)
+    torch.cuda.synchronize()
+    for (_, _, dw), ref in zip(items, refs):
+        _close(dw, 2 * ref, 2e-3, 4e-3 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("img_dtype", [torch.float32, torch.uint8])
 def test_stem_conv_and_wgrad(img_dtype):
     ops = _ops()
