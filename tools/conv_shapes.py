@@ -34,9 +34,14 @@ def main():
     groups = OrderedDict()
     for fn, args in calls:
         name = getattr(fn, "__name__", "")
-        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad"):
+        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad"):
             continue
         d = args[0]._obj
+        if name == "cdet_conv2d_wgrad_grouped":  # n = layers; the timed call is the whole group (ms and TF/s are per group launch)
+            key = ("wgrad", d.Hd, d.Wd, d.Cs, d.Cd, d.kh, -args[2])
+            g = groups.setdefault(key + (len(groups),), dict(n=0, flops=args[2] * 2.0 * d.N * d.Hd * d.Wd * d.Cd * d.Cs * 9, call=(fn, args)))
+            g["n"] += 1
+            continue
         kind = "wgrad" if name == "cdet_conv2d_wgrad" else ("dgrad" if (d.mode == L.CONV_DGRAD or name.endswith("dgrad")) else "fwd")
         if name.endswith("tiled_dgrad"):
             key = (kind, d.Hd, d.Wd, d.Cd, d.Cs, d.kh, 1)
@@ -54,7 +59,7 @@ def main():
     for key, g in groups.items():
         if key[0] not in a.what.split(","):
             continue
-        if a.only and a.only != f"{key[1]}x{key[2]}-{key[3]}-{key[4]}-{key[5]}":
+        if a.only and a.only != f"{key[1]}x{key[2]}-{key[3]}-{key[4]}-{key[5]}":  # (grouped launches: stride column = -layers)
             continue
         fn, args = g["call"]
         for _ in range(2):
@@ -70,7 +75,7 @@ def main():
     tot = {}
     print(f"{'kind':6s} {'HxW(out)':>9s} {'Cin':>5s} {'Cout':>5s} k s {'n':>3s} {'ms':>8s} {'TF/s':>7s} {'n*ms':>8s}")
     for key, n, ms, tf in sorted(rows, key=lambda r: (r[0][0], -r[1] * r[2])):
-        kind, H, W, ci, co, k, s = key
+        kind, H, W, ci, co, k, s = key[:7]
         print(f"{kind:6s} {H:4d}x{W:<4d} {ci:5d} {co:5d} {k} {s} {n:3d} {ms:8.3f} {tf:7.1f} {n * ms:8.2f}")
         t = tot.setdefault(kind, [0.0, 0.0])
         t[0] += n * ms
