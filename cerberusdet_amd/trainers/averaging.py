@@ -99,11 +99,11 @@ class Averaging:
                  linear_lr=False, use_ema=True, rank=-1, world_size=1, sync_bn=False, task_streams: Optional[bool] = None):
         self.device, self.model, self.hyp, self.task_ids = device, model, hyp, list(task_ids)
         self._gt_dropped = None
-        # one HIP stream per task pass (see _run_tasks_on_streams); off under SyncBatchNorm, whose per-layer collectives must be
-        # enqueued in one order on every rank
+        # one HIP stream per task pass (see _run_tasks_on_streams). Also under SyncBatchNorm: the host enqueue order of the per-layer
+        # collectives is a deterministic function of the model structure, hence the same on every rank
         if task_streams is None:
             task_streams = os.environ.get("CDET_TASK_STREAMS", "1") != "0"
-        self.task_streams = bool(task_streams) and not sync_bn and torch.device(device).type == "cuda"
+        self.task_streams = bool(task_streams) and torch.device(device).type == "cuda"
         self.rank, self.world_size = rank, world_size
         model.sync_bn = bool(sync_bn)  # SyncBatchNorm: per-layer statistics all-reduced over the ranks (reference train.py:140-143)
         self.epochs, self.nb = epochs, nb
@@ -173,6 +173,14 @@ class Averaging:
 
     # ---------------------------------------------------------------------------------------------------- step pieces
     def forward_backward(self, task: str, batch: dict, n_max: Optional[int] = None, active_tasks=None):
+        g = self._pass_steps(task, batch, n_max, active_tasks, None)
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    def _pass_steps(self, task: str, batch: dict, n_max, active_tasks, fired):
         """One task pass: fused forward + criterion + backward; gradients accumulate. Returns loss items (device tensor[5])."""
         img = batch["img"]
         plan = self.model.get_plan(task, img.shape, img.dtype, training=True)
@@ -180,13 +188,12 @@ class Averaging:
             for idx in {i for i, _ in plan.bwd_groups}:
                 plan.hooks[idx] = (lambda i, t=task: self.reducer.on_block_backward(i, t, self._active))
         self._active = active_tasks
-        plan.run_forward(img)
-        head = self.model.get_head(task)
+        yield from plan.iter_forward(img, fired)
         if self._gt_dropped is None:
             self._gt_dropped = torch.zeros(1, dtype=torch.int32, device=img.device)
         gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max, dropped=self._gt_dropped)
         loss5 = plan.loss(task, gt, self.gains[task], grad_scale=float(self.loss_weights[task]))
-        plan.run_backward()
+        yield from plan.iter_backward(fired)
         return loss5
 
     def _run_tasks_on_streams(self, active, batches, n_max, out):
@@ -218,12 +225,33 @@ class Averaging:
             plan.refresh_weights()  # all re-packs on the current stream, before the fork
             plan.attach_grads()
             plans.append(plan)
+        # Block-interleaved enqueue: every round lets each task enqueue its next block on its own stream. The GPU-side order is set by
+        # the streams and events alone (results are bit-identical to the sequential schedule); the HOST order matters for the
+        # collectives of SyncBatchNorm and the gradient reducer, which one communicator serialises in enqueue order -- enqueueing task A's
+        # whole pass first would hold task B's first all-reduce behind A's last. A task whose next block waits for an event that has
+        # not been recorded in this iteration yet (a shared block the earlier task has not reached) is skipped for the round.
+        fired: set = set()
         try:
+            gens = []
             for t, st, plan in zip(active, streams, plans):
                 plan.block_sync = syncs[t]
                 st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
+                gens.append((t, st, self._pass_steps(t, batches[t], n_max, active, fired)))
+            while gens:
+                progressed = False
+                for item in list(gens):
+                    t, st, g = item
+                    with torch.cuda.stream(st):
+                        try:
+                            req = next(g)
+                        except StopIteration as e:
+                            out[t] = e.value
+                            gens.remove(item)
+                            progressed = True
+                            continue
+                    progressed = progressed or req is None
+                if not progressed:
+                    raise RuntimeError("task schedule cannot make progress: a block waits for an event no active task records")
         finally:
             for plan in plans:
                 plan.block_sync = None
