@@ -644,7 +644,7 @@ using namespace cdet;
 extern "C" int64_t cdet_conv2d_wgrad_ws_elems(const cdet_conv_desc* d) {
     if (!d) return -1;
     WgradHaloPlan hp;
-    if (wgrad_halo_plan(d, &hp)) return (int64_t)hp.S * hp.Cd_pad * hp.Kp;
+    if (wgrad_halo_plan(d, &hp) || wgrad_gemm_plan(d, &hp)) return (int64_t)hp.S * hp.Cd_pad * hp.Kp;
     const WgradPlan p = plan_wgrad(d);
     return (int64_t)p.S * p.Cd_pad * p.Kp;
 }
@@ -657,10 +657,12 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_wgrad: descriptor must describe the forward convolution");
     WgradPlan p = plan_wgrad(d);
     WgradHaloPlan hp;
-    const bool halo = wgrad_halo_plan(d, &hp);
-    if (halo) {  // stride-1 3x3: tap-resident kernel, same slab layout / reduction as below
-        const int e = wgrad_halo_launch(d, hp, x, dy, ws, (hipStream_t)stream);
+    bool halo = wgrad_halo_plan(d, &hp);
+    const bool gemm = !halo && wgrad_gemm_plan(d, &hp);
+    if (halo || gemm) {  // stride-1 3x3 / 1x1: transpose-read kernels of conv_wgrad_halo.hip, same slab layout / reduction as below
+        const int e = gemm ? wgrad_gemm_launch(d, hp, x, dy, ws, (hipStream_t)stream) : wgrad_halo_launch(d, hp, x, dy, ws, (hipStream_t)stream);
         if (e) return e;
+        halo = true;
         p.S = hp.S;
         p.Cd_pad = hp.Cd_pad;
         p.Kp = hp.Kp;

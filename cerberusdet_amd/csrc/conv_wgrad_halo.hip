@@ -309,6 +309,153 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     }
 }
 
+// =====================================================================================================================================
+// 1x1 layers: dW[co][ci] = sum_p dY[p][co] * X[p][ci] -- the same machinery without halo, taps or masks. The nine "taps" of the register
+// tile become nine 16-cin planes: a workgroup owns 160 couts x 288 cins (wave: 80 couts x 144 cins = 45 accumulator tiles) and streams
+// 64-pixel stages (dY 20 KB + X 36 KB, double buffered); waves 0-3 reduce pixels 0..31 of a stage, waves 4-7 pixels 32..63, summed through
+// LDS at the end. Slab: ws[split][co][n_iblk * 288] (cins beyond Cs hold zeros; the reduction never reads them).
+// =====================================================================================================================================
+constexpr int WG_P = 64;
+constexpr int WG_DYB = 20 * 1024;
+constexpr int WG_NPL = 18;  // plane = tp * 2 + wci
+constexpr int WG_STAGE = WG_DYB + WG_NPL * WG_P * 32;
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = wave >> 2, wco = (wave >> 1) & 1, wci = wave & 1;
+    const int q = lane >> 4, li = lane & 15;
+    int L;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, qq = nwg >> 3, rr = nwg & 7, j = b >> 3;
+        L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + j;
+    }
+    const int ntiles = a.n_cblk * a.n_iblk;
+    const int split = L / ntiles;
+    const int tile = L - split * ntiles;
+    const int cblk = tile / a.n_iblk, iblk = tile - cblk * a.n_iblk;
+    const int c0 = cblk * 160, i0 = iblk * 16 * WG_NPL;
+    const int pbeg = split * a.chunk;
+    const int pend = min(pbeg + a.chunk, a.M);
+    const int nst = pbeg < pend ? (pend - pbeg + WG_P - 1) / WG_P : 0;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    // DMA duties (1 KiB per instruction): dY image di = wave + 8*idx < 20 = (16-pixel block di/5, cout pair di%5), lanes as in the 3x3
+    // kernel; X piece xi = wave + 8*idx < 36 = (plane xi>>1, 32-row block xi&1), lane -> (row lane>>1, 16-byte half lane&1)
+    const int ldyB = a.dy_ld * 2, ldxB = a.src_ld * 2;
+    const int yco_l = (lane >> 5) * 16 + (lane & 1) * 8;
+    const unsigned ydl = (unsigned)(((lane >> 1) & 15) * ldyB + yco_l * 2);
+    const unsigned xdl = (unsigned)((lane >> 1) * ldxB + (lane & 1) * 16);
+    auto issue_dma = [&](int idx, int st, int buf) {  // idx 0..2: dY images, 3..7: X pieces
+        if (st >= nst) return;
+        unsigned char* base = smem + buf * WG_STAGE;
+        const int pb0 = pbeg + st * WG_P;
+        if (idx < 3) {
+            const int di = wave + 8 * idx;
+            if (di < 20) {
+                const int pb = di / 5, cp = di - pb * 5;
+                const int cobase = c0 + cp * 32;
+                const unsigned sc = (unsigned)((pb0 + pb * 16) * ldyB + (a.dy_coff + cobase) * 2);
+                const unsigned v = yco_l < a.Cd - cobase ? ydl + sc : WH_SENT;
+                wh_dma16(rs_y, v, base + di * 1024);
+            }
+        } else {
+            const int xi = wave + 8 * (idx - 3);
+            if (xi < 2 * WG_NPL) {
+                const int pl = xi >> 1, blk = xi & 1;
+                const int cb = i0 + pl * 16;
+                const unsigned sc = (unsigned)((pb0 + blk * 32) * ldxB + (a.src_coff + cb) * 2);
+                wh_dma16(rs_x, cb < a.Cs ? xdl + sc : WH_SENT, base + WG_DYB + pl * (WG_P * 32) + blk * 1024);
+            }
+        }
+    };
+    const int yb0 = wco * 2560 + lane * 8 + half * 10240;
+    const int xb0 = WG_DYB + wci * (WG_P * 32) + half * 1024 + lane * 8;
+
+    f32x4 acc[9][5];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[tp][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_dma(i, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        int vy = yb0 + cur * WG_STAGE, vx = xb0 + cur * WG_STAGE;
+        asm volatile("" : "+v"(vy), "+v"(vx));
+        u32x2 blo[5], bhi[5];
+        wh_static_for(std::make_integer_sequence<int, 5>{}, [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            blo[j] = wh_tr<j * 512>(vy);
+            bhi[j] = wh_tr<5120 + j * 512>(vy);
+        });
+        u32x2 alo[2], ahi[2];
+        alo[0] = wh_tr<0>(vx);
+        ahi[0] = wh_tr<512>(vx);
+        wh_static_for(std::make_integer_sequence<int, 9>{}, [&](auto TP) {
+            constexpr int tp = decltype(TP)::value;
+            constexpr int cs = tp & 1, ns = cs ^ 1;
+            if constexpr (tp + 1 < 9) {
+                alo[ns] = wh_tr<(tp + 1) * 2 * WG_P * 32>(vx);
+                ahi[ns] = wh_tr<(tp + 1) * 2 * WG_P * 32 + 512>(vx);
+            }
+            if constexpr (tp < 8) issue_dma(tp, st + 1, cur ^ 1);
+            if constexpr (tp == 0) wh_wait_b<2>(blo, bhi, alo[0], ahi[0]);
+            else if constexpr (tp + 1 < 9) wh_wait<2>(alo[cs], ahi[cs]);
+            else wh_wait<0>(alo[cs], ahi[cs]);
+            const u32x4 av{alo[cs][0], alo[cs][1], ahi[cs][0], ahi[cs][1]};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const u32x4 bv{blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]};
+                wh_mfma<DT>(av, bv, acc[tp][j]);
+            }
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {  // waves 4..7 -> waves 0..3 (23 + 22 tiles of 1 KiB per wave pair)
+        const int t0 = rd * 23, t1 = rd ? 45 : 23;
+        unsigned char* slot = smem + ((wave & 3) * 23) * 1024 + lane * 16;
+        if (half == 1) {
+#pragma unroll
+            for (int tl = 0; tl < 45; ++tl)
+                if (tl >= t0 && tl < t1) *reinterpret_cast<f32x4*>(slot + (tl - t0) * 1024) = acc[tl / 5][tl % 5];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int tl = 0; tl < 45; ++tl)
+                if (tl >= t0 && tl < t1) acc[tl / 5][tl % 5] += *reinterpret_cast<const f32x4*>(slot + (tl - t0) * 1024);
+        }
+        __syncthreads();
+    }
+    if (half == 0) {
+        float* wsp = a.ws + (int64_t)split * a.Cd_pad * a.Kp;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int co = c0 + (wco * 5 + j) * 16 + li;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int k = i0 + (tp * 2 + wci) * 16 + 4 * q;
+                *reinterpret_cast<f32x4*>(wsp + (int64_t)co * a.Kp + k) = acc[tp][j];
+            }
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1)) return false;
@@ -387,6 +534,76 @@ int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const voi
         if (p.nci == 4) wgrad_halo_launch_t<CDET_F16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_F16, 2>(a, grid, p.lds, s);
     }
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+
+bool wgrad_gemm_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
+    if (!(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0)) return false;
+    if (d->Hs != d->Hd || d->Ws != d->Wd) return false;
+    // Both 1x1 kernels are bound by the L2 -> LDS stream, not by the MFMA pipe: 160 x 288 tiles move 56 KB per 5.9 MFLOP (103 FLOP/B),
+    // measured 6.6 TB/s = 690 TF/s in the main loop (tools/kstats.sh, 40x40 2560->640: 242 us against 309 us for the im2col kernel).
+    // Measured per shape at batch 32 (profiles/r02_conv_shapes.txt): 3+ cout blocks (Cout 640) 0-20 % faster, Cout 320 at 80x80
+    // 15 % slower (1280 / 960 cins), Cout 160 level -- so only the wide layers come here.
+    if (d->Cs % 16 != 0 || d->Cd < 128) return false;
+    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
+    bool wide_only = true;
+    if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel everywhere; 3: this kernel for every Cout >= 128 (tests)
+        if (atoi(e) == 0) return false;
+        wide_only = atoi(e) != 3;
+    }
+    if (wide_only && d->Cd <= 320) return false;
+    const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
+    if (M * d->src_ld * 2 >= 0xC0000000ll || M * d->dst_ld * 2 >= 0xC0000000ll) return false;
+    const int tile_ci = 16 * WG_NPL;
+    const int n_cblk = div_up(d->Cd, 160), n_iblk = div_up(d->Cs, tile_ci);
+    if (d->Cs * 10 < n_iblk * tile_ci * 7) return false;  // more than 30 % of the cin tile empty: the im2col kernel's 128-wide K blocks fit better
+    const int tiles = n_cblk * n_iblk;
+    if (tiles > 256) return false;
+    int S = 256 / tiles;
+    const int maxS = (int)((M + 511) / 512);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    int chunk = (int)((M + S - 1) / S);
+    chunk = (chunk + WG_P - 1) / WG_P * WG_P;
+    S = (int)((M + chunk - 1) / chunk);
+    out->S = S;
+    out->chunk = chunk;
+    out->Kp = n_iblk * tile_ci;
+    out->Cd_pad = n_cblk * 160;
+    out->n_cblk = n_cblk;
+    out->n_iblk = n_iblk;
+    out->XH = 0;
+    out->nci = 2;
+    out->lds = 2 * (size_t)WG_STAGE;
+    return true;
+}
+
+template <int DT>
+static void wgrad_gemm_launch_t(const WHArgs& a, int grid, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_gemm_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_gemm_kernel<DT>), dim3(grid), dim3(512), lds, s, a);
+}
+
+int wgrad_gemm_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s) {
+    WHArgs a;
+    a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.ws = ws;
+    a.items = nullptr;
+    a.H = d->Hs; a.W = d->Ws; a.M = d->N * d->Hs * d->Ws;
+    a.Cs = d->Cs; a.Cd = (d->Cd + 7) / 8 * 8;
+    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dy_ld = d->dst_ld; a.dy_coff = d->dst_coff;
+    a.Kp = p.Kp; a.Cd_pad = p.Cd_pad; a.chunk = p.chunk; a.S = p.S; a.n_cblk = p.n_cblk; a.n_iblk = p.n_iblk; a.XH = 0;
+    a.magicW = a.magicH = 0;
+    a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
+    a.dy_bytes = (unsigned)((int64_t)a.M * d->dst_ld * 2);
+    const int grid = p.S * p.n_cblk * p.n_iblk;
+    if (d->dtype == CDET_BF16) wgrad_gemm_launch_t<CDET_BF16>(a, grid, p.lds, s);
+    else wgrad_gemm_launch_t<CDET_F16>(a, grid, p.lds, s);
     CDET_LAUNCH_CHECK();
     return 0;
 }

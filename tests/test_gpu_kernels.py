@@ -181,6 +181,44 @@ def test_conv_wgrad_tap_resident(case, tile, monkeypatch):
     _close(dw, 2 * w.grad, 2e-3, 4e-3 * float(w.grad.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 20, 20, 256, 160, torch.bfloat16), (1, 24, 40, 800, 320, torch.bfloat16), (3, 16, 16, 288, 136, torch.float16),
+                                  (1, 13, 11, 1600, 200, torch.bfloat16), (1, 20, 20, 576, 640, torch.bfloat16)])
+def test_conv_wgrad_1x1_transpose_read_kernel(case, monkeypatch):
+    """1x1 weight gradient on wgrad_gemm_kernel (csrc/conv_wgrad_halo.hip) against autograd and against the im2col kernel; operands are
+    channel slices of wider buffers; pixel counts that are not multiples of the 64-pixel stage; a cin tile that is partly empty."""
+    ops = _ops()
+    N, H, W, Ci, Co, dtype = case
+    Cop = (Co + 7) // 8 * 8
+    g = torch.Generator().manual_seed(17)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype).requires_grad_(False)
+    w = _rt(torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci), dtype).requires_grad_(True)
+    y = F.conv2d(x, w)
+    dy = _rt(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    xb = torch.randn(N, H, W, Ci + 24, generator=g).to(dtype).to(DEV)
+    xb[..., 16:16 + Ci] = x.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    xv = ops.View(xb, 16, Ci)
+    yb = torch.randn(N, H, W, Cop + 8, generator=g).to(dtype).to(DEV)
+    yb[..., 8:8 + Cop] = 0
+    yb[..., 8:8 + Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    dyv = ops.View(yb, 8, Cop)
+    monkeypatch.setenv("CDET_WGRAD_HALO", "3")  # the kernel for every Cout >= 128 (by default only Cout > 320 goes there)
+    dw = torch.zeros(Co, Ci, 1, 1, device=DEV)
+    ops.conv2d_wgrad(xv, dyv, dw, 1, 1)
+    torch.cuda.synchronize()
+    scale = float(w.grad.abs().max())
+    _close(dw, w.grad, 2e-3, 2e-3 * scale)
+    monkeypatch.setenv("CDET_WGRAD_HALO", "0")
+    dw0 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(xv, dyv, dw0, 1, 1)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("CDET_WGRAD_HALO", "3")
+    _close(dw, dw0, 1e-4, 1e-4 * scale)
+    ops.conv2d_wgrad(xv, dyv, dw, 1, 1, accumulate=True)
+    torch.cuda.synchronize()
+    _close(dw, 2 * w.grad, 2e-3, 4e-3 * scale)
+
+
 @pytest.mark.parametrize("case", [(2, 20, 20, 64, 160, 5, torch.bfloat16), (1, 40, 40, 32, 136, 3, torch.float16), (1, 24, 24, 96, 320, 14, torch.bfloat16)])
 def test_conv_wgrad_grouped_launch(case):
     """cdet_conv2d_wgrad_grouped: G layers of one geometry (x views at different channel offsets of wider buffers, like the Bottleneck
