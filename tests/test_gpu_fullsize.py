@@ -100,6 +100,45 @@ def test_full_model_pass_loss_identity_and_exact_gradient_doubling(v8x_trainer):
         assert torch.equal(p.grad, 2 * g1[k]), k  # g + g is exact in fp32: bit-identical kernels, correct accumulate variants
 
 
+def test_grouped_weight_gradient_launches_equal_per_layer_launches(v8x_trainer, monkeypatch):
+    """The engine runs the same-geometry 3x3 weight gradients of a block as ONE grouped launch (Plan._flush_wgrads). Same products, a
+    different pixel split -> the fp32 sums differ in their last bits only: every gradient of the real YOLOv8x pass agrees with the
+    per-layer launches (CDET_WGRAD_GROUP=0) to 1e-4 of its scale, and the other gradients (data path untouched) exactly."""
+    import bench
+
+    model, tr, batches = v8x_trainer
+    t = bench.TASKS[1]
+    img = batches[t]["img"]
+
+    def one_pass():
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        tr.forward_backward(t, batches[t], n_max=8, active_tasks=[t])
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+
+    plan = model.get_plan(t, img.shape, img.dtype, training=True)
+    n_grouped = sum(1 for _, cs in plan.bwd_groups for fn, a in cs if getattr(fn, "__name__", "") == "cdet_conv2d_wgrad_grouped")
+    assert n_grouped >= 6  # backbone C2f x3 + neck C2f x4 (the 160x160 C2f has 80 channels: not groupable)
+    g_grouped = one_pass()
+    monkeypatch.setenv("CDET_WGRAD_GROUP", "0")
+    model._plans = {}
+    g_single = one_pass()
+    plan0 = model.get_plan(t, img.shape, img.dtype, training=True)
+    assert not any(getattr(fn, "__name__", "") == "cdet_conv2d_wgrad_grouped" for _, cs in plan0.bwd_groups for fn, a in cs)
+    monkeypatch.delenv("CDET_WGRAD_GROUP")
+    model._plans = {}
+    assert g_grouped.keys() == g_single.keys() and len(g_grouped) >= 180
+    differ = 0
+    for k, a in g_grouped.items():
+        b = g_single[k]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale, k
+        differ += int(not torch.equal(a, b))
+    assert differ <= 60  # only the grouped convolution weights may differ at all
+
+
 def test_nms_full_batch_properties():
     import bench
     from cerberusdet_amd import ops
