@@ -81,16 +81,21 @@ def _cpu_baseline_worker(cfg, q):
     g = og.build_graph(cfg, TASKS, NC)
     og.apply_cerber_schedule(g, cfg["cerber"])
     w = og.init_weights(g, seed=0)
-    t0 = time.perf_counter()
-    n_img = 0
-    for ti, t in enumerate(TASKS[:1]):
+    def task_pass(ti, t):
         wt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in w.items()}
         b = synth_batch(0, ti, 0, 1, NC[ti], 640, "cpu")
         x = b["img"].float() / 255
         feats = og.forward(g, wt, x, t, training=True)
         scalar, _ = ol.detection_loss(feats, b, NC[ti], dict(box=7.5, cls=0.5, dfl=1.5))
         scalar.backward()
-        n_img += 1
+
+    task_pass(0, TASKS[0])  # untimed: first touch of the weights, thread-pool start-up
+    t0 = time.perf_counter()
+    n_img = 0
+    for rep in range(2):  # the metric's iteration at batch 1: one pass per task, twice (~10-15 s on 64 cores)
+        for ti, t in enumerate(TASKS):
+            task_pass(ti, t)
+            n_img += 1
     dt = time.perf_counter() - t0
     extra = {}
     try:  # (ii) all-heads eval forward, bs 1
@@ -130,7 +135,7 @@ def _cpu_baseline_worker(cfg, q):
     except Exception as e:  # the headline sample above stands on its own
         extra["error"] = repr(e)
     q.put(dict(value=round(n_img / dt, 4), unit="images/sec", cores=n_thr, cpu_model=cpu, kind="port",
-               sample=f"one task pass (fwd + loss + bwd, no optimizer) of the YOLOv8x 2-task model @640, batch 1, CPU oracle (torch fp32), {dt:.1f} s",
+               sample=f"{n_img} task passes (fwd + loss + bwd per task, no optimizer; both tasks, twice, after one untimed pass) of the YOLOv8x 2-task model @640 at batch 1, CPU oracle (torch fp32), {dt:.1f} s",
                extra=extra))
 
 
