@@ -139,6 +139,54 @@ def test_grouped_weight_gradient_launches_equal_per_layer_launches(v8x_trainer, 
     assert differ <= 60  # only the grouped convolution weights may differ at all
 
 
+def test_three_task_full_size_iteration_streams_vs_sequential():
+    """BASELINE config 4's model (YOLOv8x, three tasks: blocks shared by all three and by two of them) at full width on one GPU: two
+    iterations with one HIP stream per task (block-interleaved enqueue, grouped weight gradients) give bit-identical loss items, weights
+    and BatchNorm statistics to the sequential schedule; the loss identity scalar = 2*bs*total holds for every task; every block's
+    weights moved. Batch 8 per task keeps it short -- the kernels and launch lists are the full-size ones."""
+    import yaml
+
+    import bench
+    from cerberusdet_amd.models import CerberusDet
+    from cerberusdet_amd.trainers import Averaging
+
+    dev = torch.device(DEV, 0)
+    tasks, ncs = ["voc", "objects365_animals", "objects365_tableware"], [20, 19, 12]
+    cfg = yaml.safe_load(open(bench.ROOT / "cerberusdet_amd" / "models" / "cfg" / "v8x_3task.yaml"))
+    hyp = dict(bench.HYP)
+    for k in ("box", "cls", "dfl"):
+        if isinstance(hyp[k], (list, tuple)):
+            hyp[k] = list(hyp[k]) + [hyp[k][-1]] * (3 - len(hyp[k]))
+    data = {t: bench.synth_batch(0, i, 0, 8, ncs[i], 640, dev) for i, t in enumerate(tasks)}
+    res = []
+    for streams in (False, True):
+        torch.manual_seed(0)
+        m = CerberusDet(tasks, ncs, cfg=cfg, verbose=False)
+        m.sequential_split(cfg["cerber"], "cpu")
+        m.hyp = hyp
+        m = m.to(dev).train()
+        w0 = {k: v.clone() for k, v in m.state_dict().items()}
+        tr = Averaging(dev, m, hyp, tasks, use_ema=False, task_streams=streams)
+        assert tr.task_streams == streams
+        items = [tr.train_step(data, n_max=8, ni=3000 + it) for it in range(2)]
+        torch.cuda.synchronize()
+        tr.check_targets()
+        res.append(([{t: v.clone() for t, v in it.items()} for it in items], {k: v.clone() for k, v in m.state_dict().items()}))
+        for it in items:
+            for t in tasks:
+                l = it[t].tolist()
+                assert all(math.isfinite(v) for v in l) and abs(l[4] - 2 * 8 * l[3]) <= 1e-5 * abs(l[4])
+        moved = {k.split(".")[1] for k, v in m.state_dict().items() if k.endswith("conv.weight") and not torch.equal(v, w0[k])}
+        assert moved == {str(i) for i in range(len(m.blocks)) if any(True for _ in m.blocks[i].parameters())}
+        del tr, m
+    (ia, sa), (ib, sb) = res
+    for x, y in zip(ia, ib):
+        for t in tasks:
+            assert torch.equal(x[t], y[t]), t
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_nms_full_batch_properties():
     import bench
     from cerberusdet_amd import ops
