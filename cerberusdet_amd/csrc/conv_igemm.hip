@@ -43,6 +43,7 @@ struct ConvArgs {
     struct ParClass {
         int cy, cx, kh0, kw0, nh, nw, Hc, Wc, M, nk, blk0, nblk;
     } pc[4];
+    int par_interleave;  // all four classes have the same tile count: class = L & 3, so the four classes of one pixel tile run together
     unsigned x_bytes, w_bytes;  // extents of the source / packed-weight buffers (buffer-resource bounds of the pipelined kernel)
 };
 
@@ -503,13 +504,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
         L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    // parity mode: the linear block index first selects the class (heaviest first), then the tile inside it
+    // parity mode: the linear block index selects the class and the tile inside it. With equal tile counts the classes interleave
+    // (the four classes of a pixel tile write the four pixels of every 2x2 cell: run together on one XCD their partial lines merge
+    // in L2); otherwise class by class, heaviest first
     int cls = 0;
     if (PAR) {
+        if (a.par_interleave) {
+            cls = L & 3;
+            L >>= 2;
+        } else {
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (L >= a.pc[q].blk0) cls = q;
-        L -= a.pc[cls].blk0;
+            for (int q = 1; q < 4; ++q)
+                if (L >= a.pc[q].blk0) cls = q;
+            L -= a.pc[cls].blk0;
+        }
     }
     const int cy = PAR ? a.pc[cls].cy : 0, cx = PAR ? a.pc[cls].cx : 0;
     const int kh0 = PAR ? a.pc[cls].kh0 : 0, kw0 = PAR ? a.pc[cls].kw0 : 0;
@@ -780,10 +788,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_pipe_kernel
     }
     int cls = 0;
     if (PAR) {
+        if (a.par_interleave) {  // see conv_igemm_glds_kernel
+            cls = L & 3;
+            L >>= 2;
+        } else {
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (L >= a.pc[q].blk0) cls = q;
-        L -= a.pc[cls].blk0;
+            for (int q = 1; q < 4; ++q)
+                if (L >= a.pc[q].blk0) cls = q;
+            L -= a.pc[cls].blk0;
+        }
     }
     const int cy = PAR ? a.pc[cls].cy : 0, cx = PAR ? a.pc[cls].cx : 0;
     const int kh0 = PAR ? a.pc[cls].kh0 : 0, kw0 = PAR ? a.pc[cls].kw0 : 0;
@@ -1254,6 +1267,7 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
         a.w_bytes = ok ? (unsigned)wb : 0u;
     }
     for (int q = 0; q < 4; ++q) a.pc[q] = ConvArgs::ParClass{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    a.par_interleave = 0;
     if (dg && d->stride == 2) {
         // parity classes of the dX pixels, heaviest (most taps) first so the short ones fill the tail
         int order[4] = {0, 1, 2, 3}, taps[4];
@@ -1280,6 +1294,8 @@ extern "C" int cdet_conv2d(const cdet_conv_desc* d, const void* x, const void* w
             a.pc[i].nblk = div_up(a.pc[i].M, cfg_bp(cfg)) * a.n_cblk;
             blk += a.pc[i].nblk;
         }
+        a.par_interleave = tune_env("CDET_PAR_INTERLEAVE", 1) && a.pc[0].nblk == a.pc[1].nblk && a.pc[1].nblk == a.pc[2].nblk &&
+                           a.pc[2].nblk == a.pc[3].nblk && a.pc[3].nblk > 0;
     }
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == CDET_BF16) return launch_conv<CDET_BF16>(a, cfg, dg, s);
