@@ -90,15 +90,20 @@ __device__ __forceinline__ void wh_dma16(__amdgpu_buffer_rsrc_t r, unsigned voff
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
 
-template <int DT, int NCI>
+// NARROW (Cout <= 96, NCI = 2): the tile is 80 couts x 32 cins; the factor two the cout halves would take goes to the pixels -- four
+// groups of two waves, each reducing 32 of the stage's 128 pixels, summed through LDS in two levels at the end.
+template <int DT, int NCI, bool NARROW = false>
 __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
-    constexpr int KSL = NCI == 4 ? 4 : 2;  // 32-pixel reduction steps a wave runs per stage
+    static_assert(!NARROW || NCI == 2, "the 80-cout tile exists for the 32-cin form only");
+    constexpr int KSL = NARROW ? 1 : (NCI == 4 ? 4 : 2);  // 32-pixel reduction steps a wave runs per stage
+    constexpr int CO = NARROW ? 80 : 160;                  // couts of the tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int half = NCI == 4 ? 0 : wave >> 2;
-    const int wco = NCI == 4 ? wave >> 2 : (wave >> 1) & 1;
+    const int half = NCI == 4 ? 0 : wave >> 2;             // (senders / receivers of the first end-of-kernel exchange)
+    const int prow = NARROW ? (wave >> 1) * 32 : half * 64;  // first pixel row of the stage this wave reduces
+    const int wco = NARROW ? 0 : (NCI == 4 ? wave >> 2 : (wave >> 1) & 1);
     const int wci = NCI == 4 ? wave & 3 : wave & 1;
     const int q = lane >> 4, li = lane & 15;
 
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
         x_bytes = (unsigned)a.M * (unsigned)src_ld * 2u;
     }
     const int cblk = tile / a.n_iblk, iblk = tile - cblk * a.n_iblk;
-    const int c0 = cblk * 160, i0 = iblk * 16 * NCI;
+    const int c0 = cblk * CO, i0 = iblk * 16 * NCI;
     const int pbeg = split * a.chunk;
     const int pend = min(pbeg + a.chunk, a.M);
     const int nst = pbeg < pend ? (pend - pbeg + WH_P - 1) / WH_P : 0;
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             const int di = wave + 8 * idx;  // wave-uniform
             const int pb = di / 5, cp = di - pb * 5;
             const int cobase = c0 + cp * 32;
+            if (NARROW && cp >= 3) return;  // an 80-cout tile reads cout pairs 0..2 only
             const unsigned sc = (unsigned)((pb0 + pb * 16) * ldyB + (a.dy_coff + cobase) * 2);
             const unsigned v = yco_l < a.Cd - cobase ? ydl + sc : WH_SENT;
             wh_dma16(rs_y, v, base + di * 1024);
@@ -166,9 +172,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             const int xi = wave + 8 * (idx - 5);  // wave-uniform
             if (xi < nxp) {
                 const int blk = xi / NCI, pl = xi - blk * NCI;
-                // (rows above the tensor give a negative pixel: the 32-bit offset wraps far beyond the buffer -> zeros)
+                // (rows above the tensor give a negative pixel: the 32-bit offset wraps far beyond the buffer -> zeros;
+                //  a plane beyond Cs -- the last cin tile of an 80-channel layer -- is filled with zeros as well)
                 const unsigned sc = (unsigned)((pb0 + blk * 32 - (W + 1)) * ldxB + (src_coff + i0 + pl * 16) * 2);
-                wh_dma16(rs_x, xdl + sc, base + WH_DYB + pl * XP + blk * 1024);
+                wh_dma16(rs_x, i0 + pl * 16 < a.Cs ? xdl + sc : WH_SENT, base + WH_DYB + pl * XP + blk * 1024);
             }
         }
     };
@@ -177,10 +184,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     //   dY: K-step ks (32 px), 16-pixel block 2*ks + hh, cout group cog = wco*5 + j -> image (2*ks + hh)*5 + cog/2, half cog&1
     //       = byte (2*ks + hh)*5120 + cog*512
     //   X : halo row of pixel px and tap (ky, kx) = px + ky*W + kx, plane wci
-    const int yb0 = wco * 2560 + lane * 8 + half * 20480;
-    const int xb0 = WH_DYB + wci * XP + half * 64 * 32 + lane * 8;
+    const int yb0 = wco * 2560 + lane * 8 + (prow >> 5) * 10240;
+    const int xb0 = WH_DYB + wci * XP + prow * 32 + lane * 8;
     const int zaddr = ZOFF + lane * 8;
-    const int pix_l = half * 64 + (lane >> 2);  // the lane's pixel inside a 16-pixel block, + the wave's pixel half
+    const int pix_l = prow + (lane >> 2);  // the lane's pixel inside a 16-pixel block, + the first pixel row of the wave's share
 
     f32x4 acc[9][5];
 #pragma unroll
@@ -275,18 +282,23 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     __builtin_amdgcn_s_barrier();
 
     if (NCI == 2) {
-        // ---- waves 4..7 hand their partial tiles to waves 0..3 through LDS (two rounds: 23 + 22 tiles of 1 KiB per wave pair)
+        // ---- waves 4..7 hand their partial tiles to waves 0..3 through LDS (two rounds: 23 + 22 tiles of 1 KiB per wave pair);
+        //      NARROW: then waves 2, 3 to waves 0, 1 the same way
+#pragma unroll
+        for (int lvl = 0; lvl < (NARROW ? 2 : 1); ++lvl)
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
             const int t0 = rd * 23, t1 = rd ? 45 : 23;
-            unsigned char* slot = smem + ((wave & 3) * 23) * 1024 + lane * 16;
-            if (half == 1) {
+            const bool snd = lvl == 0 ? half == 1 : (wave == 2 || wave == 3);
+            const bool rcv = lvl == 0 ? half == 0 : wave < 2;
+            unsigned char* slot = smem + ((lvl == 0 ? wave & 3 : wave & 1) * 23) * 1024 + lane * 16;
+            if (snd) {
 #pragma unroll
                 for (int tl = 0; tl < 45; ++tl)
                     if (tl >= t0 && tl < t1) *reinterpret_cast<f32x4*>(slot + (tl - t0) * 1024) = acc[tl / 5][tl % 5];
             }
             __syncthreads();
-            if (half == 0) {
+            if (rcv) {
 #pragma unroll
                 for (int tl = 0; tl < 45; ++tl)
                     if (tl >= t0 && tl < t1) acc[tl / 5][tl % 5] += *reinterpret_cast<const f32x4*>(slot + (tl - t0) * 1024);
@@ -294,8 +306,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             __syncthreads();
         }
     }
-    // ---- partial slab: C[ci][co] tiles -> ws[split][co][tap*Cs + ci], 4 consecutive cins per lane
-    if (half == 0) {
+    // ---- partial slab: C[ci][co] tiles -> ws[split][co][tap*Cs + ci], 4 consecutive cins per lane (not the cins beyond Cs)
+    if ((NARROW ? wave < 2 : half == 0) && i0 + wci * 16 < a.Cs) {
         float* wsp = a.ws + (int64_t)slab_id * a.Cd_pad * a.Kp;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -460,7 +472,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WHArgs a) {
 bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1)) return false;
     if (d->Hs != d->Hd || d->Ws != d->Wd) return false;
-    if (d->Cs % 32 != 0 || d->Cd < 128) return false;  // an 80-cout layer would leave half of the 160-cout tile empty
+    const bool narrow = d->Cd <= 96;  // 80-cout tile (the Cout-80 layers: C2f 160x160 Bottlenecks, the box-branch stems of the heads)
+    if (narrow ? (d->Cs % 16 != 0 || d->Cd < 64) : (d->Cs % 32 != 0 || d->Cd < 128)) return false;
+    if (d->Cs * 10 < (d->Cs + 31) / 32 * 32 * 7) return false;  // last cin tile more than 30 % empty
     if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
     int force_nci = 0;
     if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel (the tests compare the two); 4: 64-cin tile where it fits
@@ -475,12 +489,13 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     // the layer, 47 MB at 32 cins against 94 MB -- measured 0.096 vs 0.105 ms per launch (profiles/r02_wgrad_kstats.txt). The
     // 64-cin form is kept for CDET_WGRAD_HALO=4 (parity-tested): it is the right tile once launches are grouped and S drops to 1.
     int nci = 2;
-    if (force_nci == 4 && d->Cs % 64 == 0 && lds_of(4) <= 160 * 1024) nci = 4;
+    if (!narrow && force_nci == 4 && d->Cs % 64 == 0 && lds_of(4) <= 160 * 1024) nci = 4;
     if (lds_of(nci) > 160 * 1024) return false;
-    if (nci * (XH / 32) > 40) return false;  // 5 X pieces per wave
+    if (nci * (XH / 32) > (narrow ? 32 : 40)) return false;  // 5 X pieces per wave (4 for the 80-cout form: one reduction step per stage)
     if (M * d->src_ld * 2 >= 0xC0000000ll || M * d->dst_ld * 2 >= 0xC0000000ll) return false;
     if (M >= (1 << 24)) return false;  // the magic-multiply quotients are exact far beyond this; keep a wide margin
-    const int n_cblk = div_up(d->Cd, 160), n_iblk = d->Cs / (16 * nci);
+    const int co_tile = narrow ? 80 : 160;
+    const int n_cblk = div_up(d->Cd, co_tile), n_iblk = div_up(d->Cs, 16 * nci);
     const int tiles = n_cblk * n_iblk * (n_items < 1 ? 1 : n_items);  // a grouped launch spreads the CUs over all its layers
     if (n_cblk * n_iblk > 256) return false;
     // one workgroup per CU: the largest split count that keeps the grid within one round; every split costs a slab write + re-read
@@ -494,23 +509,24 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     out->S = S;
     out->chunk = chunk;
     out->Kp = 9 * d->Cs;
-    out->Cd_pad = n_cblk * 160;
+    out->Cd_pad = n_cblk * co_tile;
     out->n_cblk = n_cblk;
     out->n_iblk = n_iblk;
     out->XH = XH;
     out->nci = nci;
+    out->narrow = narrow ? 1 : 0;
     out->lds = lds_of(nci);
     return true;
 }
 
-template <int DT, int NCI>
+template <int DT, int NCI, bool NARROW = false>
 static void wgrad_halo_launch_t(const WHArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<DT, NCI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<DT, NCI, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad_halo_kernel<DT, NCI>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((wgrad_halo_kernel<DT, NCI, NARROW>), dim3(grid), dim3(512), lds, s, a);
 }
 
 int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s,
@@ -528,10 +544,12 @@ int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const voi
     a.dy_bytes = (unsigned)((int64_t)a.M * d->dst_ld * 2);
     const int grid = (items_dev ? n_items : 1) * p.S * p.n_cblk * p.n_iblk;
     if (d->dtype == CDET_BF16) {
-        if (p.nci == 4) wgrad_halo_launch_t<CDET_BF16, 4>(a, grid, p.lds, s);
+        if (p.narrow) wgrad_halo_launch_t<CDET_BF16, 2, true>(a, grid, p.lds, s);
+        else if (p.nci == 4) wgrad_halo_launch_t<CDET_BF16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_BF16, 2>(a, grid, p.lds, s);
     } else {
-        if (p.nci == 4) wgrad_halo_launch_t<CDET_F16, 4>(a, grid, p.lds, s);
+        if (p.narrow) wgrad_halo_launch_t<CDET_F16, 2, true>(a, grid, p.lds, s);
+        else if (p.nci == 4) wgrad_halo_launch_t<CDET_F16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_F16, 2>(a, grid, p.lds, s);
     }
     CDET_LAUNCH_CHECK();
@@ -576,6 +594,7 @@ bool wgrad_gemm_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     out->n_iblk = n_iblk;
     out->XH = 0;
     out->nci = 2;
+    out->narrow = 0;
     out->lds = 2 * (size_t)WG_STAGE;
     return true;
 }

@@ -137,6 +137,10 @@ WGRAD_HALO_CASES = [
     (1, 16, 16, 32, 128, torch.bfloat16),    # one split, two stages
     (2, 20, 20, 128, 160, torch.bfloat16),   # Cin % 64 == 0: also runs on the 64-cin tile
     (1, 40, 40, 64, 200, torch.float16),     # 64-cin tile, two cout blocks, the second 40 wide
+    (2, 40, 40, 80, 80, torch.bfloat16),     # 80-cout tile, Cin = 80: the last 32-cin tile is half empty
+    (1, 32, 160, 80, 80, torch.bfloat16),    # 160-wide rows (the C2f 160 x 160 Bottlenecks): halo 450 rows
+    (1, 20, 20, 640, 80, torch.float16),     # head box-branch stem
+    (2, 24, 24, 96, 72, torch.bfloat16),     # Cout 72
     (2, 20, 100, 32, 192, torch.bfloat16),   # wide rows: the halo is 330 rows
 ]
 
