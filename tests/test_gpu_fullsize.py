@@ -120,7 +120,7 @@ def test_grouped_weight_gradient_launches_equal_per_layer_launches(v8x_trainer, 
 
     plan = model.get_plan(t, img.shape, img.dtype, training=True)
     n_grouped = sum(1 for _, cs in plan.bwd_groups for fn, a in cs if getattr(fn, "__name__", "") == "cdet_conv2d_wgrad_grouped")
-    assert n_grouped >= 6  # backbone C2f x3 + neck C2f x4 (the 160x160 C2f has 80 channels: not groupable)
+    assert n_grouped >= 8  # backbone C2f x4 + neck C2f x4 (+ the head's 3x3 convolutions, one geometry each)
     g_grouped = one_pass()
     monkeypatch.setenv("CDET_WGRAD_GROUP", "0")
     model._plans = {}
@@ -136,7 +136,7 @@ def test_grouped_weight_gradient_launches_equal_per_layer_launches(v8x_trainer, 
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * scale, k
         differ += int(not torch.equal(a, b))
-    assert differ <= 60  # only the grouped convolution weights may differ at all
+    assert differ <= 80  # only the grouped 3x3 convolution weights may differ at all (72 stride-1 3x3 layers on a task's path)
 
 
 def test_three_task_full_size_iteration_streams_vs_sequential():
