@@ -20,7 +20,11 @@
 //     the image are redirected per lane to a zero region with ONE v_cndmask on a precomputed 64-lane mask (top / bottom / left /
 //     right validity of the lane's pixel; corner taps AND two masks on the scalar unit). The transpose reads are inline asm with
 //     explicit lgkmcnt accounting: the compiler would otherwise drain vmcnt(0) -- the next stage's DMA -- in front of every LDS read.
-// Output: partial slab ws[split][co][tap*Cs + ci] (fp32) -- the layout wgrad_reduce_kernel<3,3> of conv_wgrad.hip reduces.
+//   * NARROW (Cout <= 96): 80-cout x 32-cin tile; the eight waves are four pixel groups x two cin halves (see the kernel);
+//   * grouped launches: with a.items set, the workgroups of ONE launch are spread over n layers of identical geometry (device table of
+//     per-layer tensors), so the pixel split per layer -- and the slab below -- shrinks by n (cdet_conv2d_wgrad_grouped).
+// Output: partial slab ws[layer][split][co][tap*Cs + ci] (fp32) -- the layout wgrad_reduce_kernel<3,3> of conv_wgrad.hip reduces.
+// wgrad_gemm_kernel further down is the 1x1 form of the same machinery.
 #include "common.h"
 
 #include <utility>
