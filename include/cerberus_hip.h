@@ -148,7 +148,9 @@ int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const void* dy, fl
  * autograd convolution_backward(weight) in the reference, models/common.py:107-117). One workgroup per CU over ALL layers, so the
  * pixel split per layer -- and with it the fp32 partial-slab round trip -- shrinks by n. `d` carries the shared geometry (N, H, W, Cs,
  * Cd, dtype, dst_ld/dst_coff of dy); each item its own tensors and the channel stride / offset of its x view.
- * cdet_conv2d_wgrad_groupable(d): 1 when the tap-resident kernel takes the geometry (stride-1 3x3, Cs % 32 == 0, Cd >= 128). */
+ * cdet_conv2d_wgrad_groupable(d): 1 when the tap-resident kernel takes the geometry (stride-1 3x3; Cs % 32 == 0 and Cd >= 128, or
+ * Cd <= 96 with Cs % 16 == 0). The item table lives in device memory, so the library cannot validate it: src_ld and src_coff of every
+ * item must be multiples of 8 (16-byte rows), N*H*W*src_ld*2 < 3 GiB, and every dw distinct. */
 typedef struct {
     const void* x;      /* source activation view (NHWC), channel stride src_ld, first channel src_coff */
     const void* dy;     /* gradient of the convolution output, layout d->dst_ld / d->dst_coff             */
