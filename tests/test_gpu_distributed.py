@@ -194,3 +194,58 @@ def test_two_ranks_syncbn_vs_one_process_whole_batch():
         assert cos > 0.98 and 0.4 < np.linalg.norm(b) / np.linalg.norm(a) < 2.5, (k, cos, np.linalg.norm(b) / np.linalg.norm(a))
         n += 1
     assert n >= 8
+
+
+def _worker_sched(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cerberusdet_amd.trainers import Averaging
+
+        synth, meta, mmeta = _setup()
+        half = BS // world
+        batches = _batches(synth, meta, rank * half, (rank + 1) * half)
+        out = {}
+        for streams in (False, True):
+            m = _model(synth, meta, mmeta)
+            tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False, rank=rank, world_size=world,
+                           sync_bn=True, task_streams=streams)
+            assert tr.task_streams == streams
+            items = None
+            for it in range(2):
+                items = tr.train_step(batches, n_max=8, ni=2000 + it)
+            torch.cuda.synchronize()
+            tr.check_targets()
+            out[streams] = ({t: v.cpu().numpy() for t, v in items.items()}, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_train_step_task_streams_equal_sequential_under_syncbn():
+    """Two ranks, SyncBatchNorm, gradient reducer, two iterations of train_step: the block-interleaved task-stream schedule enqueues
+    the per-layer collectives in one order on both ranks (a mismatch deadlocks gloo: the test would time out) and gives bit-identical
+    loss items, weights and running statistics to the sequential schedule; both ranks end with the same weights."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1500) + 13
+    procs = [ctx.Process(target=_worker_sched, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        (it_s, sd_s), (it_p, sd_p) = res[rank][False], res[rank][True]
+        for t in it_s:
+            assert np.array_equal(it_s[t], it_p[t]), (rank, t)
+        for k in sd_s:
+            assert np.array_equal(sd_s[k], sd_p[k]), (rank, k)
+    for k in res[0][True][1]:
+        assert np.array_equal(res[0][True][1][k], res[1][True][1][k]), k
