@@ -13,6 +13,7 @@ class _PlanFunction(torch.autograd.Function):
     def forward(ctx, plan, x, anchor):
         plan.run_forward(x)
         ctx.plan = plan
+        ctx.generation = plan.generation  # the saved z / mean / invstd live in the plan's buffers: valid until its next forward
         outs = []
         for t in plan.tasks:
             nc = plan.model.get_head(t).nc
@@ -22,6 +23,10 @@ class _PlanFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         plan = ctx.plan
+        if plan.generation != ctx.generation:
+            raise RuntimeError("backward() of a forward whose plan has run forward again since: the compiled plan keeps ONE set of saved "
+                               "activations per (tasks, shape, dtype) -- call backward() before the next forward of the same configuration "
+                               "(the reference's per-task forward / backward order does)")
         i = 0
         for t in plan.tasks:
             nc = plan.model.get_head(t).nc

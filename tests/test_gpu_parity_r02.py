@@ -237,3 +237,17 @@ def test_pad_targets_kernel_matches_oracle_and_counts_overflow():
     assert torch.equal(short.cpu(), got[:, :cut].cpu())
     assert int(dropped) == int(np.maximum(counts - cut, 0).sum())
     assert pad_targets({k: v[:0] for k, v in tb.items()}, 6, (96, 128), dev).shape == (6, 1, 5)
+
+
+def test_autograd_bridge_refuses_backward_after_a_newer_forward():
+    """Two forwards of one plan before backward(): the first graph's saved activations are gone -- the bridge raises instead of
+    silently replaying the second pass (the reference allocates per call; here the plan owns one set of buffers)."""
+    arrays, meta = load_golden("model_tiny2")
+    m = _build(meta).train()
+    x = torch.rand(2, 3, 64, 64, device=DEV)
+    t = meta["tasks"][0]
+    out1 = m(x, t)
+    out2 = m(x, t)
+    out2[0].float().sum().backward()  # the newest forward may go backward
+    with pytest.raises(RuntimeError, match="has run forward again"):
+        out1[0].float().sum().backward()
