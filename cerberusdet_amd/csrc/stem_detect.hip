@@ -104,14 +104,26 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N,
         const void* f = d.f[lvl];
         const int64_t base = ((int64_t)n * d.h[lvl] * d.w[lvl] + la) * no;
         float dist[4];
+        const bool vec = dtype == CDET_F32 && (no & 3) == 0;  // the engine's head maps: fp32 rows of 64 + pad8(nc) floats -> 16-byte loads
+        const f32x4* row4 = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(f) + base);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float v[16];
             float mx = -INFINITY;
+            if (vec) {
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                v[b] = load_elem(f, base + s * 16 + b, dtype);
-                mx = fmaxf(mx, v[b]);
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const f32x4 q = row4[s * 4 + b4];
+                    v[b4 * 4 + 0] = q[0]; v[b4 * 4 + 1] = q[1]; v[b4 * 4 + 2] = q[2]; v[b4 * 4 + 3] = q[3];
+                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) mx = fmaxf(mx, v[b]);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    v[b] = load_elem(f, base + s * 16 + b, dtype);
+                    mx = fmaxf(mx, v[b]);
+                }
             }
             float den = 0.f, num = 0.f;
 #pragma unroll
@@ -129,9 +141,18 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N,
         store_elem(y, yo + 1 * (int64_t)A, (y1 + y2) * 0.5f * st, out_dtype);
         store_elem(y, yo + 2 * (int64_t)A, (x2 - x1) * st, out_dtype);
         store_elem(y, yo + 3 * (int64_t)A, (y2 - y1) * st, out_dtype);
-        for (int c = 0; c < nc; ++c) {
-            const float z = load_elem(f, base + 64 + c, dtype);
-            store_elem(y, yo + (int64_t)(4 + c) * A, 1.0f / (1.0f + expf(-z)), out_dtype);
+        if (vec) {
+            for (int c4 = 0; c4 * 4 < nc; ++c4) {
+                const f32x4 q = row4[16 + c4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c4 * 4 + i < nc) store_elem(y, yo + (int64_t)(4 + c4 * 4 + i) * A, 1.0f / (1.0f + expf(-q[i])), out_dtype);
+            }
+        } else {
+            for (int c = 0; c < nc; ++c) {
+                const float z = load_elem(f, base + 64 + c, dtype);
+                store_elem(y, yo + (int64_t)(4 + c) * A, 1.0f / (1.0f + expf(-z)), out_dtype);
+            }
         }
     }
 }
