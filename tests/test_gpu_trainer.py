@@ -158,9 +158,13 @@ def test_freeze_shared_layers_then_unfreeze():
     torch.cuda.synchronize()
 
     def trunk_out(p):
+        # the last BatchNorm + SiLU of the shared blocks: (buffer, ld, coff, M, C) of its output view -- with the in-place Concat
+        # placement of an un-frozen plan that view is a channel slice of the first neck Concat's buffer
         end = dict(p.fwd_marks)[max(shared)]
-        dst = next(args[10] for fn, args in reversed(p.fwd[:end]) if getattr(fn, "__name__", "") == "cdet_bn_silu_fwd")
-        return next(t for t in p.keep if isinstance(t, torch.Tensor) and t.data_ptr() <= dst < t.data_ptr() + t.numel() * t.element_size())
+        args = next(args for fn, args in reversed(p.fwd[:end]) if getattr(fn, "__name__", "") == "cdet_bn_silu_fwd")
+        dst, ld, coff, M, C = args[10], args[11], args[12], args[13], args[14]
+        t = next(t for t in p.keep if isinstance(t, torch.Tensor) and t.data_ptr() == dst)
+        return t.reshape(-1, ld)[:M, coff:coff + C]
 
     ta = trunk_out(plan).clone()
     s_mid = snap()
