@@ -36,6 +36,32 @@ def det_tensor(seed: int, key: str, shape) -> np.ndarray:
     return rng.uniform(-b, b, shape).astype(np.float32)
 
 
+def det_tensor_wc(seed: int, key: str, shape) -> np.ndarray:
+    """Well-conditioned variant of det_tensor for the train-mode fixture `train_wc`: BatchNorm weight in [0.4, 0.6] and bias in [1, 2]
+    keep the SiLU pre-activations in its near-linear range, so a random-weight BatchNorm network no longer amplifies a 16-bit storage
+    rounding layer by layer (with det_tensor's values it does: head maps move by 5-12 % and gradient cosines fall to 0.3-0.8 when ONLY
+    the weights are rounded to bf16, see test_train_fixture_sensitivity); the class-logit bias sits at -4 like a trained head
+    (reference bias_init, models/yolo.py:102-110) so the BCE term is not dominated by 8400 confident false positives."""
+    rng = _rng(seed, key)
+    shape = tuple(shape)
+    if key.endswith("bn.weight"):
+        return rng.uniform(0.4, 0.6, shape).astype(np.float32)
+    if key.endswith("bn.bias"):
+        return rng.uniform(1.0, 2.0, shape).astype(np.float32)
+    if ".cv3." in key and key.endswith(".2.bias"):
+        return rng.uniform(-4.5, -3.5, shape).astype(np.float32)
+    return det_tensor(seed, key, shape)
+
+
+def sample(a, n=1024) -> np.ndarray:
+    """Strided sample of at most ~n elements of an array (what train_wc.npz stores of every gradient / weight tensor)."""
+    f = np.asarray(a).reshape(-1)
+    return f[::max(1, f.size // n)].copy()
+
+
+TRAIN_WC = dict(seed=21, bs=8, imgsz=128, boxes_per_img=3, iters=2)  # tests/golden/train_wc.npz (tools/make_golden.py train_wc)
+
+
 def det_image(seed: int, bs: int, imgsz: int) -> np.ndarray:
     return _rng(seed, "image").uniform(0, 1, (bs, 3, imgsz, imgsz)).astype(np.float32)
 

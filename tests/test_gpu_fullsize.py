@@ -63,6 +63,81 @@ def test_conv_checksum_and_adjoint_identities_exact(case):
     assert float(dw.abs().max()) < 2 ** 24  # the fp32 sums really were exact integers
 
 
+# (N, H, W, Cin, Cout, k, src slice (ld, coff) or None): every tile form of the tap-resident kernel at BASELINE.json's batch 32 @640 --
+# linear 256-pixel tiles (40x40), 16x16 patches (80x80, 160x160 with the 3-fragment / partial-chunk form), half tiles (20x20),
+# 1x1 incl. the 160x160 layers that run against HBM, a 2-stage-ring... (none at these widths), and a source / destination that are
+# channel slices of C2f / Concat buffers as the engine passes them.
+TILED_FULL = [(32, 40, 40, 320, 320, 3, None), (32, 80, 80, 160, 160, 3, None), (32, 160, 160, 80, 80, 3, None),
+              (32, 20, 20, 320, 320, 3, None), (32, 80, 80, 320, 320, 3, None), (32, 40, 40, 640, 320, 3, None),
+              (32, 80, 80, 960, 320, 1, None), (32, 160, 160, 400, 160, 1, None), (32, 40, 40, 1600, 640, 1, None),
+              (32, 160, 160, 160, 160, 1, None), (32, 80, 80, 160, 160, 3, (1280, 320)), (32, 20, 20, 640, 640, 1, (1280, 8))]
+
+
+def _sparse_pm1(shape, nnz_per_row, row_len, g):
+    """Tensor of {-1, 0, +1} whose expected number of non-zeros per reduction row is nnz_per_row (so that |sum| stays far below 256)."""
+    p = min(1.0, nnz_per_row / row_len)
+    mask = torch.rand(shape, generator=g, device=DEV) < p
+    sign = torch.randint(0, 2, shape, generator=g, device=DEV) * 2 - 1
+    return (mask * sign).float()
+
+
+@pytest.mark.parametrize("case", TILED_FULL)
+def test_tiled_conv_and_its_data_gradient_exact_at_full_size(case):
+    """cdet_conv2d_tiled (csrc/conv_halo.hip: the dominant kernel of the step -- every stride-1 forward and data gradient) at BASELINE
+    sizes against the plain fp32 PyTorch reference (tests/torchref.py). Operands are small integers and the weights are sparse enough
+    that every output is an integer of magnitude <= 256: exactly representable in bf16, and every fp32 partial sum is exact whatever
+    the order -- so the 16-bit output, the BatchNorm partial sums, the data gradient through the flipped / transposed operand and its
+    accumulate form (gradient fan-in) must EQUAL the reference bit for bit, over the whole tensor."""
+    import torchref as R
+    from cerberusdet_amd import ops
+
+    N, H, W, Ci, Co, k, sl = case
+    g = torch.Generator(device=DEV).manual_seed(23)
+    dtype = torch.bfloat16
+    # |x|, |dy| <= 2; weights +-1 with ~48 non-zeros per output row AND per input column -> |y|, |dx| <= 2 * (48 + 6 sigma) < 256
+    w = _sparse_pm1((Co, Ci, k, k), 48.0, max(Ci, Co) * k * k, g)
+    assert float(w.abs().sum((1, 2, 3)).max()) <= 120 and float(w.abs().sum((0, 2, 3)).max()) <= 120
+    ld, coff = sl if sl else (Ci, 0)
+    xb = torch.full((N, H, W, ld), float("nan"), dtype=dtype, device=DEV)      # channels outside the slice are NaN: never read
+    xb[..., coff:coff + Ci] = torch.randint(-2, 3, (N, H, W, Ci), generator=g, device=DEV).to(dtype)
+    src = ops.View(xb, coff, Ci)
+    x32 = src.torch().float()
+    wf, wd = ops.pack_weight_tiled(w, dtype, fwd=True, dgrad=True)
+    # ---- forward: raw output + BN partial sums, into a channel slice when the source is one
+    dld, dcoff = (Co + 24, 16) if sl else (Co, 0)
+    yb = torch.full((N, H, W, dld), 7.0, dtype=dtype, device=DEV)
+    dst = ops.View(yb, dcoff, Co)
+    assert ops.conv2d_tiled_ok(src, dst, k, 1)
+    nblk = ops.conv_tiled_stat_blocks(src, dst, k)
+    stats = torch.zeros(nblk * 2 * Co, device=DEV)
+    ops.conv2d_tiled(src, wf, dst, k, stats=stats)
+    ref = R.conv_fwd(x32, w, 1)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(dst.torch().float(), ref), f"{int((dst.torch().float() != ref).sum())} of {ref.numel()} outputs differ"
+    if sl:
+        assert bool((yb[..., :dcoff].float() == 7.0).all()) and bool((yb[..., dcoff + Co:].float() == 7.0).all())
+    st = stats.view(nblk, 2, Co).double().sum(0)
+    assert torch.equal(st[0], ref.double().sum((0, 1, 2))) and torch.equal(st[1], (ref.double() ** 2).sum((0, 1, 2)))
+    del ref
+    # ---- data gradient = forward convolution of dY with the DGRAD operand; then the same launch accumulating onto a gradient already there
+    dy = torch.randint(-2, 3, (N, H, W, Co), generator=g, device=DEV).to(dtype)
+    dyv = ops.View(dy)
+    dxb = torch.full((N, H, W, ld), 3.0, dtype=dtype, device=DEV)
+    dx = ops.View(dxb, coff, Ci)
+    ops.conv2d_tiled(dyv, wd, dx, k)
+    dref = R.conv_dgrad(dy.float(), w, 1, H, W)
+    assert float(dref.abs().max()) <= 250
+    assert torch.equal(dx.torch().float(), dref), f"{int((dx.torch().float() != dref).sum())} of {dref.numel()} gradient elements differ"
+    prev = torch.randint(-3, 4, (N, H, W, Ci), generator=g, device=DEV).to(dtype)
+    out = ops.new_act(N, H, W, Ci, dtype)
+    ops.conv2d_tiled(dyv, wd, out, k, res=ops.View(prev))
+    assert torch.equal(out.torch().float(), dref + prev.float())
+    # ---- adjoint identity with the (already pinned) weight gradient: <conv(x), dy> = <w, wgrad(x, dy)>, all exact integers
+    dw = torch.zeros(Co, Ci, k, k, device=DEV)
+    ops.conv2d_wgrad(src, dyv, dw, k, 1)
+    assert float((dw.double() * w.double()).sum()) == float((dst.torch().double() * dy.double()).sum())
+
+
 @pytest.fixture(scope="module")
 def v8x_trainer():
     import bench

@@ -340,3 +340,56 @@ def test_inference_api_predict_matches_reference_golden(tmp_path):
     y_loaded = api.model(x.to(DEV))
     for t in mmeta["tasks"]:
         assert torch.allclose(y_direct[t][0], y_loaded[t][0], rtol=1e-5, atol=1e-5)
+
+
+def test_multi_task_train_mode_forward_backward_equals_the_per_task_passes():
+    """model.train(); out = model(x) with task_ids None / a list (reference cerberus.py:804-882 returns a dict of raw head maps) runs
+    the shared trunk ONCE and every task's branch; its backward must give every task's branch the gradients of that task's own pass,
+    and the shared blocks the sum over tasks -- checked through the autograd bridge against the single-task plans on the same input."""
+    from cerberusdet_amd.models import CerberusDet
+
+    arrays, meta = load_golden("train_wc")  # well-conditioned weights: 16-bit noise stays at the percent level
+    m = CerberusDet(meta["tasks"], meta["nc"], cfg=copy.deepcopy(meta["cfg"]), verbose=False)
+    m.sequential_split(meta["cfg"]["cerber"], "cpu")
+    m.load_state_dict({k: torch.from_numpy(synth.det_tensor_wc(meta["seed"], k, v.shape)) for k, v in m.state_dict().items()})
+    m = m.to(DEV).train()
+    x = torch.from_numpy(synth.det_image(41, 4, 128)).to(DEV)
+    cots = {}
+
+    def run(task_ids):
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        out = m(x, task_ids)
+        outs = {task_ids: out} if isinstance(task_ids, str) else out
+        loss = 0
+        for t, maps in outs.items():
+            for i, f in enumerate(maps):
+                c = cots.setdefault((t, i), torch.from_numpy(synth.det_array(41, f"cot/{t}/{i}", f.shape)).to(DEV))
+                loss = loss + (f * c).sum()
+        maps = {t: [f.detach().clone() for f in v] for t, v in outs.items()}
+        loss.backward()
+        torch.cuda.synchronize()
+        return maps, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+
+    per_task = [run(t) for t in meta["tasks"]]
+    maps_all, g_all = run(list(meta["tasks"]))
+    assert set(maps_all) == set(meta["tasks"])
+    want = {}
+    for (maps, g), t in zip(per_task, meta["tasks"]):
+        for i in range(3):
+            assert torch.equal(maps_all[t][i], maps[t][i]), (t, i)  # same kernels on the same inputs: identical head maps
+        for k, v in g.items():
+            want[k] = want.get(k, 0) + v
+    assert set(want) == set(g_all)
+    shared = [k for k in want if all(k in g for _, g in per_task)]
+    assert len(shared) > 30 and len(shared) < len(want)
+    worst = 1.0
+    for k, v in want.items():
+        a, b = g_all[k].flatten().double(), v.flatten().double()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, cos)
+        if k not in shared:  # a task's own branch sees exactly the launches of its single-task plan
+            assert float((a - b).abs().max()) <= 2 ** -6 * float(b.abs().max()), k
+        assert cos > 0.97, (k, cos)
+    print(f"[multi-task train plan] {len(want)} gradient tensors ({len(shared)} shared), worst cosine vs the per-task passes {worst:.5f}")

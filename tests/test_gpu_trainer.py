@@ -34,7 +34,6 @@ def test_two_iterations_vs_reference_golden():
     # parameter groups as the reference's optimizer sees them (bias, decay, bn)
     assert tr.group_sizes == meta["param_group_sizes"]
     assert {str(k): float(max(len(v), 1)) for k, v in tr.serving.items()} == meta["num_branches"]
-    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
     for it in range(2):
         batches = {}
         for ti, t in enumerate(meta["tasks"]):
@@ -52,25 +51,102 @@ def test_two_iterations_vs_reference_golden():
             # bs 2 @64 with random weights is the noise regime of tests/test_oracle_golden.py::test_train_fixture_sensitivity
             assert np.allclose(got[:4], want, rtol=0.15, atol=0.05), (it, t, got, want)
             assert abs(got[4] - 2 * meta["bs"] * got[3]) < 1e-3 * abs(got[4])  # scalar == 2*bs*total (loss.py:179-181)
-        sd = m.state_dict()
-        esd = tr.ema.ema.state_dict()
-        for k in meta["watch"]:
-            w_ref, w_got, w0 = arrays[f"it{it}/w/{k}"], sd[k].float().cpu().numpy(), sd_before[k].float().cpu().numpy()
-            e_ref, e_got = arrays[f"it{it}/ema/{k}"], esd[k].float().cpu().numpy()
-            # the UPDATE (w - w0) is gradient noise-limited; the values themselves must agree to the size of the update
-            scale = np.abs(w_ref - synth.det_tensor(mmeta["seed"], k, w_ref.shape)).max() + 1e-12
-            # (1.25: the bound is the noise floor itself -- which kernel family / tiling carries a layer changes the fp32 summation
-            #  order and with it the realisation of the bf16 noise; round 2's tap-resident kernel moved the worst tensor from 0.9 to 1.07)
-            assert np.abs(w_got - w_ref).max() < 1.25 * scale + 1e-6, (it, k, np.abs(w_got - w_ref).max(), scale)
-            assert np.abs(e_got - e_ref).max() < 1.25 * scale + 1e-6, (it, k)  # d ~ 5e-4 at update 1: the EMA tracks w
-            if "running" not in k:
-                d_ref, d_got = (w_ref - w0).ravel(), (w_got - w0).ravel()
-                if np.linalg.norm(d_ref) > 0:
-                    c = float(d_ref @ d_got / (np.linalg.norm(d_ref) * np.linalg.norm(d_got) + 1e-30))
-                    print(f"it{it} {k}: update cosine {c:.3f}")
-                    assert c > 0.5, (it, k, c)
+        # (This fixture -- bs 2 @64, BatchNorm over 8 samples, a chaotic random-weight net -- cannot separate 16-bit storage noise from a
+        #  wrong update: rounding only the weights to bf16 in the fp32 oracle already moves its gradients by O(1). The weights, running
+        #  statistics and updates of the trainer are compared with the reference on the well-conditioned fixture instead:
+        #  test_two_iterations_vs_well_conditioned_reference_golden.)
         # gradients are zeroed by the fused step
         assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters() if p.grad is not None)
+
+
+def _wc_model(meta):
+    from cerberusdet_amd.models import CerberusDet
+
+    m = CerberusDet(meta["tasks"], meta["nc"], cfg=copy.deepcopy(meta["cfg"]), verbose=False)
+    m.sequential_split(meta["cfg"]["cerber"], "cpu")
+    m.load_state_dict({k: torch.from_numpy(synth.det_tensor_wc(meta["seed"], k, v.shape)) for k, v in m.state_dict().items()})
+    m.hyp = meta["hyp"]
+    return m.to(DEV).train()
+
+
+def _wc_batch(meta, ti, img_seed, label_seed):
+    img = torch.from_numpy(synth.det_image(img_seed + ti, meta["bs"], meta["imgsz"])).to(DEV)
+    b = synth.make_batch(meta["bs"], meta["boxes_per_img"], meta["nc"][ti], label_seed + ti)
+    return dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()})
+
+
+def test_one_pass_vs_well_conditioned_reference_golden():
+    """tests/golden/train_wc (REAL reference; weights synth.det_tensor_wc keep the random net out of the chaotic regime, batch 8 @128):
+    one forward + criterion + backward per task through the compiled train launch list. Head maps within 1.2 % rel-L2, loss items within
+    2 %, and EVERY parameter gradient within the 16-bit-storage bounds util.WC_BOUNDS (median rel-L2 <= 8 %, worst cosine >= 0.85,
+    90 % of the tensors above 0.97) -- the same bounds the bf16-emulating fp32 oracle meets on this fixture (CPU test
+    test_train_wc_fixture_oracle_matches_reference_and_is_well_conditioned). Reference: trainers/averaging.py:142-168, utils/loss.py:133-181."""
+    from cerberusdet_amd.trainers import Averaging
+    from util import WC_BOUNDS, update_error, wc_check
+
+    arrays, meta = load_golden("train_wc")
+    m = _wc_model(meta)
+    tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False)
+    errs = []
+    for ti, t in enumerate(meta["tasks"]):
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        batch = _wc_batch(meta, ti, 300, 400)
+        loss5 = tr.forward_backward(t, batch, active_tasks=[t])
+        torch.cuda.synchronize()
+        plan = m.get_plan(t, batch["img"].shape, batch["img"].dtype, training=True)
+        nc = meta["nc"][ti]
+        for i, f in enumerate(plan.feats[t]):
+            got = synth.sample(f[..., :64 + nc].permute(0, 3, 1, 2).float().cpu().numpy(), 16384)
+            ref = arrays[f"A/{t}/feat{i}"]
+            e = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            assert e < WC_BOUNDS["map_rel_l2"], (t, i, e)
+        items = loss5.cpu().numpy()
+        assert np.allclose(items[:4], arrays[f"A/{t}/items"], rtol=WC_BOUNDS["items_rtol"]), (t, items, arrays[f"A/{t}/items"])
+        assert abs(items[4] - meta["A_loss"][t]) < WC_BOUNDS["items_rtol"] * abs(items[4])
+        named = dict(m.named_parameters())
+        keys = [k[len(f"A/{t}/grad/"):] for k in arrays if k.startswith(f"A/{t}/grad/")]
+        assert len(keys) >= 170
+        for k in keys:
+            errs.append(update_error(synth.sample(named[k].grad.float().cpu().numpy()), arrays[f"A/{t}/grad/{k}"]) + (f"{t}:{k}",))
+    print("[train_wc/HIP] " + wc_check(errs, "gradients of one pass per task"))
+
+
+def test_two_iterations_vs_well_conditioned_reference_golden():
+    """Two iterations of the trainer (per-task forward / loss / backward, clip, per-block division, SGD-Nesterov, EMA; reference
+    trainers/averaging.py:132-223) against the real reference on the well-conditioned fixture: loss items within 2 %, the global
+    gradient norm within 2 %, and the UPDATE of every parameter tensor (w - w_start, strided sample) within util.WC_BOUNDS of the
+    reference's update; BatchNorm running statistics within 1e-3 of their scale."""
+    from cerberusdet_amd.trainers import Averaging
+    from util import WC_BOUNDS, update_error, wc_check
+
+    arrays, meta = load_golden("train_wc")
+    m = _wc_model(meta)
+    tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000)
+    start = {k: v.detach().float().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    for it in range(meta["iters"]):
+        out = {}
+        for ti, t in enumerate(meta["tasks"]):
+            out[t] = tr.forward_backward(t, _wc_batch(meta, ti, 500 + 10 * it, 600 + 10 * it), active_tasks=meta["tasks"])
+        tr.optimizer_step([meta["hyp"]["lr0"]] * 3, meta["hyp"]["momentum"])
+        torch.cuda.synchronize()
+        for t in meta["tasks"]:
+            got, want = out[t].cpu().numpy(), arrays[f"B/it{it}/{t}/items"]
+            assert np.allclose(got[:4], want, rtol=WC_BOUNDS["items_rtol"]), (it, t, got, want)
+        sd = m.state_dict()
+        errs = []
+        for k in arrays:
+            if not k.startswith(f"B/it{it}/w/"):
+                continue
+            name = k[len(f"B/it{it}/w/"):]
+            got = sd[name].float().cpu().numpy()
+            if name in meta["stat_keys"]:
+                assert np.abs(got - arrays[k]).max() <= 1e-3 * (np.abs(arrays[k]).max() + 1e-6), (it, name)
+            elif np.abs(arrays[k] - synth.sample(start[name])).max() > 0:
+                errs.append(update_error(synth.sample(got), arrays[k], synth.sample(start[name])) + (name,))
+        assert len(errs) >= 170
+        print(f"[train_wc/HIP] it{it} " + wc_check(errs, "parameter updates"))
 
 
 @pytest.mark.parametrize("which", ["model_tiny2", "model_tiny3"])

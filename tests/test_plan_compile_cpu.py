@@ -1,0 +1,87 @@
+"""Host-side checks that need no GPU: the plan compiler (engine.Plan) on the shipped model YAMLs, and the fp32 GEMM-form convolution
+reference used by the GPU parity tests.
+
+engine.Plan only CALLS kernels when a plan runs; compiling one needs the library's host-side geometry helpers (cdet_conv2d_tiled_ok,
+*_stat_blocks, *_ws_elems) and torch allocations, both of which work on the CPU. So every (task set, train / eval) combination the
+reference's forward accepts (cerberus.py:804-882: a str, a list, None = all tasks; model.train() or model.eval()) is compiled here."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+import torchref as R
+
+CFG_DIR = os.path.join(os.path.dirname(__file__), "..", "cerberusdet_amd", "models", "cfg")
+NCS = {"voc": 20, "objects365_animals": 19, "objects365_tableware": 12}
+
+
+def _model(cfg_name, tasks):
+    from cerberusdet_amd.models import CerberusDet
+
+    cfg = yaml.safe_load(open(os.path.join(CFG_DIR, cfg_name)))
+    m = CerberusDet(tasks, [NCS[t] for t in tasks], cfg=cfg, verbose=False)
+    if cfg.get("cerber"):
+        m.sequential_split(cfg["cerber"], "cpu")
+    return m
+
+
+@pytest.mark.parametrize("cfg_name,tasks", [("v8x_2task.yaml", ["voc", "objects365_animals"]),
+                                            ("v8x_3task.yaml", ["voc", "objects365_animals", "objects365_tableware"]),
+                                            ("v8n_2task.yaml", ["voc", "objects365_animals"])])
+def test_every_task_set_compiles_in_train_and_eval_form(cfg_name, tasks):
+    from cerberusdet_amd.engine import Plan
+
+    m = _model(cfg_name, tasks)
+    dev = torch.device("cpu")
+    single = {}
+    for training in (False, True):
+        for ts in [[t] for t in tasks] + [tasks]:
+            p = Plan(m, ts, 2, 64, 64, training, torch.bfloat16, torch.uint8, dev)
+            assert p.n_fwd_calls > 0 and (p.n_bwd_calls > 0) == training
+            if len(ts) == 1:
+                single[(training, ts[0])] = p
+            elif training:
+                # the multi-task training plan (model.train(); model(x)): the shared trunk runs once, every task's branch is there,
+                # and each conv unit has a backward -- fewer launches than the per-task plans together
+                convs = sum(1 for r in p.trace if r["kind"] == "conv")
+                per_task = [sum(1 for r in single[(True, t)].trace if r["kind"] == "conv") for t in tasks]
+                assert max(per_task) < convs < sum(per_task)
+                assert all("bwd_lo" in r for r in p.trace if r["kind"] in ("conv", "bias"))
+                assert any(r["kind"] == "copy" for r in p.trace)  # the backbone taps both necks concatenate are copied, not placed
+    # single-task training plans keep every Concat input in place except the ones a non-Conv producer feeds
+    assert sum(1 for r in single[(True, tasks[0])].trace if r["kind"] == "copy") <= 2
+
+
+def test_frozen_trunk_plan_compiles_without_backward_for_shared_blocks():
+    from cerberusdet_amd.engine import Plan
+    from cerberusdet_amd.models import CerberusDet
+
+    tasks = ["voc", "objects365_animals"]
+    m = _model("v8n_2task.yaml", tasks)
+    CerberusDet.freeze_shared_layers(m)
+    frozen = tuple(i for i, b in enumerate(m.blocks) if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters()))
+    assert 0 in frozen
+    p = Plan(m, [tasks[0]], 2, 64, 64, True, torch.bfloat16, torch.uint8, torch.device("cpu"), frozen=frozen)
+    assert 0 in p.dead and all(idx not in p.dead or not calls for idx, calls in p.bwd_groups)
+
+
+@pytest.mark.parametrize("case", [(2, 9, 7, 5, 6, 3, 1), (2, 8, 8, 4, 3, 3, 2), (1, 5, 6, 7, 2, 1, 1), (2, 7, 9, 3, 4, 3, 2)])
+def test_gemm_form_reference_equals_torch_conv2d_and_its_autograd(case):
+    N, H, W, Ci, Co, k, s = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, H, W, Ci, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g)
+    xn = x.permute(0, 3, 1, 2).clone().requires_grad_()
+    wn = w.clone().requires_grad_()
+    y = F.conv2d(xn, wn, None, s, k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dyn = dy.permute(0, 2, 3, 1).contiguous()
+    assert torch.allclose(R.conv_fwd(x, w, s), y.detach().permute(0, 2, 3, 1), atol=1e-4)
+    assert torch.allclose(R.conv_dgrad(dyn, w, s, H, W), xn.grad.permute(0, 2, 3, 1), atol=1e-4)
+    assert torch.allclose(R.conv_wgrad(x, dyn, k, s), wn.grad, atol=1e-4)
+    # integer operands: exact, whatever the order
+    xi, wi = torch.randint(-2, 3, x.shape).float(), torch.randint(-1, 2, w.shape).float()
+    assert torch.equal(R.conv_fwd(xi, wi, s), F.conv2d(xi.permute(0, 3, 1, 2), wi, None, s, k // 2).permute(0, 2, 3, 1))

@@ -401,6 +401,84 @@ def gen_trainer_fixture(m, tasks, nc, cfg):
     json.dump(meta, open(OUT / "trainer.json", "w"), indent=1)
 
 
+def gen_train_wc_fixture():
+    """Well-conditioned train-mode fixture (tests/golden/train_wc.npz): the tiny 2-task model with synth.det_tensor_wc weights at
+    batch 8 @128. Part A: one forward + Loss + backward per task from the initial weights (head maps, loss items, EVERY parameter
+    gradient). Part B: two iterations of Averaging's inner loop + optimizer_step + EMA (trainers/averaging.py:142-223): loss items,
+    the total gradient norm, every parameter and a few running statistics / EMA entries after each iteration
+    (gradients / weights as strided samples of <= ~1024 elements per tensor, synth.sample)."""
+    from cerberusdet.models.cerberus import CerberusDet
+    from cerberusdet.trainers.averaging import Averaging, get_optimizer
+    from cerberusdet.utils.loss import Loss
+    from cerberusdet.utils.torch_utils import ModelEMA
+
+    W = synth.TRAIN_WC
+    seed, bs, imgsz, nbox = W["seed"], W["bs"], W["imgsz"], W["boxes_per_img"]
+    cfg = tiny_cfg(False)
+    tasks, nc = ["voc", "objects365_animals"], [20, 19]
+    m = CerberusDet(task_ids=tasks, nc=nc, cfg=copy.deepcopy(cfg), ch=3, verbose=False)
+    m.sequential_split(copy.deepcopy(cfg["cerber"]), "cpu")
+    sd = m.state_dict()
+    for k, v in sd.items():
+        v.copy_(torch.from_numpy(synth.det_tensor_wc(seed, k, v.shape)))
+    m.load_state_dict(sd)
+    m.hyp = HYP
+    m.train()
+    arrays, meta = {}, dict(tasks=tasks, nc=nc, cfg=cfg, hyp=HYP, torch=torch.__version__, iter_info=[], **W)
+    crit = Loss(m, tasks)
+    # ---- part A
+    sd0 = copy.deepcopy(m.state_dict())
+    for ti, t in enumerate(tasks):
+        x = torch.from_numpy(synth.det_image(300 + ti, bs, imgsz))
+        batch = make_batch(bs, nbox, nc[ti], 400 + ti)
+        m.zero_grad()
+        feats = m(x, t)
+        loss, items = crit(feats, dict(batch, img=x), t)
+        loss.backward()
+        for i, f in enumerate(feats):
+            arrays[f"A/{t}/feat{i}"] = synth.sample(f.detach().numpy(), 16384)
+        arrays[f"A/{t}/items"] = items.numpy()
+        meta.setdefault("A_loss", {})[t] = float(loss)
+        for k, p in m.named_parameters():
+            if p.grad is not None and float(p.grad.abs().max()) > 0:
+                arrays[f"A/{t}/grad/{k}"] = synth.sample(p.grad.numpy())  # strided sample of <= ~1024 elements per tensor
+        m.load_state_dict(sd0)  # BN running statistics back to the start
+    m.zero_grad()
+    # ---- part B
+    ema = ModelEMA(m)
+    tr = object.__new__(Averaging)
+    tr.optimizer = get_optimizer(m, HYP)
+    tr.scaler = torch.amp.GradScaler("cuda", enabled=False)
+    num_branches = {idx: torch.tensor(float(max(len(c.serving_tasks), 1.0))) for idx, (c, b) in enumerate(m.control_blocks())}
+    tr.optimizer.zero_grad()
+    stat_keys = [k for k in m.state_dict() if k.endswith(("running_mean", "running_var"))]
+    stat_keys = stat_keys[:4] + stat_keys[len(stat_keys) // 2: len(stat_keys) // 2 + 4] + stat_keys[-4:]
+    for it in range(W["iters"]):
+        info = {}
+        for ti, t in enumerate(tasks):
+            x = torch.from_numpy(synth.det_image(500 + 10 * it + ti, bs, imgsz))
+            batch = make_batch(bs, nbox, nc[ti], 600 + 10 * it + ti)
+            out = m(x, t)
+            loss, items = crit(out, dict(batch, img=x), t)
+            loss.backward()
+            arrays[f"B/it{it}/{t}/items"] = items.numpy()
+            info[t] = float(loss)
+        gsq = sum(float((p.grad.double() ** 2).sum()) for p in m.parameters() if p.grad is not None)
+        info["grad_norm"] = gsq ** 0.5
+        tr.optimizer_step(m, ema, num_branches)
+        sd, esd = m.state_dict(), ema.ema.state_dict()
+        for k, p in m.named_parameters():
+            arrays[f"B/it{it}/w/{k}"] = synth.sample(sd[k].numpy())
+        for k in stat_keys:
+            arrays[f"B/it{it}/w/{k}"] = sd[k].numpy().copy()
+        for k in list(dict(m.named_parameters()))[::12]:
+            arrays[f"B/it{it}/ema/{k}"] = synth.sample(esd[k].numpy())
+        meta["iter_info"].append(info)
+    meta["stat_keys"] = stat_keys
+    np.savez_compressed(OUT / "train_wc.npz", **arrays)
+    json.dump(meta, open(OUT / "train_wc.json", "w"), indent=1)
+
+
 def main():
     if not REF.exists():
         sys.exit("make_golden.py needs /root/reference (build container only)")
@@ -409,6 +487,10 @@ def main():
     sys.path.insert(0, str(REF))
     torch.set_num_threads(8)
     torch.manual_seed(0)
+    if sys.argv[1:] == ["train_wc"]:  # only the well-conditioned train fixture (the others are untouched)
+        gen_train_wc_fixture()
+        print("train_wc done", (OUT / "train_wc.npz").stat().st_size // 1024, "KiB")
+        return
     ka = gen_graph_known_answers()
     ka["clones"] = gen_clone_fixture()
     json.dump(ka, open(OUT / "graph_known_answers.json", "w"), indent=1)
@@ -423,6 +505,8 @@ def main():
     print("nms done")
     gen_trainer_fixture(m, tasks, nc, cfg)
     print("trainer done")
+    gen_train_wc_fixture()
+    print("train_wc done")
     for f in sorted(OUT.iterdir()):
         print(f"{f.name:32s} {f.stat().st_size / 1024:9.1f} KiB")
 
