@@ -10,6 +10,7 @@ synthetic 640x640 images -> forward -> TAL/CIoU/DFL/BCE loss -> backward (gradie
 Inputs are resident in HBM before the timed region (synthetic data). Rank 0 prints ONE JSON line.
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -64,8 +65,9 @@ def _cpu_baseline_worker(cfg, q):
     """Child process (never touches the GPU): the CPU oracle (pure torch fp32 restatement of the reference's graph / loss / NMS,
     pinned against the real reference by tests/golden) timed on the host cores -- BASELINE.md section 4:
       value  one task pass fwd + loss + bwd of the headline model (YOLOv8x 2-task) at bs 1 @640 -- the metric's workload, bounded;
-      extra  (i) BASELINE config 1: YOLOv8n 1-task bs 2 @640 fwd + loss + bwd + SGD-nesterov step, (ii) YOLOv8x 2-task all-heads
-             eval forward bs 1, (iii) NMS (inference settings) on the section-8d prediction tensor, 16 images."""
+      extra  BASELINE.md section 4's workloads with its protocol (3 warm-up + 10 timed iterations, median): (i) BASELINE config 1: YOLOv8n
+             1-task bs 2 @640 fwd + loss + bwd + SGD-nesterov step, (ii) YOLOv8x 2-task all-heads eval forward bs 1 and bs 8,
+             (iii) NMS (inference settings) on the section-8d prediction tensor, 128 images."""
     import yaml
 
     from oracle import graph as og
@@ -98,17 +100,26 @@ def _cpu_baseline_worker(cfg, q):
             n_img += 1
     dt = time.perf_counter() - t0
     extra = {}
-    try:  # (ii) all-heads eval forward, bs 1
-        x1 = synth_batch(0, 0, 1, 1, NC[0], 640, "cpu")["img"].float() / 255
+
+    def timed(fn, warm=3, n=10):
+        """BASELINE.md section 4 protocol: 3 warm-up + 10 timed iterations, median (seconds)."""
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t1 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t1)
+        return sorted(ts)[len(ts) // 2]
+
+    try:
+        # (ii) all-heads eval forward, bs 1 and bs 8
         with torch.no_grad():
-            og.forward(g, w, x1, None, training=False)
-            ts = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                og.forward(g, w, x1, None, training=False)
-                ts.append(time.perf_counter() - t1)
-        extra["v8x_2task_allheads_forward_bs1"] = {"ms": round(sorted(ts)[1] * 1e3, 1), "images_per_sec": round(1 / sorted(ts)[1], 3)}
-        # (i) config 1
+            for bsx in (1, 8):
+                xb = synth_batch(0, 0, 1, bsx, NC[0], 640, "cpu")["img"].float() / 255
+                m = timed(lambda: og.forward(g, w, xb, None, training=False))
+                extra[f"v8x_2task_allheads_forward_bs{bsx}"] = {"ms": round(m * 1e3, 1), "images_per_sec": round(bsx / m, 3)}
+        # (i) config 1: YOLOv8n 1-task bs 2 @640, forward + loss + backward + SGD step
         cfgn = yaml.safe_load(open(ROOT / "cerberusdet_amd" / "models" / "cfg" / "v8n.yaml"))
         gn = og.build_graph(cfgn, ["voc"], [20])
         wn = og.init_weights(gn, seed=0)
@@ -116,26 +127,25 @@ def _cpu_baseline_worker(cfg, q):
         opt = torch.optim.SGD([v for v in wtn.values() if isinstance(v, torch.Tensor) and v.requires_grad], lr=0.00309, momentum=0.952, nesterov=True)
         bn = synth_batch(0, 0, 2, 2, 20, 640, "cpu")
         xn = bn["img"].float() / 255
-        ts = []
-        for it in range(4):
-            t1 = time.perf_counter()
+
+        def step_n():
             opt.zero_grad()
             f = og.forward(gn, wtn, xn, "voc", training=True)
             sc, _ = ol.detection_loss(f, bn, 20, dict(box=7.5, cls=0.5, dfl=1.5))
             sc.backward()
             opt.step()
-            if it:
-                ts.append(time.perf_counter() - t1)
-        extra["config1_v8n_1task_bs2_train_step"] = {"ms": round(sorted(ts)[1] * 1e3, 1), "images_per_sec": round(2 / sorted(ts)[1], 2)}
-        # (iii) NMS
-        y = nms_inputs(16, 20, 8400, dtype=torch.float32).numpy()
-        t1 = time.perf_counter()
-        on.non_max_suppression(y, conf_thres=0.25, iou_thres=0.45, max_det=300)
-        extra["nms_infer_settings_16_images"] = {"ms": round((time.perf_counter() - t1) * 1e3, 1)}
+
+        m = timed(step_n)
+        extra["config1_v8n_1task_bs2_train_step"] = {"ms": round(m * 1e3, 1), "images_per_sec": round(2 / m, 2)}
+        # (iii) NMS (inference settings) on the section-8d prediction tensor, batch 128
+        y = nms_inputs(128, 20, 8400, dtype=torch.float32).numpy()
+        m = timed(lambda: on.non_max_suppression(y, conf_thres=0.25, iou_thres=0.45, max_det=300))
+        extra["nms_infer_settings_128_images"] = {"ms": round(m * 1e3, 1)}
+        extra["protocol"] = "BASELINE.md section 4: 3 warm-up + 10 timed iterations, median, fp32, all host cores"
     except Exception as e:  # the headline sample above stands on its own
         extra["error"] = repr(e)
     q.put(dict(value=round(n_img / dt, 4), unit="images/sec", cores=n_thr, cpu_model=cpu, kind="port",
-               sample=f"{n_img} task passes (fwd + loss + bwd per task, no optimizer; both tasks, twice, after one untimed pass) of the YOLOv8x 2-task model @640 at batch 1, CPU oracle (torch fp32), {dt:.1f} s",
+               sample=f"{n_img} task passes (fwd + loss + bwd per task, no optimizer; both tasks, twice, after one untimed pass) of the YOLOv8x 2-task model @640 at batch 1, CPU oracle (torch fp32), {dt:.1f} s; extra = BASELINE.md section 4 workloads, 3 warm-up + 10 timed iterations each, median",
                extra=extra))
 
 
@@ -259,7 +269,7 @@ def north_star_forward(model, device, bs=32, imgsz=640, reps=40):
         t_w = time.perf_counter()
         n_w = 0
         while n_w < 5 or time.perf_counter() - t_w < 1.0:
-            model(x)
+            model(x, zero_copy=True)
             n_w += 1
             if n_w % 10 == 0:
                 torch.cuda.synchronize()
@@ -267,14 +277,21 @@ def north_star_forward(model, device, bs=32, imgsz=640, reps=40):
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
-            model(x)
+            model(x, zero_copy=True)  # outputs are views of the plan's buffers (what CerberusDetInference / val.run consume)
         e1.record()
         torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+        ms = e0.elapsed_time(e1) / reps
+        e0.record()
+        for _ in range(reps):
+            model(x)  # the reference-like default: fresh output tensors per call (one device copy of y and the head maps)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_fresh = e0.elapsed_time(e1) / reps
     tf = bs * 381.31e9 * (imgsz / 640) ** 2 / (ms * 1e-3) / 1e12
     model.train()
     return {"ms": round(ms, 3), "tflops": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "images_per_sec": round(bs / ms * 1e3, 1),
             "config": f"YOLOv8x 2-task all-heads forward + decode, eval form (BN folded), bf16, batch {bs} @{imgsz}",
+            "ms_with_fresh_output_tensors": round(ms_fresh, 3),
             "gflop_per_image": 381.31, "timing": f"HIP events around {reps} back-to-back forwards on the launch stream after {n_w} warm-up forwards (>= 1 s)"}
 
 
@@ -289,12 +306,12 @@ def inference_section(model, device, bs=128, imgsz=640, reps=10, nms_reps=50):
         t_w = time.perf_counter()
         n_w = 0
         while n_w < 2 or time.perf_counter() - t_w < 1.0:  # clock ramp-up, see north_star_forward
-            model(x)
+            model(x, zero_copy=True)
             torch.cuda.synchronize()
             n_w += 1
         t0 = time.perf_counter()
         for _ in range(reps):
-            model(x)
+            model(x, zero_copy=True)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     out["infer_images_per_sec"] = round(bs / dt, 1)
@@ -324,15 +341,30 @@ def inference_section(model, device, bs=128, imgsz=640, reps=10, nms_reps=50):
 def predict_e2e(model, device, bs=32, reps=5):
     """End-to-end CerberusDetInference.predict throughput (reference cerberusdet_inference.py + cerberusdet_preprocessor.py): host
     uint8 BGR 720x1280 frames -> upload + GPU letterbox -> fp16 all-heads forward -> per-task batched NMS -> cross-task merge +
-    scale_boxes -> one D2H copy -> list of dicts. Synthetic frames, random-init weights (no detections survive conf 0.25, so the
-    NMS stage is at its floor; its cost under load is nms_infer above)."""
+    scale_boxes -> one D2H copy -> list of dicts. Synthetic frames, random-init weights. With the reference's bias_init (class logit
+    bias -10) nothing would survive conf 0.25 and NMS / merge / dict building would run at their floor, so the class-logit biases of
+    every head are shifted (calibrated on these frames) until about 100 anchors per image and task pass the confidence threshold:
+    NMS, the cross-task merge, the D2H copy and the result dicts then do the work of a trained detector's busy frame."""
+    import copy
+
     from cerberusdet_amd.cerberusdet_inference import CerberusDetInference
     from cerberusdet_amd.cerberusdet_preprocessor import CerberusPreprocessor
 
+    model = copy.deepcopy(model)
     det = CerberusDetInference(model, device=str(device), half=True, img_size=640)
     pre = CerberusPreprocessor(img_size=640, stride=det.stride, half=True, auto=False)
     rng = np.random.default_rng(11)
     frames = [rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8) for _ in range(bs)]
+    with torch.no_grad():  # calibrate: shift every head's class-logit bias so that ~100 anchors per image exceed conf 0.25
+        out = det.model(pre.preprocess(frames, device), zero_copy=True)
+        for t, (y, _) in out.items():
+            best = y[:, 4:].float().amax(1).clamp(1e-7, 1 - 1e-7)               # [bs, A] best class probability per anchor
+            logit = torch.log(best / (1 - best))
+            q = torch.quantile(logit.flatten().float().cpu(), 1 - 100.0 / logit.shape[1])
+            shift = float(math.log(0.25 / 0.75) - q)
+            for lvl in range(3):
+                det.model.get_head(t).cv3[lvl][2].bias += shift
+        det.model.mark_weights_changed()
     stages = {"preprocess_ms": [], "predict_ms": []}
     for i in range(reps + 2):
         torch.cuda.synchronize()
@@ -350,7 +382,72 @@ def predict_e2e(model, device, bs=32, reps=5):
     return {"infer_e2e_images_per_sec": round(bs / ((pm + qm) * 1e-3), 1),
             "infer_e2e": {"batch": bs, "frame": "720x1280 BGR uint8 (host memory)", "preprocess_ms": round(pm, 2), "predict_ms": round(qm, 2),
                           "results_per_image": round(sum(len(r) for r in res) / bs, 1),
-                          "note": "preprocess includes the PCIe upload of the raw frames; predict = forward + NMS + merge + D2H + dict build"}}
+                          "note": "preprocess includes the PCIe upload of the raw frames; predict = forward + NMS + merge + D2H + dict build; class-logit biases shifted so that ~100 anchors per image and task pass conf 0.25 (random weights otherwise yield no detection)"}}
+
+
+def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
+    """8-GPU readiness that one GPU can prove: the host ORDER in which every rank enqueues its collectives. One communicator serialises
+    them in enqueue order, so two ranks that enqueue different sequences deadlock (or reduce the wrong tensors into each other). Here
+    torch.distributed.all_reduce is replaced by a recorder -- (bytes, stream, position); nothing is sent -- and the trainer runs a few
+    iterations once per VIRTUAL rank (its own rank id, its own synthetic shard) for the 2-task and the 3-task model, with SyncBatchNorm
+    and gradient reduction on, task streams on, and a --skip-batches pattern (all tasks / first only / all / last only). The recorded
+    sequences must be identical on all virtual ranks. Reference: train.py:140-143 (SyncBatchNorm), 182-184 (DDP), trainers/averaging.py:144-163."""
+    import yaml
+
+    from cerberusdet_amd.models import CerberusDet
+    from cerberusdet_amd.trainers import Averaging
+
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29513")
+    os.environ["CDET_REDUCE_ALWAYS"] = "1"
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)  # a real (1-rank) group: the plans compile their SyncBN form
+    real = dist.all_reduce
+    log, streams = [], {}
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def recorder(t, op=None, group=None, async_op=False):
+        sid = streams.setdefault(torch.cuda.current_stream().cuda_stream, len(streams))
+        log.append((t.numel() * t.element_size(), sid))
+        return _Done() if async_op else None
+
+    out = {"mode": "dry-comm", "virtual_ranks": virtual_ranks, "batch": batch, "imgsz": imgsz, "plans": {}}
+    ok = True
+    try:
+        dist.all_reduce = recorder
+        for cfg_name, tasks, ncs in (("v8x_2task.yaml", TASKS, NC), ("v8x_3task.yaml", TASKS + ["objects365_tableware"], NC + [12])):
+            cfg = yaml.safe_load(open(ROOT / "cerberusdet_amd" / "models" / "cfg" / cfg_name))
+            patterns = [list(tasks), tasks[:1], list(tasks), tasks[-1:]]
+            seqs = []
+            for vr in range(virtual_ranks):
+                torch.manual_seed(0)
+                model = CerberusDet(tasks, ncs, cfg=cfg, verbose=False)
+                model.sequential_split(cfg["cerber"], "cpu")
+                model.hyp = HYP
+                model = model.to(device).train()
+                tr = Averaging(device, model, HYP, tasks, epochs=100, nb=1000, rank=vr, world_size=virtual_ranks, sync_bn=True)
+                per_step = []
+                for i, active in enumerate(patterns):
+                    log.clear()
+                    tr.train_step({t: synth_batch(vr, tasks.index(t), i, batch, ncs[tasks.index(t)], imgsz, device) for t in active}, n_max=8)
+                    torch.cuda.synchronize()
+                    per_step.append(list(log))
+                seqs.append(per_step)
+                del tr, model
+            same = all(s_ == seqs[0] for s_ in seqs[1:])
+            ok = ok and same
+            out["plans"][cfg_name] = {"identical_on_all_ranks": same,
+                                      "steps": [{"active_tasks": a, "collectives": len(st), "bytes": sum(b for b, _ in st),
+                                                 "streams_used": len({s_ for _, s_ in st})} for a, st in zip(patterns, seqs[0])]}
+    finally:
+        dist.all_reduce = real
+        dist.destroy_process_group()
+    out["identical_on_all_ranks"] = ok
+    return out
 
 
 def main():
@@ -361,11 +458,16 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per task per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--cfg", default="v8x_2task.yaml")
+    ap.add_argument("--dry-comm", action="store_true", help="record (do not execute) every collective of a few iterations for several virtual ranks and check that "
+                    "all ranks enqueue the same sequence (2- and 3-task plans, SyncBatchNorm, --skip-batches pattern); prints one JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (BASELINE.json configs[2]); default: per-GPU statistics")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference + NMS section (secondary part of the metric)")
     args = ap.parse_args()
+    if args.dry_comm:
+        print(json.dumps(dry_comm(args)))
+        return
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -428,6 +530,11 @@ def main():
     loss_items = {t: [round(float(v), 5) for v in items[t].tolist()] for t in TASKS}
     finite = all(np.isfinite(v).all() for v in loss_items.values())
 
+    agg_all = None
+    if not args.no_breakdown and args.sync_bn and world > 1:
+        # SyncBatchNorm's per-layer collectives sit inside the launch lists: EVERY rank replays the instrumented iteration (the gradient
+        # reducer stays off in the replay), rank 0 reports
+        agg_all = kernel_breakdown(trainer, data[0], n_max)
     if rank == 0:
         imgs_per_step = args.batch * len(TASKS) * world
         value = imgs_per_step * args.steps / dt
@@ -443,8 +550,8 @@ def main():
             "step_tflop_per_gpu": round(step_tflop, 2), "achieved_tflops_per_gpu": round(step_tflop / (ms_per_step / 1e3), 1),
             "loss_items": loss_items, "loss_finite": bool(finite),
         }
-        if not args.no_breakdown and not (args.sync_bn and world > 1):  # (SyncBN's per-layer collectives cannot be replayed by one rank)
-            agg = kernel_breakdown(trainer, data[0], n_max)
+        if not args.no_breakdown:
+            agg = agg_all if agg_all is not None else kernel_breakdown(trainer, data[0], n_max)
             tot = sum(a["ms"] for a in agg.values())
             out["kernel_ms"] = {k: round(a["ms"], 3) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
             out["kernel_ms_total"] = round(tot, 3)

@@ -17,11 +17,15 @@ from .models import CerberusDet
 from .utils.general import check_img_size, nms_between_tasks, non_max_suppression, scale_boxes
 
 
-def save_checkpoint(path, model: CerberusDet, names: Dict[str, List[str]] = None):
+def checkpoint_dict(model: CerberusDet, names: Dict[str, List[str]] = None) -> dict:
     """Portable checkpoint: plain state dict in the reference's key schema + what is needed to rebuild the graph."""
-    torch.save(dict(format="cerberusdet_amd/1", cfg=model.yaml, task_ids=list(model.heads.keys()),
-                    nc=[model.get_head(t).nc for t in model.heads], names=names or getattr(model, "names", None),
-                    fused=any(getattr(m, "fused", False) for m in model.modules()), state_dict=model.state_dict()), path)
+    return dict(format="cerberusdet_amd/1", cfg=model.yaml, task_ids=list(model.heads.keys()),
+                nc=[model.get_head(t).nc for t in model.heads], names=names or getattr(model, "names", None),
+                fused=any(getattr(m, "fused", False) for m in model.modules()), state_dict=model.state_dict())
+
+
+def save_checkpoint(path, model: CerberusDet, names: Dict[str, List[str]] = None):
+    torch.save(checkpoint_dict(model, names), path)
 
 
 def attempt_load(weights, map_location=None) -> CerberusDet:
@@ -81,7 +85,7 @@ class CerberusDetInference:
         conf_thres = self.conf_thres if conf_thres is None else conf_thres
         iou_thres = self.iou_thres if iou_thres is None else iou_thres
         iou_bt = self.iou_thres_between_tasks if iou_thres_between_tasks is None else iou_thres_between_tasks
-        all_out = self.model(tensor.to(self.device))
+        all_out = self.model(tensor.to(self.device), zero_copy=True)  # consumed by NMS right away
         return self.postprocess({t: o[0] for t, o in all_out.items()}, tuple(tensor.shape[2:]), original_shape, max_det, agnostic_nms,
                                 conf_thres, iou_thres, iou_bt)
 

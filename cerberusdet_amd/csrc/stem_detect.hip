@@ -182,6 +182,25 @@ extern "C" int cdet_stem_conv_wgrad(const void* img, int32_t img_dtype, const vo
     return 0;
 }
 
+__global__ void fold_padded_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int Ip, int I, int taps, int accumulate) {
+    const int n = O * I * taps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int o = i / (I * taps), r = i - o * (I * taps);
+        const float v = src[(int64_t)o * Ip * taps + r];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+
+extern "C" int cdet_fold_padded_wgrad(const float* dw_pad, float* dw, int32_t O, int32_t I_pad, int32_t I_real, int32_t taps, int32_t accumulate,
+                                      void* stream) {
+    CDET_CHECK_ARG(dw_pad && dw && O > 0 && I_real > 0 && I_real <= I_pad && taps > 0, "cdet_fold_padded_wgrad: bad arguments");
+    const int n = O * I_real * taps;
+    hipLaunchKernelGGL(fold_padded_wgrad_kernel, dim3(div_up(n, 256) < 64 ? div_up(n, 256) : 64), dim3(256), 0, (hipStream_t)stream, dw_pad, dw, O, I_pad,
+                       I_real, taps, accumulate);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int cdet_detect_decode(const void* f0, const void* f1, const void* f2, const int32_t* hw6, const float* strides3, int32_t N, int32_t nc,
                                   int32_t f_ld, int32_t dtype, void* y, int32_t out_dtype, void* stream) {
     CDET_CHECK_ARG(f0 && f1 && f2 && hw6 && strides3 && y, "cdet_detect_decode: null pointer");

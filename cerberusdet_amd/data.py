@@ -1,0 +1,161 @@
+"""Plain data path for `train.py --data <yaml>`: YOLO-txt labels -> the reference's batch dicts (data/datasets.py:440-459).
+
+What the reference does per sample without augmentation (data/datasets.py:361-438 with augment=False / rect=False): load the image,
+letterbox it to a square of `imgsz` (data/augmentations.py:59-89, auto=False), move the normalised xywh labels into the letterboxed
+frame (xywhn2xyxy with ratio / pad, then xyxy2xywhn with clip, utils/general.py) and collate
+{"img" uint8 [N,3,H,W] RGB, "cls" [n,1], "prob" [n,1], "bboxes" [n,4] xywh in [0,1], "batch_idx" [n], "im_file", "ori_shape", "ratio_pad"}.
+Here the host only decodes the files (PIL) and parses the labels; resize + border + layout run as ONE HIP kernel per batch
+(csrc/preprocess.hip, the same kernel CerberusPreprocessor uses, uint8 output) and the batch is born on the GPU.
+
+Dataset YAML = the reference's (data/voc_obj365_animals.yaml): `train` / `val`: one image directory (or .txt list) per task,
+`nc`, `names`, `task_ids`. Label files sit next to the images with /images/ replaced by /labels/ (datasets.py:90-103); a row is
+`cls x y w h` or `cls prob x y w h` (datasets.py:654-666).
+
+Not reproduced (SURVEY.md section 8f.4 "later"): mosaic / mixup / affine / HSV / flips, the label cache, BalancedBatchSampler.
+Shards: rank r takes samples r, r + world, ... of the (per-epoch, seeded) permutation, like a DistributedSampler.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from .cerberusdet_preprocessor import letterbox_geometry
+
+IMG_EXT = {".bmp", ".jpg", ".jpeg", ".png", ".tif", ".tiff", ".webp"}
+
+
+def img2label_path(image_path: str) -> str:
+    """reference data/datasets.py:90-103 (txt labels)."""
+    sa, sb = os.sep + "images" + os.sep, os.sep + "labels" + os.sep
+    return sb.join(str(Path(image_path).with_suffix(".txt")).rsplit(sa, 1))
+
+
+def list_images(path: str) -> List[str]:
+    p = Path(path)
+    if p.is_dir():
+        files = [str(f) for f in sorted(p.rglob("*")) if f.suffix.lower() in IMG_EXT]
+    elif p.is_file():  # a text file of image paths (relative ones resolve against its directory)
+        files = [str((p.parent / ln[2:]) if ln.startswith("./") else ln) for ln in p.read_text().strip().splitlines() if ln.strip()]
+    else:
+        raise FileNotFoundError(f"{path} does not exist")
+    if not files:
+        raise FileNotFoundError(f"no images found under {path}")
+    return files
+
+
+def read_labels(label_path: str, nc: int) -> np.ndarray:
+    """-> [n, 6] float32 (cls, prob, x, y, w, h), duplicates removed; missing file = background image (datasets.py:654-680)."""
+    if not os.path.isfile(label_path):
+        return np.zeros((0, 6), np.float32)
+    rows = [ln.split() for ln in Path(label_path).read_text().strip().splitlines() if ln.strip()]
+    if not rows:
+        return np.zeros((0, 6), np.float32)
+    rows = [[r[0], "1.0"] + r[1:] if len(r) == 5 else r for r in rows]
+    lb = np.array(rows, np.float32)
+    assert lb.shape[1] == 6, f"{label_path}: labels require 5 or 6 columns each"
+    assert (lb[:, [0, 2, 3, 4, 5]] >= 0).all(), f"{label_path}: negative label values"
+    assert (lb[:, 2:] <= 1).all(), f"{label_path}: non-normalized or out of bounds coordinates"
+    assert lb[:, 0].max() < nc, f"{label_path}: class {int(lb[:, 0].max())} exceeds nc = {nc}"
+    _, keep = np.unique(lb, axis=0, return_index=True)
+    return lb[np.sort(keep)]
+
+
+def letterbox_labels(lb_xywhn: np.ndarray, shape_hw, imgsz: int):
+    """Normalised xywh of the original image -> normalised xywh of its letterboxed `imgsz` x `imgsz` frame, plus the reference's
+    `shapes` entry ((h0, w0), ((h / h0, w / w0), (dw, dh))) that val uses to map boxes back (datasets.py:395-407, 428)."""
+    h0, w0 = shape_hw
+    r = imgsz / max(h0, w0)  # load_image (datasets.py:546-560): long side -> imgsz with truncated sizes, then letterbox(auto=False)
+    h, w = (int(h0 * r), int(w0 * r)) if r != 1 else (h0, w0)
+    new_w, new_h, top, _, left, _ = letterbox_geometry((h, w), (imgsz, imgsz), False, 32)
+    dw, dh = (imgsz - new_w) / 2, (imgsz - new_h) / 2
+    out = lb_xywhn.copy()
+    if len(out):
+        x, y, bw, bh = (lb_xywhn[:, i] for i in range(4))
+        x1, y1 = new_w * (x - bw / 2) + dw, new_h * (y - bh / 2) + dh
+        x2, y2 = new_w * (x + bw / 2) + dw, new_h * (y + bh / 2) + dh
+        eps = 1e-3
+        x1, x2 = np.clip(x1, 0, imgsz - eps), np.clip(x2, 0, imgsz - eps)
+        y1, y2 = np.clip(y1, 0, imgsz - eps), np.clip(y2, 0, imgsz - eps)
+        out = np.stack(((x1 + x2) / 2 / imgsz, (y1 + y2) / 2 / imgsz, (x2 - x1) / imgsz, (y2 - y1) / imgsz), 1).astype(np.float32)
+    return out, ((h0, w0), ((h / h0, w / w0), (dw, dh))), (new_w, new_h, top, left)
+
+
+class TaskDataset:
+    """Iterable over one task's batches for one rank; `len()` = batches per epoch. Every `iter()` starts a new epoch."""
+
+    def __init__(self, path: str, imgsz: int, batch_size: int, nc: int, device, rank: int = 0, world_size: int = 1, shuffle: bool = True,
+                 seed: int = 0):
+        self.files = list_images(path)
+        self.labels = [read_labels(img2label_path(f), nc) for f in self.files]
+        self.imgsz, self.bs, self.nc, self.device = imgsz, batch_size, nc, torch.device(device)
+        self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
+        per_rank = (len(self.files) + world_size - 1) // world_size
+        self.nb = max((per_rank + batch_size - 1) // batch_size, 1)
+
+    def __len__(self):
+        return self.nb
+
+    def _order(self):
+        n = len(self.files)
+        idx = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        pad = (-n) % self.world  # pad by wrapping so that every rank sees the same number of samples
+        idx = np.concatenate((idx, idx[:pad])) if pad else idx
+        return idx[self.rank::self.world]
+
+    def __iter__(self):
+        from PIL import Image
+
+        from . import _lib as L
+
+        lib = L.load()
+        order = self._order()
+        self.epoch += 1
+        S = self.imgsz
+        for b0 in range(0, len(order), self.bs):
+            ids = order[b0:b0 + self.bs]
+            items = (L.LetterboxItem * len(ids))()
+            keep, cls, prob, box, bidx, shapes, files = [], [], [], [], [], [], []
+            for j, i in enumerate(ids):
+                im = np.asarray(Image.open(self.files[i]).convert("RGB"))[:, :, ::-1]  # the kernel takes cv2's BGR order
+                lb = self.labels[i]
+                xywh, shp, (new_w, new_h, top, left) = letterbox_labels(lb[:, 2:], im.shape[:2], S)
+                t = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=True)
+                keep.append(t)
+                it = items[j]
+                it.img, it.h, it.w, it.pitch = t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3
+                it.new_w, it.new_h, it.top, it.left = new_w, new_h, top, left
+                cls.append(lb[:, 0:1]), prob.append(lb[:, 1:2]), box.append(xywh), bidx.append(np.full(len(lb), j, np.float32))
+                shapes.append(shp), files.append(self.files[i])
+            tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+            img = torch.empty((len(ids), 3, S, S), dtype=torch.uint8, device=self.device)
+            st = torch.cuda.current_stream(self.device)
+            L.check(lib.cdet_letterbox_batch(tab.data_ptr(), len(ids), img.data_ptr(), S, S, L.U8, 114, st.cuda_stream), "cdet_letterbox_batch")
+            for t in keep + [tab]:
+                t.record_stream(st)
+            cat = lambda xs, w: torch.from_numpy(np.concatenate(xs, 0).reshape(-1, w).astype(np.float32)).to(self.device)  # noqa: E731
+            yield {"img": img, "cls": cat(cls, 1), "prob": cat(prob, 1), "bboxes": cat(box, 4), "batch_idx": cat(bidx, 1).reshape(-1),
+                   "im_file": tuple(files), "ori_shape": tuple(s[0] for s in shapes), "ratio_pad": tuple(s[1] for s in shapes)}
+
+
+def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: Sequence[int], imgsz: int, device="cuda", rank: int = 0,
+                       world_size: int = 1):
+    """-> (train {task: TaskDataset}, val {task: TaskDataset} (rank 0 validates, unsharded), names {task: [str]})."""
+    import yaml
+
+    d = yaml.safe_load(open(path))
+    ids = list(d.get("task_ids", tasks))
+    assert list(tasks) == ids, f"--tasks {list(tasks)} does not match the dataset's task_ids {ids}"
+    assert [int(v) for v in d["nc"]] == [int(v) for v in nc], f"--nc {list(nc)} does not match the dataset's nc {d['nc']}"
+    root = Path(path).resolve().parent
+
+    def res(p):
+        return str(p if os.path.isabs(p) else root / p)
+
+    train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i) for i, t in enumerate(ids)}
+    val = {t: TaskDataset(res(d["val"][i]), imgsz, bs[i], nc[i], device, 0, 1, shuffle=False) for i, t in enumerate(ids)} if d.get("val") else None
+    names = {t: [str(n) for n in d["names"][i]] for i, t in enumerate(ids)} if d.get("names") else None
+    return train, val, names

@@ -477,7 +477,8 @@ class CerberusDet(nn.Module):
         training = self.training if training is None else training
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
         frozen = ()
-        if training:  # blocks whose parameters are all frozen (freeze_shared_layers) compile in eval form without backward
+        if training:  # blocks whose parameters are all frozen (freeze_shared_layers): train-form forward with batch statistics, running
+            # statistics untouched, no backward (engine.Plan.frozen)
             frozen = tuple(i for i, b in enumerate(self.blocks)
                            if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters()))
         key = (tuple(tasks), tuple(shape), img_dtype, training, self.compute_dtype, bool(getattr(self, "sync_bn", False)), frozen)
@@ -491,12 +492,14 @@ class CerberusDet(nn.Module):
             self._plans[key] = plan
         return plan
 
-    def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False):
+    def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False, zero_copy=False):
         """Same contract as the reference (cerberus.py:804-882): a `str` task -> that head's output, otherwise a dict.
         train mode -> list of 3 raw maps [N, 64+nc, h, w]; eval mode -> (y [N, 4+nc, A], maps).
-        Unlike the reference, which allocates fresh outputs per call, the returned tensors are VIEWS of the compiled plan's buffers:
-        the next forward of the same (tasks, shape, dtype, mode) overwrites them. Consume them (NMS, loss) or `.clone()` them before
-        calling the model again with the same configuration; CerberusDetInference and the trainer do the former."""
+        Like the reference, every call returns FRESH tensors (one device copy of the head maps / `y`, ~0.1 ms at batch 32 @640).
+        `zero_copy=True` returns VIEWS of the compiled plan's buffers instead: the next forward of the same (tasks, shape, dtype, mode)
+        overwrites them, so consume them (NMS, loss) before calling the model again -- CerberusDetInference, val.run and the trainer
+        do. Either way a train-mode forward keeps ONE set of saved activations per configuration: call backward() before the next
+        forward of the same configuration (autograd_bridge refuses a stale backward)."""
         if task_ids is None and hasattr(self, "cur_task"):
             task_ids = self.cur_task
         elif task_ids is None:
@@ -504,17 +507,20 @@ class CerberusDet(nn.Module):
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
         x = input_tensor.contiguous()
         plan = self.get_plan(tasks, x.shape, x.dtype)
+        own = (lambda t: t) if zero_copy else (lambda t: t.clone())
         if self.training and torch.is_grad_enabled():
             from ..autograd_bridge import run_with_autograd
 
             outs = run_with_autograd(plan, x)
+            if not zero_copy:
+                outs = {t: [own(f) for f in maps] for t, maps in outs.items()}
         else:
             plan.run_forward(x)
             outs = {}
             for t in tasks:
                 nc = self.get_head(t).nc
-                maps = [f[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
-                outs[t] = maps if self.training else (plan.y[t], maps)
+                maps = [own(f[..., :64 + nc].permute(0, 3, 1, 2)) for f in plan.feats[t]]
+                outs[t] = maps if self.training else (own(plan.y[t]), maps)
         return outs[task_ids] if isinstance(task_ids, str) else outs
 
     # ------------------------------------------------------------------------------------------------------ freezing

@@ -2,11 +2,17 @@
 one process per GPU (`python -m torch.distributed.run --nproc-per-node N cerberusdet_amd/train.py ...`), env LOCAL_RANK /
 RANK / WORLD_SIZE, `train(hyp, opt, device, train_dataset=None, val_dataset=None)`, `run(**kwargs)`.
 
-Scope: the hot path -- model, loss, backward, gradient all-reduce, optimizer -- is native here. The
-reference's CPU data pipeline (cv2 mosaic/augmentations, label caches), validation harness, plotting and MLflow/TensorBoard
-logging are out of scope; `train_dataset` therefore is any iterable per task that yields the reference's batch dicts
-({"img": uint8 [N,3,H,W], "cls", "bboxes" (xywh in [0,1]), "batch_idx"}), and `--data synthetic` provides the benchmark's
-generator.
+Scope: the hot path -- model, loss, backward, gradient all-reduce, optimizer, and the validation arithmetic
+(val.run: NMS at the reference's val settings, device matcher, AP) -- is native here. The reference's cv2 mosaic / augmentation
+pipeline, plotting and MLflow / TensorBoard logging are out of scope; `train_dataset` / `val_dataset` are therefore per-task
+iterables that yield the reference's batch dicts ({"img": uint8 [N,3,H,W], "cls", "bboxes" (xywh in [0,1]), "batch_idx"}):
+`--data synthetic` provides the benchmark's generator, `--data <yaml>` the plain YOLO-txt loader of cerberusdet_amd.data
+(letterbox only, no augmentation).
+
+Per epoch (reference trainers/base_trainer.py:114-194, utils/models_manager.py:262-294): rank 0 validates every task on the EMA
+weights (unless --noval, always on the final epoch), fitness = 0.1 * mAP@.5 + 0.9 * mAP@.5:.95 (utils/metrics.py:28-34) per task and
+averaged over the tasks; `weights/{task}_best.pt` on a new per-task best, `weights/best.pt` on a new mean best, `weights/last.pt` always;
+--patience stops early like the reference's EarlyStopping (utils/torch_utils.py:257-279).
 """
 from __future__ import annotations
 
@@ -44,7 +50,7 @@ def parse_opt(known=False):
     p.add_argument("--imgsz", "--img", "--img-size", type=int, default=640)
     p.add_argument("--resume", nargs="?", const=True, default=False)
     p.add_argument("--nosave", action="store_true")
-    p.add_argument("--noval", action="store_true", help="accepted for CLI compatibility: this entry point never runs validation (use cerberusdet_amd.val)")
+    p.add_argument("--noval", action="store_true", help="only validate the final epoch")
     p.add_argument("--device", default="")
     p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm: per-layer statistics all-reduced over the ranks")
     p.add_argument("--workers", type=int, default=8, help="accepted for CLI compatibility: batches come from the caller's iterables / the synthetic generator")
@@ -52,12 +58,13 @@ def parse_opt(known=False):
     p.add_argument("--name", default="exp")
     p.add_argument("--exist-ok", action="store_true")
     p.add_argument("--linear-lr", action="store_true")
-    p.add_argument("--patience", type=int, default=30, help="accepted for CLI compatibility: early stopping needs the validation loop, which this entry point does not run")
+    p.add_argument("--patience", type=int, default=30, help="EarlyStopping patience (epochs without improvement of the mean fitness); 0 disables it")
     p.add_argument("--local_rank", "--local-rank", type=int, default=-1)
     p.add_argument("--single-cls", action="store_true")
     p.add_argument("--freeze-shared-till-epoch", type=int, default=0)
     p.add_argument("--skip-batches", action="store_true")
     p.add_argument("--iters-per-epoch", type=int, default=20, help="synthetic data: iterations per epoch")
+    p.add_argument("--val-iters", type=int, default=2, help="synthetic data: validation batches per task and epoch")
     p.add_argument("--tasks", type=str, default="voc,objects365_animals")
     p.add_argument("--nc", type=str, default="20,19")
     return p.parse_known_args()[0] if known else p.parse_args()
@@ -79,7 +86,40 @@ def fill_tasks_parameters(model, hyp, imgsz, names=None):
     return hyp
 
 
+def fitness(results) -> float:
+    """Weighted combination of [P, R, mAP@.5, mAP@.5:.95] (reference utils/metrics.py:28-34)."""
+    return 0.0 * results[0] + 0.0 * results[1] + 0.1 * results[2] + 0.9 * results[3]
+
+
+class EarlyStopping:
+    """Reference utils/torch_utils.py:257-279."""
+
+    def __init__(self, patience=30):
+        self.best_fitness, self.best_epoch = 0.0, 0
+        self.patience = patience or float("inf")
+        self.possible_stop = False
+
+    def __call__(self, epoch, fit):
+        if fit >= self.best_fitness:  # >= to allow for the early zero-fitness stage of training
+            self.best_epoch, self.best_fitness = epoch, fit
+        delta = epoch - self.best_epoch
+        self.possible_stop = delta >= (self.patience - 1)
+        return delta >= self.patience
+
+
+def reduce_precision_like_reference(model):
+    """`model.half().float()` of the reference (train.py:160, rank 0, not when resuming): every floating-point parameter and buffer is
+    rounded to fp16 once before the ranks are synchronised; the EMA copy made earlier keeps the un-rounded values. (CerberusDet.half()
+    here switches the compute dtype instead, so the rounding is spelled out.)"""
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.is_floating_point():
+                t.copy_(t.half().float())
+    model.mark_weights_changed()
+
+
 def train(hyp, opt, device, train_dataset=None, val_dataset=None):
+    from cerberusdet_amd import val as validate
     from cerberusdet_amd.models import CerberusDet
     from cerberusdet_amd.trainers import Averaging
 
@@ -96,26 +136,38 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         ck = torch.load(opt.weights, map_location="cpu", weights_only=False)
         model.load_state_dict(ck["state_dict"], strict=False)
     model = model.to(device).train()
-    hyp = fill_tasks_parameters(model, hyp, opt.imgsz)
+    names = None
+    if train_dataset is None:
+        if opt.data == "synthetic":
+            import bench
+
+            def gen(ti, t, n=None, seed0=0):
+                i = 0
+                while n is None or i < n:
+                    yield bench.synth_batch(max(RANK, 0), ti, seed0 + i % 4, bs[ti], nc[ti], opt.imgsz, device)
+                    i += 1
+            train_dataset = {t: gen(ti, t) for ti, t in enumerate(tasks)}
+            if val_dataset is None:
+                val_dataset = {t: (lambda ti=ti, t=t: gen(ti, t, opt.val_iters, 100)) for ti, t in enumerate(tasks)}
+            nb = opt.iters_per_epoch
+        else:
+            from cerberusdet_amd import data as cdata
+
+            train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE)
+            val_dataset = val_dataset if val_dataset is not None else val_dataset_y
+            nb = max(len(d) for d in train_dataset.values())
+    else:
+        nb = max(len(d) if hasattr(d, "__len__") else opt.iters_per_epoch for d in train_dataset.values())
+    hyp = fill_tasks_parameters(model, hyp, opt.imgsz, names)
+    # the EMA inside the trainer copies the model BEFORE the fp16 rounding below, like the reference (utils/models_manager.py:231)
+    trainer = Averaging(device, model, hyp, tasks, epochs=max(opt.epochs, 2), nb=nb, linear_lr=opt.linear_lr, rank=RANK, world_size=WORLD_SIZE,
+                        sync_bn=opt.sync_bn and WORLD_SIZE > 1)
+    if RANK in (-1, 0) and not opt.resume:
+        reduce_precision_like_reference(model)
     if WORLD_SIZE > 1:
         for t in list(model.state_dict().values()):  # what DDP's constructor does in the reference (train.py:182-184)
             dist.broadcast(t, src=0)
-    if train_dataset is None:
-        if opt.data != "synthetic":
-            raise NotImplementedError("cerberusdet_amd.train: pass per-task iterables of batch dicts as train_dataset, or --data synthetic")
-        import bench
-
-        def gen(ti, t):
-            i = 0
-            while True:
-                yield bench.synth_batch(max(RANK, 0), ti, i % 4, bs[ti], nc[ti], opt.imgsz, device)
-                i += 1
-        train_dataset = {t: gen(ti, t) for ti, t in enumerate(tasks)}
-        nb = opt.iters_per_epoch
-    else:
-        nb = max(len(d) if hasattr(d, "__len__") else opt.iters_per_epoch for d in train_dataset.values())
-    trainer = Averaging(device, model, hyp, tasks, epochs=max(opt.epochs, 2), nb=nb, linear_lr=opt.linear_lr, rank=RANK, world_size=WORLD_SIZE,
-                        sync_bn=opt.sync_bn and WORLD_SIZE > 1)
+        model.mark_weights_changed()
     iters = {t: iter(d) for t, d in train_dataset.items()}
     # --skip-batches (reference trainers/averaging.py:50-54,144-146): a task with a shorter dataset is visited every
     # max_len // len iterations only; the optimizer step then divides by the number of tasks that really ran
@@ -126,9 +178,12 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         if RANK in (-1, 0):
             print(f"viewing tasks iteration frequency: {iters_per_task}")
     out_dir = Path(opt.project) / opt.name
+    wdir = out_dir / "weights"
     start_epoch = 0
+    best_fitness, best_fitness_per_task = 0.0, {t: 0.0 for t in tasks}
+    stopper = EarlyStopping(opt.patience)
     if opt.resume:  # reference train.py:359-372 + utils/models_manager.py:296-308: weights, optimizer, EMA, epoch
-        ck_path = Path(opt.resume) if isinstance(opt.resume, str) else out_dir / "last.pt"
+        ck_path = Path(opt.resume) if isinstance(opt.resume, str) else wdir / "last.pt"
         ck = torch.load(str(ck_path), map_location="cpu", weights_only=False)
         if "trainer" not in ck:
             raise ValueError(f"{ck_path} holds weights only: it cannot resume a run (use --weights)")
@@ -136,9 +191,13 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         model.mark_weights_changed()
         trainer.load_state_dict(ck["trainer"])
         start_epoch = trainer.epoch + 1
+        best_fitness = float(ck.get("best_fitness", 0.0))
+        best_fitness_per_task.update(ck.get("best_fitness_per_task", {}))
+        stopper.best_fitness, stopper.best_epoch = best_fitness, int(ck.get("best_epoch", trainer.epoch))
         if RANK in (-1, 0):
             print(f"resuming {ck_path} at epoch {start_epoch} (iteration {trainer.steps})")
     results, items = {}, {}
+    val_results = {}
     for epoch in range(start_epoch, opt.epochs):
         trainer.epoch = epoch
         if epoch < opt.freeze_shared_till_epoch:  # reference trainers/averaging.py:100-103
@@ -164,23 +223,66 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         if RANK in (-1, 0):
             ips = nb * sum(bs) * WORLD_SIZE / (time.time() - t0)
             print(f"epoch {epoch}: " + "  ".join(f"{t}: box {r[0]:.4f} cls {r[1]:.4f} dfl {r[2]:.4f}" for t, r in results.items()) + f"  [{ips:.1f} img/s]")
-        if RANK in (-1, 0) and not opt.nosave:
-            save_training_checkpoint(out_dir / "last.pt", model, trainer)
-    return results, opt.epochs - 1
+        # ---- validation, fitness, checkpoints: rank 0 only, like the reference (train.py:218-226, base_trainer.py:114-194)
+        final_epoch = epoch + 1 == opt.epochs or stopper.possible_stop
+        stop = False
+        if RANK in (-1, 0):
+            fit_per_task = {}
+            if val_dataset is not None and (not opt.noval or final_epoch):
+                eval_model = trainer.ema.ema if trainer.ema else model
+                if trainer.ema:  # ema.update_attr(model, include=[... "nc", "hyp", "names", "stride" ...]) of the reference
+                    for a in ("nc", "hyp", "names", "stride"):
+                        if hasattr(model, a):
+                            setattr(eval_model, a, getattr(model, a))
+                for t in tasks:
+                    vd = val_dataset[t]
+                    r = validate.run(eval_model, t, vd() if callable(vd) else vd, single_cls=opt.single_cls)
+                    val_results[t] = (r["mp"], r["mr"], r["map50"], r["map"])
+                    fit_per_task[t] = fitness(val_results[t])
+                    print(f"epoch {epoch} val {t}: P {r['mp']:.4f} R {r['mr']:.4f} mAP@.5 {r['map50']:.4f} mAP@.5:.95 {r['map']:.4f} ({r['seen']} images)")
+                    if fit_per_task[t] > best_fitness_per_task[t]:
+                        best_fitness_per_task[t] = fit_per_task[t]
+                        if not opt.nosave or final_epoch:  # tracks the task's best model (not meant for resuming, base_trainer.py:158-170)
+                            save_training_checkpoint(wdir / f"{t}_best.pt", model, trainer, epoch, best_fitness, best_fitness_per_task, stopper.best_epoch)
+                last_fitness = sum(fit_per_task.values()) / len(fit_per_task)
+                is_best = last_fitness > best_fitness
+                best_fitness = max(best_fitness, last_fitness)
+                stop = stopper(epoch, last_fitness)
+            else:
+                is_best = False
+            if not opt.nosave or final_epoch:
+                save_training_checkpoint(wdir / "last.pt", model, trainer, epoch, best_fitness, best_fitness_per_task, stopper.best_epoch)
+                if is_best:
+                    save_training_checkpoint(wdir / "best.pt", model, trainer, epoch, best_fitness, best_fitness_per_task, stopper.best_epoch)
+        if WORLD_SIZE > 1:  # every rank leaves the loop together (reference train.py:251-257 broadcasts the stop flag)
+            flag = torch.tensor([int(stop)], device=device)
+            dist.broadcast(flag, src=0)
+            stop = bool(flag.item())
+        if stop:
+            if RANK in (-1, 0):
+                print(f"Stopping training early: no improvement in the last {opt.patience} epochs (best epoch {stopper.best_epoch}, weights/best.pt)")
+            break
+    if val_results:
+        results = {t: val_results.get(t, ()) + tuple(results.get(t, ())) for t in tasks}
+    return results, epoch if opt.epochs > start_epoch else opt.epochs - 1
 
 
-def save_training_checkpoint(path, model, trainer):
-    """last.pt: the inference checkpoint of cerberusdet_inference.save_checkpoint (EMA weights when there is an EMA, like the
-    reference's models_manager.py:262-290) plus what --resume needs: the raw model weights and the trainer state."""
-    from cerberusdet_amd.cerberusdet_inference import save_checkpoint
+def save_training_checkpoint(path, model, trainer, epoch=-1, best_fitness=0.0, best_fitness_per_task=None, best_epoch=0):
+    """The inference checkpoint of cerberusdet_inference.save_checkpoint (EMA weights when there is an EMA, like the reference's
+    models_manager.py:262-290) plus what --resume needs: the raw model weights, the trainer state, epoch and best fitness. Built once
+    and written through a temporary file + os.replace, so an interrupted save never leaves a truncated checkpoint behind."""
+    from cerberusdet_amd.cerberusdet_inference import checkpoint_dict
 
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
-    save_checkpoint(path, trainer.ema.ema if trainer.ema else model, getattr(model, "names", None))
-    ck = torch.load(str(path), map_location="cpu", weights_only=False)
+    ck = checkpoint_dict(trainer.ema.ema if trainer.ema else model, getattr(model, "names", None))
+    ck["state_dict"] = {k: v.detach().cpu() for k, v in ck["state_dict"].items()}
     ck["model_state_dict"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ck["trainer"] = trainer.state_dict()
-    torch.save(ck, str(path))
+    ck.update(epoch=epoch, best_fitness=float(best_fitness), best_fitness_per_task=dict(best_fitness_per_task or {}), best_epoch=int(best_epoch))
+    tmp = path.with_suffix(path.suffix + ".tmp")
+    torch.save(ck, str(tmp))
+    os.replace(str(tmp), str(path))
 
 
 def main(opt):

@@ -261,7 +261,8 @@ class Averaging:
     def set_shared_frozen(self, frozen: bool):
         """--freeze-shared-till-epoch (reference trainers/averaging.py:100-103, models/cerberus.py:885-925): the blocks that serve
         every task stop training -- their parameters take part in neither the clipping norm nor the update (a frozen slot is an
-        EMA-only slot), their BatchNorms run from the running statistics, and the engine compiles them without a backward."""
+        EMA-only slot); their BatchNorms keep normalising with BATCH statistics (train-form forward, the reference leaves model.train()
+        on, trainers/averaging.py:106) while their running statistics stay untouched, and the engine compiles them without a backward."""
         from ..models import CerberusDet
 
         (CerberusDet.freeze_shared_layers if frozen else CerberusDet.unfreeze_shared_layers)(self.model)
@@ -317,6 +318,12 @@ class Averaging:
         lrs, mom = self.lrs(ni, self.epoch)
         active = [t for t in self.task_ids if t in batches]
         out = {}
+        if n_max is None and active:
+            # the reference sizes the padded targets per task pass (`counts.max()`, utils/loss.py:117 -- a host sync inside every pass);
+            # here ONE sync before the task streams fork sizes them for all tasks (padding rows are masked: results do not depend on it)
+            counts = [torch.bincount(batches[t]["batch_idx"].reshape(-1).long(), minlength=batches[t]["img"].shape[0]).max()
+                      for t in active if batches[t]["batch_idx"].numel()]
+            n_max = max(int(torch.stack(counts).max()), 1) if counts else 1
         if self.task_streams and len(active) > 1:
             self._run_tasks_on_streams(active, batches, n_max, out)
         else:

@@ -44,7 +44,7 @@ def run(model, task: str, batches: Iterable[dict], conf_thres: float = 0.001, io
         if img.dtype != torch.uint8:
             img = img.half() if half else img.float()
         N, _, H, W = img.shape
-        y = model(img, task)
+        y = model(img, task, zero_copy=True)  # consumed by NMS right away
         y = y[0] if isinstance(y, (tuple, list)) else y
         rows, cnt = ops.nms_batched(y.contiguous(), conf_thres, iou_thres, agnostic=single_cls, multi_label=True, max_det=max_det)
         bi = batch["batch_idx"].to(device).long()

@@ -176,6 +176,11 @@ int cdet_image_to_nhwc8(const void* img_nchw, int32_t img_dtype, void* out_nhwc8
 /* d(stem weight) from dy (NHWC, dtype) and the image; accumulates into fp32 OIHW [Cout,3,3,3]. */
 int cdet_stem_conv_wgrad(const void* img_nchw, int32_t img_dtype, const void* dy, int32_t dtype, float* dw_oihw,
                          int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t accumulate, void* stream);
+/* Weight gradient of the stem computed on the channel-padded image copy (cdet_image_to_nhwc8 + cdet_conv2d_wgrad): fold the
+ * first I_real input channels of dw_pad [O, I_pad, kh, kw] into dw [O, I_real, kh, kw] (+= when accumulate). Completes
+ * `loss.backward()` for models/common.py:57's first Conv without leaving the launch list. */
+int cdet_fold_padded_wgrad(const float* dw_pad, float* dw, int32_t O, int32_t I_pad, int32_t I_real, int32_t taps, int32_t accumulate,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Inference pre-processing (cerberusdet_preprocessor.py:42-74, data/augmentations.py:59-89): letterbox of a list of

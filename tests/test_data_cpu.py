@@ -1,0 +1,40 @@
+"""Host side of the --data path (cerberusdet_amd/data.py): file discovery, label parsing and the label geometry of the letterboxed frame.
+Expected values were produced by the reference's own xywhn2xyxy / xyxy2xywhn (utils/general.py) for load_image + letterbox(auto=False)
+(data/datasets.py:395-407) in the build container; they are constants here because the reference does not travel."""
+import numpy as np
+import pytest
+
+from cerberusdet_amd.data import img2label_path, letterbox_labels, list_images, read_labels
+
+
+def test_label_geometry_matches_reference_known_answers():
+    lb = np.array([[0.02, 0.5, 0.1, 0.2], [0.5, 0.5, 0.4, 0.3], [0.9, 0.1, 0.3, 0.3]], np.float32)
+    got, shp, geo = letterbox_labels(lb, (375, 500), 640)
+    assert geo == (640, 480, 80, 0) and shp == ((375, 500), ((480 / 375, 640 / 500), (0.0, 80.0)))
+    want = np.array([[0.035, 0.5, 0.07, 0.15], [0.5, 0.5, 0.4, 0.225], [0.87499925, 0.2, 0.2499985, 0.225]], np.float32)
+    assert np.abs(got - want).max() < 1e-6
+    # narrow image: the reference truncates the resized size (int(97 * 256 / 333) = 74) before letterboxing
+    got, shp, geo = letterbox_labels(lb[1:2], (333, 97), 256)
+    assert geo == (74, 256, 0, 91) and shp[1][1] == (91.0, 0.0)
+    assert np.abs(got - np.array([[0.5, 0.5, 0.4 * 74 / 256, 0.3]], np.float32)).max() < 1e-6
+    empty, _, _ = letterbox_labels(np.zeros((0, 4), np.float32), (480, 640), 128)
+    assert empty.shape == (0, 4)
+
+
+def test_discovery_and_label_parsing(tmp_path):
+    (tmp_path / "images" / "a").mkdir(parents=True)
+    (tmp_path / "labels" / "a").mkdir(parents=True)
+    for n in ("1.jpg", "2.png", "notes.txt"):
+        (tmp_path / "images" / "a" / n).write_bytes(b"x")
+    files = list_images(str(tmp_path / "images"))
+    assert [f.rsplit("/", 1)[1] for f in files] == ["1.jpg", "2.png"]
+    lp = img2label_path(files[0])
+    assert lp == str(tmp_path / "labels" / "a" / "1.txt")
+    open(lp, "w").write("3 0.5 0.5 0.2 0.2\n1 0.7 0.25 0.25 0.1 0.1\n3 0.5 0.5 0.2 0.2\n")
+    lb = read_labels(lp, 20)
+    assert lb.shape == (2, 6) and lb[0].tolist() == pytest.approx([3, 1.0, 0.5, 0.5, 0.2, 0.2]) and lb[1][1] == pytest.approx(0.7)
+    assert read_labels(img2label_path(files[1]), 20).shape == (0, 6)  # background image
+    with pytest.raises(AssertionError):
+        read_labels(lp, 3)  # class id beyond nc
+    with pytest.raises(FileNotFoundError):
+        list_images(str(tmp_path / "labels" / "a" / "none"))

@@ -249,3 +249,26 @@ def test_two_ranks_train_step_task_streams_equal_sequential_under_syncbn():
             assert np.array_equal(sd_s[k], sd_p[k]), (rank, k)
     for k in res[0][True][1]:
         assert np.array_equal(res[0][True][1][k], res[1][True][1][k]), k
+
+
+def test_dry_comm_every_virtual_rank_enqueues_the_same_collective_sequence():
+    """bench.py --dry-comm: collectives recorded instead of executed, three virtual ranks with their own shards, 2- and 3-task plans,
+    SyncBatchNorm + gradient reduction + task streams, all-tasks / one-task iterations (--skip-batches): identical (bytes, stream)
+    sequences on every rank -- the precondition for the single RCCL communicator not to deadlock at 8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--dry-comm"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["identical_on_all_ranks"] is True and set(out["plans"]) == {"v8x_2task.yaml", "v8x_3task.yaml"}
+    two = out["plans"]["v8x_2task.yaml"]["steps"]
+    # 97 BatchNorm layers per task path, one all-reduce per layer and direction (forward statistics, backward sums), + one gradient
+    # bucket per block with parameters on the executed path; a single-task iteration runs exactly that task's share
+    assert two[0]["active_tasks"] == ["voc", "objects365_animals"] and two[0]["collectives"] >= 2 * 2 * 97
+    assert two[1]["collectives"] < two[0]["collectives"] and two[1]["collectives"] >= 2 * 97
+    assert two[0]["collectives"] == two[2]["collectives"] and two[0]["bytes"] == two[2]["bytes"]
+    assert out["plans"]["v8x_3task.yaml"]["steps"][0]["collectives"] > two[0]["collectives"]

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Profiling build of the library (-DCDET_PROFILING: workgroup timeline stamps, ablation switches, tuning environment variables) into
+# tools/debug/_build/libcdet_prof.so (git-ignored; select it with CDET_LIB_PATH). The product library is untouched.
+set -e
+cd "$(dirname "$0")/../cerberusdet_amd/csrc"
+OUT=../../tools/debug/_build
+mkdir -p $OUT/obj
+for f in core conv_igemm conv_halo conv_wgrad conv_wgrad_halo elementwise stem_detect stem_mfma nms det_loss optim preprocess; do
+  if [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ] || [ common.h -nt $OUT/obj/$f.o ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -DCDET_PROFILING $EXTRA -c $f.hip -o $OUT/obj/$f.o &
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/obj/*.o -o $OUT/libcdet_prof.so
+echo built $OUT/libcdet_prof.so

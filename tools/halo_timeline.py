@@ -22,8 +22,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--bs", type=int, default=32)
+    ap.add_argument("--custom", type=str, default="", help="H,W,Cin,Cout,k instead of --shape")
+    ap.add_argument("--mode", default="silu", choices=["silu", "raw"], help="eval epilogue (scale/bias/SiLU) or train form (raw output + BN partial sums)")
     a = ap.parse_args()
-    H, W, ci, co, k, _ = SHAPES[a.shape]
+    H, W, ci, co, k, _ = SHAPES[a.shape] if not a.custom else tuple(int(v) for v in a.custom.split(",")) + (1,)
     dev, dtype = "cuda", torch.bfloat16
     lib = L.load()
     g = torch.Generator(device=dev).manual_seed(5)
@@ -33,10 +35,17 @@ def main():
     bias = torch.randn(co, generator=g, device=dev) * 0.1
     src, y = ops.View(x), ops.new_act(a.bs, H, W, co, dtype)
     wt, _ = ops.pack_weight_tiled(w, dtype)
-    run = lambda: ops.conv2d_tiled(src, wt, y, k, scale=scale, bias=bias, act=L.ACT_SILU)  # noqa: E731
+    if a.mode == "silu":
+        run = lambda: ops.conv2d_tiled(src, wt, y, k, scale=scale, bias=bias, act=L.ACT_SILU)  # noqa: E731
+    else:
+        stats = torch.zeros(ops.conv_tiled_stat_blocks(src, y, k) * 2 * co, device=dev)
+        run = lambda: ops.conv2d_tiled(src, wt, y, k, stats=stats)  # noqa: E731
     for _ in range(3):
         run()
-    nblk = ((a.bs * H * W + 255) // 256) * ((co + 159) // 160)
+    hp = 256 * ops.conv_tiled_stat_blocks(src, y, k) // ((a.bs * H * W + 255) // 256) if False else None
+    n_p = ops.conv_tiled_stat_blocks(src, y, k)  # pixel tiles (256-pixel, 16 x 16 patch or 128-pixel half tiles)
+    rb = 96 if co <= 96 else 160
+    nblk = n_p * ((co + rb - 1) // rb)
     buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
     fn = lib.cdet_debug_halo_timeline
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
@@ -51,7 +60,7 @@ def main():
     t = t.astype(np.int64)
     t0 = t[:, 2].min()
     st, lo, ep, en = (t[:, i] - t0 for i in (2, 3, 4, 5))
-    print(f"shape {SHAPES[a.shape]}, {nblk} workgroups on {len(set(cu.tolist()))} distinct CUs; kernel span {en.max()} clocks (s_memtime)")
+    print(f"shape {(H, W, ci, co, k)} mode {a.mode}, {nblk} workgroups on {len(set(cu.tolist()))} distinct CUs; kernel span {en.max()} clocks (s_memtime)")
     print(f"per workgroup (clocks): prologue {np.median(lo - st):.0f}  K loop {np.median(ep - lo):.0f}  epilogue {np.median(en - ep):.0f}   (min/max loop {(ep - lo).min()}/{(ep - lo).max()})")
     lp = (ep - lo).astype(np.float64)
     print(f"inside the K loop (wave 0): counted vmcnt/lgkmcnt wait {np.median(t[:, 6] / lp):.3f} of the loop, barrier behind it {np.median(t[:, 7] / lp):.3f}"
