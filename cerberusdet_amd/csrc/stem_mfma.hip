@@ -2,13 +2,16 @@
 // reference's NCHW image directly (uint8 scaled by 1/255: trainers/base_trainer.py:61-63, or float / half).
 //
 // K = 27 is too short for the implicit-GEMM kernels (padding the image to 8 channels makes K = 72 -> 128: 0.5 ms for 0.44 GFLOP/img,
-// 5x off the HBM roofline of the 524 MB bf16 output at batch 32). Here one workgroup owns an 8 x 32 patch of output pixels:
-//   * its 17 x 65 x 3 input patch is converted once (/255, 16-bit) into LDS (6.7 KB);
-//   * each wave gathers the im2col fragment of its 2 x 32 pixels from LDS (16 ds_read_u16 per fragment half, K padded 27 -> 32) and
-//     multiplies it with the 96 x 32 weight operand held in registers: 12 x v_mfma_f32_32x32x16 per wave;
+// 5x off the HBM roofline of the 524 MB bf16 output at batch 32). Here one persistent workgroup walks 8 x 32 patches of output pixels:
+//   * the 17 x 65 x 3 input patch of the NEXT patch is fetched with aligned dword loads into registers (4 uint8 / 2 halfs / 1 float
+//     per load) while the current patch computes, then converted (/255, 16-bit) into the other half of a double-buffered LDS tile;
+//   * the GEMM's K axis is laid out as k = 4 * (c * 3 + kh) + kw with a fourth, zero-weight column, K = 36 -> 48: the eight k values a
+//     lane feeds to one v_mfma_f32_32x32x16 are then two runs of four CONSECUTIVE image columns, i.e. two ds_read2_b32 straight from
+//     the tile -- no per-element gather, no packing arithmetic (the round-2 kernel spent 16 ds_read_u16 + 8 shifts per fragment half);
+//   * 18 MFMAs per wave and patch against the 96 x 48 weight operand held in registers;
 //   * epilogue as in conv_halo.hip: BN partial sums from the fp32 accumulators (train), scale / bias / SiLU (eval), permlane32 swap to
 //     8 couts per lane, LDS-staged whole-row stores.
-// Bound: HBM (output write); the arithmetic is 1 % of the MFMA roof.
+// Bound: HBM (output write); the arithmetic is 1.5 % of the MFMA roof.
 #include "common.h"
 
 namespace cdet {
@@ -30,8 +33,11 @@ struct StemArgs {
 };
 
 constexpr int ST_PH = 8, ST_PW = 32;              // output patch
-constexpr int ST_IH = 2 * ST_PH + 1, ST_IW = 2 * ST_PW + 1, ST_IWP = ST_IW + 1;  // input patch 17 x 65 (+1 pad)
-constexpr int ST_HC = 96, ST_NF = 3;
+constexpr int ST_IH = 2 * ST_PH + 1;              // input rows per channel (17); columns: entries c' = 0 .. 65 <-> image column 64*tx - 1 + c'
+constexpr int ST_ROWS = 3 * ST_IH;                // LDS tile rows (channel-major)
+constexpr int ST_PITCH = 136;                     // bytes per tile row: 66 entries of 2 bytes, padded (row -> row shifts 2 banks)
+constexpr int ST_TILE = (ST_ROWS * ST_PITCH + 15) / 16 * 16;
+constexpr int ST_HC = 96, ST_NF = 3, ST_KS = 3;   // couts per block, 32-cout fragments, k16 steps (K = 48)
 constexpr int ST_RS = ST_HC * 2 + 16;
 
 template <int DT>
@@ -57,9 +63,13 @@ __device__ __forceinline__ float shalf_sum32(float v) {
     return v;
 }
 
-template <int DT>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
-    __shared__ uint16_t tile[3 * ST_IH * ST_IWP];
+// A: image elements per aligned dword load (4 = uint8, 2 = half / bfloat16, 1 = float)
+template <int DT, int A>
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs a) {
+    constexpr int ND = (A + 64) / A;                    // dwords per tile row: columns 64*tx - A .. 64*tx + 63
+    constexpr int NITEM = ST_ROWS * ND;
+    constexpr int NPT = (NITEM + 255) / 256;            // prefetch registers per thread: 4 / 7 / 13
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[2 * ST_TILE];
     __shared__ __attribute__((aligned(16))) float red[4 * 2 * ST_HC];
     __shared__ __attribute__((aligned(16))) float sb[2 * ST_HC];
     __shared__ __attribute__((aligned(16))) unsigned char stg[4 * 32 * ST_RS];
@@ -70,58 +80,117 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
         sb[t] = a.scale ? a.scale[c] : 1.f;
         sb[ST_HC + t] = a.bias ? a.bias[c] : 0.f;
     }
-    // ---- weight operand (A): row co = f*32 + l31, k = s*16 + h*8 + j over the OIHW row [27], zero beyond
-    u32x4 af[ST_NF][2];
+    // both tile buffers start as zeros: entries that are never written (c' = 65) must hold finite values (their weights are zero)
+    for (int i = t; i < 2 * ST_TILE / 4; i += 256) reinterpret_cast<uint32_t*>(tiles)[i] = 0u;
+    // ---- weight operand (A): row co = f*32 + l31; k = 16*s + 8*h + j  <->  (c*3 + kh) = k / 4, kw = k % 4 (kw = 3 and rows >= 9: zero)
+    u32x4 af[ST_NF][ST_KS];
 #pragma unroll
     for (int f = 0; f < ST_NF; ++f) {
         const int co = f * 32 + l31;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < ST_KS; ++s) {
             float wv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = s * 16 + h * 8 + j;
-                wv[j] = (co < a.Cout && k < 27) ? a.w[co * 27 + k] : 0.f;
+                const int r = k >> 2, kw = k & 3;
+                wv[j] = (co < a.Cout && r < 9 && kw < 3) ? a.w[co * 27 + r * 3 + kw] : 0.f;
             }
             af[f][s] = u32x4{spack2<DT>(wv[0], wv[1]), spack2<DT>(wv[2], wv[3]), spack2<DT>(wv[4], wv[5]), spack2<DT>(wv[6], wv[7])};
         }
     }
+    // ---- B-fragment addresses (bytes inside a tile buffer): for (g, s) the lane reads 4 entries of tile row R(4s + 2h) and 4 of
+    //      R(4s + 2h + 1), R(r) = (r / 3) * 17 + r % 3 + 2 * oy_l, from entry 2 * ox_l on (rows beyond 8 re-read row 8: zero weights)
+    int boff[2][ST_KS][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int s = 0; s < ST_KS; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                int r = 4 * s + 2 * h + q;
+                r = r > 8 ? 8 : r;
+                boff[g][s][q] = ((r / 3) * ST_IH + r % 3 + 2 * (2 * wave + g)) * ST_PITCH + 4 * l31;
+            }
     uint16_t* const yp = reinterpret_cast<uint16_t*>(a.y);
     unsigned char* const st = stg + wave * (32 * ST_RS);
     constexpr int CH = ST_HC / 8;
-    // persistent over patches: the weight operand and scale / bias are set up once per workgroup
     const int n_patches = a.N * a.tiles_y * a.tiles_x;
-    for (int patch = blockIdx.x; patch < n_patches; patch += gridDim.x) {
+    const int es = A == 4 ? 1 : (A == 2 ? 2 : 4);
+
+    uint32_t pre[NPT];
+    // raw dwords of patch `pt` -> registers (zeros outside the image)
+    auto fetch = [&](int pt) {
+        int b = pt;
+        const int tx = b % a.tiles_x;
+        b /= a.tiles_x;
+        const int ty = b % a.tiles_y;
+        const int n = b / a.tiles_y;
+        const int iy0 = 2 * ty * ST_PH - 1, col00 = 64 * tx - A;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int idx = i * 256 + t;
+            uint32_t v = 0u;
+            if (idx < NITEM) {
+                const int row = idx / ND, d = idx - row * ND;
+                const int c = row / ST_IH, r = row - c * ST_IH;
+                const int iy = iy0 + r, col0 = col00 + d * A;
+                if ((unsigned)iy < (unsigned)a.H && col0 >= 0 && col0 < a.W) {
+                    const int64_t e0 = (((int64_t)n * 3 + c) * a.H + iy) * a.W + col0;
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.img) + e0 * es;
+                    if (col0 + A <= a.W) {
+                        v = *reinterpret_cast<const uint32_t*>(src);
+                    } else {  // W not a multiple of the load width: the row's last, partial dword element by element
+#pragma unroll
+                        for (int e = 0; e < A; ++e)
+                            if (col0 + e < a.W) {
+                                if (A == 4) v |= (uint32_t)src[e] << (8 * e);
+                                else v |= (uint32_t)reinterpret_cast<const uint16_t*>(src)[e] << (16 * e);
+                            }
+                    }
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    // registers -> 16-bit tile entries of buffer `buf` (entry c' = 1 - A + d*A + e)
+    auto stash = [&](int buf) {
+        uint16_t* const tl = reinterpret_cast<uint16_t*>(tiles + buf * ST_TILE);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int idx = i * 256 + t;
+            if (idx < NITEM) {
+                const int row = idx / ND, d = idx - row * ND;
+                const uint32_t v = pre[i];
+#pragma unroll
+                for (int e = 0; e < A; ++e) {
+                    const int cp = 1 - A + d * A + e;
+                    float f;
+                    if (A == 4) f = (float)((v >> (8 * e)) & 0xffu) * (1.0f / 255.0f);
+                    else if (A == 2) f = a.img_dtype == CDET_F16 ? f16_bits_to_f32((uint16_t)(v >> (16 * e))) : bf16_bits_to_f32((uint16_t)(v >> (16 * e)));
+                    else f = __uint_as_float(v);
+                    if (cp >= 0) tl[row * (ST_PITCH / 2) + cp] = Elem<DT>::from_f32(f);
+                }
+            }
+        }
+    };
+
+    int patch = blockIdx.x;
+    if (patch < n_patches) fetch(patch);
+    __syncthreads();  // the zero fill (and sb) before the first tile entries land
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (; patch < n_patches; patch += gridDim.x) {
     int b = patch;
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
     const int ty = b % a.tiles_y;
     const int n = b / a.tiles_y;
     const int oy0 = ty * ST_PH, ox0 = tx * ST_PW;
-    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
-    __syncthreads();  // the previous patch's fragment gathers are done with `tile`, its statistics with `red`
-    // ---- input patch -> LDS (16-bit, uint8 scaled by 1/255); outside the image = the zero padding. 5 threads per (channel, row):
-    //      13 consecutive columns each
-    if (t < 3 * ST_IH * 5) {
-        const int row = t / 5, part = t - row * 5;
-        const int c = row / ST_IH, r = row - c * ST_IH;
-        const int iy = iy0 + r;
-        const bool rok = (unsigned)iy < (unsigned)a.H;
-        const int64_t rbase = (((int64_t)n * 3 + c) * a.H + (rok ? iy : 0)) * a.W;
-#pragma unroll
-        for (int j = 0; j < 13; ++j) {
-            const int col = part * 13 + j;
-            const int ix = ix0 + col;
-            float v = 0.f;
-            if (rok && (unsigned)ix < (unsigned)a.W) {
-                const int64_t i = rbase + ix;
-                v = a.img_dtype == CDET_U8 ? (float)((const uint8_t*)a.img)[i] * (1.0f / 255.0f) : load_elem(a.img, i, a.img_dtype);
-            }
-            tile[row * ST_IWP + col] = Elem<DT>::from_f32(v);
-        }
-    }
-    __syncthreads();
-    // ---- im2col fragments (B) of this wave's 2 x 32 pixels and the 12 MFMAs
+    const bool more = patch + (int)gridDim.x < n_patches;
+    if (more) fetch(patch + gridDim.x);  // in flight under this patch's MFMAs and epilogue
+    // ---- B fragments straight from the tile (two ds_read2_b32 each) and the 18 MFMAs
     sf32x16 acc[ST_NF][2];
 #pragma unroll
     for (int f = 0; f < ST_NF; ++f)
@@ -129,24 +198,14 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
+    const unsigned char* const tb = tiles + cur * ST_TILE;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const int base = (2 * (2 * wave + g)) * ST_IWP + 2 * l31;  // tile row 2*oy_l (+kh), column 2*ox_l (+kw)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint32_t e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // k = s*16 + h*8 + j: both candidates are compile-time, the lane's half picks one
-                const int k0 = s * 16 + j, k1 = s * 16 + 8 + j;
-                const int i0 = k0 < 27 ? ((k0 / 9) * ST_IH + (k0 % 9) / 3) * ST_IWP + k0 % 3 : -1;
-                const int i1 = k1 < 27 ? ((k1 / 9) * ST_IH + (k1 % 9) / 3) * ST_IWP + k1 % 3 : -1;
-                uint32_t v0 = 0u, v1 = 0u;
-                if (i0 >= 0) v0 = tile[base + i0];
-                if (i1 >= 0) v1 = tile[base + i1];
-                e[j] = h ? v1 : v0;
-            }
-            const u32x4 bf = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        for (int s = 0; s < ST_KS; ++s) {
+            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(tb + boff[g][s][0]);
+            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(tb + boff[g][s][1]);
+            const u32x4 bf = u32x4{p0[0], p0[1], p1[0], p1[1]};
 #pragma unroll
             for (int f = 0; f < ST_NF; ++f) smfma32<DT>(af[f][s], bf, acc[f][g]);
         }
@@ -239,6 +298,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+    if (more) stash(cur ^ 1);  // (waits for the prefetched dwords) the other buffer was last read before the previous barrier
+    __syncthreads();
+    cur ^= 1;
     }  // patches
 }
 
@@ -263,9 +325,20 @@ extern "C" int cdet_stem_conv(const void* img, int32_t img_dtype, const float* w
     a.tiles_x = div_up(a.Wo, ST_PW);
     a.tiles_y = div_up(a.Ho, ST_PH);
     const int n_patches = N * a.tiles_x * a.tiles_y;
-    const int blocks = n_patches < 1024 ? n_patches : 1024;  // persistent: 4 workgroups per CU
-    if (out_dtype == CDET_BF16) hipLaunchKernelGGL(stem_mfma_kernel<CDET_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(stem_mfma_kernel<CDET_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const int blocks = n_patches < 512 ? n_patches : 512;  // persistent: 2 workgroups per CU (the register budget of __launch_bounds__(256, 2))
+    const int per = img_dtype == CDET_U8 ? 4 : (img_dtype == CDET_F32 ? 1 : 2);  // image elements per dword load
+    hipStream_t s = (hipStream_t)stream;
+#define CDET_STEM_LAUNCH(DT_, A_) hipLaunchKernelGGL((stem_mfma_kernel<DT_, A_>), dim3(blocks), dim3(256), 0, s, a)
+    if (out_dtype == CDET_BF16) {
+        if (per == 4) CDET_STEM_LAUNCH(CDET_BF16, 4);
+        else if (per == 2) CDET_STEM_LAUNCH(CDET_BF16, 2);
+        else CDET_STEM_LAUNCH(CDET_BF16, 1);
+    } else {
+        if (per == 4) CDET_STEM_LAUNCH(CDET_F16, 4);
+        else if (per == 2) CDET_STEM_LAUNCH(CDET_F16, 2);
+        else CDET_STEM_LAUNCH(CDET_F16, 1);
+    }
+#undef CDET_STEM_LAUNCH
     CDET_LAUNCH_CHECK();
     return 0;
 }
