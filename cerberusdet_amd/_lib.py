@@ -79,6 +79,10 @@ _SIGS = {
     "cdet_conv2d_tiled_ok": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_tiled_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_tiled": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_conv2d_s2_tiled_ok": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_s2_tiled_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_s2_tiled": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_conv2d_s2_tiled_dgrad": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_tiled_weight_elems": (i64, [i32, i32, i32, i32]),
     "cdet_pack_weights_tiled": (i32, [vp, i32, i32, i32, vp]),
     "cdet_pack_weight_tiled": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

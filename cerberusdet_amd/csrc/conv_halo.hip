@@ -21,11 +21,9 @@
 // ds_read_b128 lane group (MI355X_MICROARCH.md LDS table) hit 16 distinct slots of the 256-B bank row.
 #include <stdlib.h>
 
-#include "common.h"
+#include "halo_common.h"
 
 namespace cdet {
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct HaloArgs {
     const uint16_t* x;
@@ -45,73 +43,11 @@ struct HaloArgs {
     int XH;  // halo rows per chunk buffer (multiple of 16)
     int tiles_x, tiles_per_img;  // patch mode: 16x16 pixel patches per image row / per image
     unsigned x_bytes, w_bytes;
+    int wts, wt0;  // weight tile of K step `step` = tile step * wts + wt0 of the packed operand (1, 0: the operand's own order; 9, 4: the centre
+                   // tap of a 9-tap operand -- the (0, 0) parity class of a stride-2 data gradient, conv_vt.hip)
+    int Hd, Wd, cp, cq;  // OMAP: tile pixel (n, y, x) is written to pixel (2y + cp, 2x + cq) of an Hd x Wd destination
 };
 
-constexpr int HP = 256;             // pixels per block (128 in the half-tile form, template parameter NG = 1)
-constexpr int HROW = 64;            // bytes per LDS row (32 channels)
-constexpr int HZERO = 256;          // LDS bytes reserved in front (zero row)
-constexpr int MAXXP = 7;            // X DMA pieces (16 rows each) per wave per chunk: XH <= 448
-constexpr unsigned HSENT = 0xE0000000u;  // byte offset beyond every buffer: the DMA returns zeros
-constexpr int PATCH_W = 16, PATCH_HPW = PATCH_W + 2;  // patch mode: 16 x 16 pixel tiles, halo pitch 18
-
-template <int DT>
-__device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c) {
-    if (DT == CDET_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-
-template <int AUX = 0>
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, AUX);
-}
-#ifndef CDET_HALO_X_AUX
-#define CDET_HALO_X_AUX 0  // default cache policy. Measured: non-temporal (2) on the pixel stream is SLOWER (40x40 320->320: 0.103 -> 0.112 ms) -- a halo row
-                           // is fetched by both cout blocks of its tile and by the neighbouring tiles, and those re-reads want the L2 copy
-#endif
-
-// wave-uniform counted wait
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    }
-}
-template <int N>
-__device__ __forceinline__ void wait_vm_lgkm0() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
-
-typedef __attribute__((ext_vector_type(2))) float hf32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
-typedef __attribute__((ext_vector_type(2))) _Float16 hf16x2;
-template <int DT>
-__device__ __forceinline__ uint32_t hpack2(float a, float b) {
-    if (DT == CDET_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(hf32x2{a, b}, hbf16x2));
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hf32x2{a, b}, hf16x2));
-}
-
-// sum over the 32 lanes of a half wave (every lane ends up with the total)
-__device__ __forceinline__ float half_sum32(float v) {
-#define CDET_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
-    CDET_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
-    CDET_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
-    CDET_DPP_ADD(0x141);  // row_half_mirror
-    CDET_DPP_ADD(0x140);  // row_mirror
-#undef CDET_DPP_ADD
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
-    return v;
-}
-
-constexpr int HEPI_RAW = 0, HEPI_FULL = 1;
 constexpr int HEPI_STAGE_OFF = 6912;  // epilogue LDS map (after HZERO): statistics scratch [4][2][HC] fp32, scale/bias [2][HC] fp32, then the store staging
 
 #ifdef CDET_PROFILING
@@ -132,7 +68,7 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // of 256 consecutive pixels (halo 256 + 2W + 2 rows) -- half the halo on the 80-wide maps, and the only form that fits for 160-wide.
 // ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no epilogue
 // stores, 16 = no K loop
-template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0>
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     constexpr int HPB = 128 * NG;         // pixels per block: a wave owns NG 32-pixel fragments (NG = 1: half tiles for layers whose
                                           // 256-pixel tiles would leave most CUs idle, e.g. the 20 x 20 maps at batch 32)
@@ -214,14 +150,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     const int xls = (lane & 3) ^ ((lane >> 4) & 3);          // logical 16-byte slot this lane fetches (the same for every piece)
     // ---- W DMA: a plain linear copy of the packed tile; wave w copies bytes [w*WQ, (w+1)*WQ) -----------------------------------
     const unsigned wvoff = (unsigned)(wave * WQ + lane * 16);
-    const unsigned wtile0 = (unsigned)cblk * (unsigned)nsteps * (unsigned)WTILE;
+    const unsigned wtile0 = (unsigned)cblk * (unsigned)(nsteps * (OMAP ? a.wts : 1)) * (unsigned)WTILE;
 
     // Steps / chunks beyond the end are requested through an EMPTY descriptor (every load returns zeros), so the number of DMA
     // instructions per step -- what the counted vmcnt waits rely on -- never changes.
     auto dma_w1 = [&](int step, int stage, int j) {  // piece j of this wave of the weight tile of K step `step` -> ring stage `stage`
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, step < nsteps ? (int)a.w_bytes : 0, 0x00020000);
         unsigned char* dst = wbase + stage * WTILE + wave * WQ + j * 1024;
-        const unsigned soff = wtile0 + (unsigned)step * (unsigned)WTILE;
+        const unsigned soff = wtile0 + (OMAP ? (unsigned)(step * a.wts + a.wt0) : (unsigned)step) * (unsigned)WTILE;
         if (j < NWP - 1) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);
         else if (j == NWP - 1 && lane < 32) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);  // the 512-byte tail of the wave's share
     };
@@ -254,6 +190,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             pixh[g] = i + halo0;
             const int p = p0 + i;
             pout[g] = p;
+            if (OMAP) {  // destination pixel of the strided form (also addresses the residual = the gradient already there)
+                const int n_ = p / (a.H * W), r_ = p - n_ * (a.H * W);
+                const int y_ = r_ / W, x_ = r_ - y_ * W;
+                pout[g] = p < a.M ? (n_ * a.Hd + 2 * y_ + a.cp) * a.Wd + 2 * x_ + a.cq : a.M;
+            }
             if (p < a.M) {
                 if (NT == 9) {
                     const int x = p % W;
@@ -511,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int p = pout[g];
-        const bool pok = p < a.M;
+        const bool pok = OMAP ? (p0 + wave * (32 * NG) + g * 32 + l31) < a.M : p < a.M;
         const int64_t rb = (int64_t)p * a.res_ld + a.res_coff;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -572,7 +513,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 if (PATCH) po = (pn * a.H + py0 + i / PATCH_W) * W + px0 + i % PATCH_W;
                 else po = p0 + i;
                 const int co = c0 + 8 * c;
-                if (po < a.M && co < a.Cd) {
+                bool in = po < a.M;
+                if (OMAP && in) {
+                    const int n_ = po / (a.H * W), r_ = po - n_ * (a.H * W);
+                    const int y_ = r_ / W, x_ = r_ - y_ * W;
+                    po = (n_ * a.Hd + 2 * y_ + a.cp) * a.Wd + 2 * x_ + a.cq;
+                }
+                if (in && co < a.Cd) {
                     if (!(ABL & 8)) *reinterpret_cast<u32x4*>(yp + (int64_t)po * a.dst_ld + a.dst_coff + co) = pk;
                     else asm volatile("" ::"v"(pk));
                 }
@@ -859,6 +806,7 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     a.tiles_per_img = (d->Hs / PATCH_W) * (d->Ws / PATCH_W);
     a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * d->kh * d->kw * rb * HROW);
+    a.wts = 1; a.wt0 = 0; a.Hd = d->Hd; a.Wd = d->Wd; a.cp = a.cq = 0;
     const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
     const int nblocks = a.n_pblk * a.n_cblk;
     hipStream_t s = (hipStream_t)stream;
@@ -867,3 +815,65 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     CDET_LAUNCH_CHECK();
     return 0;
 }
+
+// The (0, 0) parity class of a stride-2 3x3 data gradient (conv_vt.hip): dX(2y, 2x) = sum_co dY(y, x) w[co, ci, 1, 1] -- a 1x1 convolution of
+// dY with the centre tap of the 9-tap DGRAD operand, written to every other pixel of every other row of dX (residual = the gradient
+// already there, same addressing). d: the CDET_CONV_DGRAD descriptor of the stride-2 convolution (source = dY, destination = dX).
+namespace cdet {
+template <int DT, int NF, int NG>
+static void launch_class00(const HaloArgs& a, bool full, size_t lds, int nblocks, hipStream_t s) {
+    if (full) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, 1, NF, HEPI_FULL, 3, false, NG, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv_halo_kernel<DT, 1, NF, HEPI_FULL, 3, false, NG, 0, true>), dim3(nblocks), dim3(256), lds, s, a);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, 1, NF, HEPI_RAW, 3, false, NG, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv_halo_kernel<DT, 1, NF, HEPI_RAW, 3, false, NG, 0, true>), dim3(nblocks), dim3(256), lds, s, a);
+    }
+}
+
+int halo_launch_class00(const cdet_conv_desc* d, const void* dy, const void* w_dgrad_tiled, const void* residual, void* dx, hipStream_t s) {
+    cdet_conv_desc d1 = *d;
+    d1.kh = d1.kw = 1; d1.stride = 1; d1.pad = 0; d1.mode = CDET_CONV_FWD;
+    d1.Hd = d->Hs; d1.Wd = d->Ws;  // the 1x1 convolution's own output grid = dY's; the strided mapping is applied by the kernel
+    const HaloPlan pl = halo_plan(&d1);
+    CDET_CHECK_ARG(pl.ok && !pl.patch, "cdet_conv2d_s2_tiled_dgrad: the (0, 0) class does not fit the 1x1 kernel");
+    const int rb = pl.nf * 32;
+    HaloArgs a;
+    a.x = (const uint16_t*)dy; a.w = (const uint16_t*)w_dgrad_tiled; a.scale = nullptr; a.bias = nullptr; a.res = (const uint16_t*)residual;
+    a.y = dx; a.stats = nullptr;
+    a.H = d->Hs; a.W = d->Ws; a.Cd = d->Cd;
+    a.M = d->N * d->Hs * d->Ws;
+    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;
+    a.res_ld = d->res_ld; a.res_coff = d->res_coff;
+    a.nchunk = div_up(d->Cs, 32);
+    a.Cs = d->Cs;
+    a.n_pblk = div_up(a.M, pl.hp);
+    a.n_cblk = div_up(d->Cd, rb);
+    a.act = CDET_ACT_NONE;
+    a.XH = pl.XH;
+    a.tiles_x = a.tiles_per_img = 1;
+    a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
+    a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * 9 * rb * HROW);
+    a.wts = 9; a.wt0 = 4; a.Hd = d->Hd; a.Wd = d->Wd; a.cp = 0; a.cq = 0;
+    const bool full = residual != nullptr;
+    const int nblocks = a.n_pblk * a.n_cblk;
+    const bool bf = d->dtype == CDET_BF16;
+    if (pl.nf == 5) {
+        if (pl.ng == 2) { if (bf) launch_class00<CDET_BF16, 5, 2>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 5, 2>(a, full, pl.lds, nblocks, s); }
+        else { if (bf) launch_class00<CDET_BF16, 5, 1>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 5, 1>(a, full, pl.lds, nblocks, s); }
+    } else {
+        if (pl.ng == 2) { if (bf) launch_class00<CDET_BF16, 3, 2>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 3, 2>(a, full, pl.lds, nblocks, s); }
+        else { if (bf) launch_class00<CDET_BF16, 3, 1>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 3, 1>(a, full, pl.lds, nblocks, s); }
+    }
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace cdet

@@ -1,0 +1,76 @@
+// Device helpers shared by the tap-resident convolution kernels (conv_halo.hip: stride-1 3x3 / 1x1; conv_vt.hip: the stride-2
+// forward and the stride-2 data-gradient classes): MFMA 32x32x16 wrapper, LDS-DMA piece, counted waits, packing, half-wave sums.
+#pragma once
+#include "common.h"
+
+namespace cdet {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int HP = 256;             // pixels per block (128 in the half-tile form, template parameter NG = 1)
+constexpr int HROW = 64;            // bytes per LDS row (32 channels)
+constexpr int HZERO = 256;          // LDS bytes reserved in front (zero row)
+constexpr int MAXXP = 7;            // X DMA pieces (16 rows each) per wave per chunk: XH <= 448
+constexpr unsigned HSENT = 0xE0000000u;  // byte offset beyond every buffer: the DMA returns zeros
+constexpr int PATCH_W = 16, PATCH_HPW = PATCH_W + 2;  // patch mode: 16 x 16 pixel tiles, halo pitch 18
+constexpr int HEPI_RAW = 0, HEPI_FULL = 1;           // epilogue: raw 16-bit output (+ BN partial sums) / scale, bias, SiLU, residual
+
+template <int DT>
+__device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c) {
+    if (DT == CDET_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int AUX = 0>
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, AUX);
+}
+#ifndef CDET_HALO_X_AUX
+#define CDET_HALO_X_AUX 0  // default cache policy. Measured: non-temporal (2) on the pixel stream is SLOWER (40x40 320->320: 0.103 -> 0.112 ms) -- a halo row
+                           // is fetched by both cout blocks of its tile and by the neighbouring tiles, and those re-reads want the L2 copy
+#endif
+
+// wave-uniform counted wait
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    }
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((ext_vector_type(2))) float hf32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 hf16x2;
+template <int DT>
+__device__ __forceinline__ uint32_t hpack2(float a, float b) {
+    if (DT == CDET_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(hf32x2{a, b}, hbf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(hf32x2{a, b}, hf16x2));
+}
+
+// sum over the 32 lanes of a half wave (every lane ends up with the total)
+__device__ __forceinline__ float half_sum32(float v) {
+#define CDET_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    CDET_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    CDET_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    CDET_DPP_ADD(0x141);  // row_half_mirror
+    CDET_DPP_ADD(0x140);  // row_mirror
+#undef CDET_DPP_ADD
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // lane ^ 16
+    return v;
+}
+
+
+}  // namespace cdet

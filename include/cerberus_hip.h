@@ -162,6 +162,20 @@ int64_t cdet_conv2d_wgrad_grouped_ws_elems(const cdet_conv_desc* d, int32_t n_it
 int cdet_conv2d_wgrad_grouped(const cdet_conv_desc* d, const cdet_wgrad_item* items_dev, int32_t n_items, float* ws,
                               int32_t accumulate, void* stream);
 
+/* Stride-2 3x3 convolutions (models/common.py:57-62 with s = 2: the down-sampling rows of backbone and neck) on the tap-resident
+ * machinery (csrc/conv_vt.hip): the input's four parity planes are staged as strided gathers and serve 4 / 2 / 2 / 1 taps each.
+ * cdet_conv2d_s2_tiled: forward, arguments as cdet_conv2d_tiled (w_tiled = the forward operand of cdet_pack_weights_tiled).
+ * cdet_conv2d_s2_tiled_dgrad: data gradient; d is the CDET_CONV_DGRAD descriptor cdet_conv2d takes (source = dY, destination = dX),
+ * w_tiled = the DGRAD operand of cdet_pack_weights_tiled, residual = the gradient already in dX's place (fan-in) or NULL; the four
+ * parity classes of dX run as four launches. scale / bias / stats must be NULL. _ok: 1 when the geometry is taken (d->mode selects
+ * forward or data gradient). */
+int cdet_conv2d_s2_tiled_ok(const cdet_conv_desc* d);
+int cdet_conv2d_s2_tiled_stat_blocks(const cdet_conv_desc* d);
+int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
+                         const void* residual, void* y, float* stats, void* stream);
+int cdet_conv2d_s2_tiled_dgrad(const cdet_conv_desc* d, const void* dy, const void* w_tiled, const float* scale, const float* bias,
+                               const void* residual, void* dx, float* stats, void* stream);
+
 /* Stem convolution (models/common.py:57 for the first backbone row, Cin = 3): reads the image in the
  * reference's NCHW layout (uint8 scaled by 1/255 -- trainers/base_trainer.py:61-63 -- or float), 3x3 stride 2 pad 1,
  * writes NHWC. Direct (non-MFMA) kernel: K = 27, HBM-bound. Same epilogue/stat semantics as cdet_conv2d. */

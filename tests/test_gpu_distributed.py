@@ -263,7 +263,7 @@ def test_dry_comm_every_virtual_rank_enqueues_the_same_collective_sequence():
     root = Path(__file__).resolve().parents[1]
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--dry-comm"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])  # (RCCL prints its banner after the JSON line)
     assert out["identical_on_all_ranks"] is True and set(out["plans"]) == {"v8x_2task.yaml", "v8x_3task.yaml"}
     two = out["plans"]["v8x_2task.yaml"]["steps"]
     # 97 BatchNorm layers per task path, one all-reduce per layer and direction (forward statistics, backward sums), + one gradient

@@ -138,6 +138,57 @@ def test_tiled_conv_and_its_data_gradient_exact_at_full_size(case):
     assert float((dw.double() * w.double()).sum()) == float((dst.torch().double() * dy.double()).sum())
 
 
+# (N, H, W of the INPUT, Cin, Cout): the stride-2 rows of YOLOv8x at batch 32 @640 (backbone rows 1, 3, 5, 7 and the two of a neck)
+S2_FULL = [(32, 320, 320, 80, 160), (32, 160, 160, 160, 320), (32, 80, 80, 320, 640), (32, 40, 40, 640, 640), (32, 80, 80, 320, 320)]
+
+
+@pytest.mark.parametrize("case", S2_FULL)
+def test_stride2_tiled_conv_and_data_gradient_exact_at_full_size(case):
+    """cdet_conv2d_s2_tiled / cdet_conv2d_s2_tiled_dgrad (csrc/conv_vt.hip: parity-plane forward, four-class data gradient) at
+    BASELINE sizes against the plain fp32 PyTorch reference, with the small-integer operands of
+    test_tiled_conv_and_its_data_gradient_exact_at_full_size: output, BatchNorm partial sums, data gradient and its fan-in form
+    must EQUAL the reference bit for bit, and the adjoint identity with the weight gradient holds exactly."""
+    import torchref as R
+    from cerberusdet_amd import _lib as L
+    from cerberusdet_amd import ops
+
+    N, H, W, Ci, Co = case
+    Ho, Wo = H // 2, W // 2
+    g = torch.Generator(device=DEV).manual_seed(29)
+    dtype = torch.bfloat16
+    w = _sparse_pm1((Co, Ci, 3, 3), 48.0, max(Ci, Co) * 9, g)
+    assert float(w.abs().sum((1, 2, 3)).max()) <= 120 and float(w.abs().sum((0, 2, 3)).max()) <= 120
+    x = torch.randint(-2, 3, (N, H, W, Ci), generator=g, device=DEV).to(dtype)
+    src = ops.View(x)
+    wf, wd = ops.pack_weight_tiled(w, dtype, fwd=True, dgrad=True)
+    dst = ops.new_act(N, Ho, Wo, Co, dtype)
+    assert ops.conv2d_s2_tiled_ok(src, dst)
+    nblk = ops.conv_s2_tiled_stat_blocks(src, dst)
+    stats = torch.zeros(nblk * 2 * Co, device=DEV)
+    ops.conv2d_s2_tiled(src, wf, dst, stats=stats)
+    ref = R.conv_fwd(x.float(), w, 2)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(dst.torch().float(), ref), f"{int((dst.torch().float() != ref).sum())} of {ref.numel()} outputs differ"
+    st = stats.view(nblk, 2, Co).double().sum(0)
+    assert torch.equal(st[0], ref.double().sum((0, 1, 2))) and torch.equal(st[1], (ref.double() ** 2).sum((0, 1, 2)))
+    del ref
+    dy = torch.randint(-2, 3, (N, Ho, Wo, Co), generator=g, device=DEV).to(dtype)
+    dyv = ops.View(dy)
+    dx = ops.new_act(N, H, W, Ci, dtype)
+    assert ops.conv2d_s2_tiled_ok(dyv, dx, L.CONV_DGRAD)
+    ops.conv2d_s2_tiled_dgrad(dyv, wd, dx)
+    dref = R.conv_dgrad(dy.float(), w, 2, H, W)
+    assert float(dref.abs().max()) <= 250
+    assert torch.equal(dx.torch().float(), dref), f"{int((dx.torch().float() != dref).sum())} of {dref.numel()} gradient elements differ"
+    prev = torch.randint(-3, 4, (N, H, W, Ci), generator=g, device=DEV).to(dtype)
+    out = ops.View(prev.clone())
+    ops.conv2d_s2_tiled_dgrad(dyv, wd, out, res=out)
+    assert torch.equal(out.torch().float(), dref + prev.float())
+    dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    ops.conv2d_wgrad(src, dyv, dw, 3, 2)
+    assert float((dw.double() * w.double()).sum()) == float((dst.torch().double() * dy.double()).sum())
+
+
 @pytest.fixture(scope="module")
 def v8x_trainer():
     import bench
