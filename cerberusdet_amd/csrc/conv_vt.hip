@@ -41,6 +41,7 @@ struct VtArgs {
     int tiles_x, tiles_per_img;
     int cp, cq;  // class parity: the class writes dX(2y' + cp, 2x' + cq)
     unsigned x_bytes, w_bytes;
+    int dbg;
 };
 
 constexpr int VT_S2FWD = 0, VT_CLASS11 = 1, VT_CLASS10 = 2, VT_CLASS01 = 3;
@@ -81,8 +82,12 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
     constexpr bool FWD = MODE == VT_S2FWD;
     constexpr int HC = NF * 32;
     constexpr int WTILE = HC * HROW;
-    constexpr int WQ = WTILE / 4;
-    constexpr int NWP = (WQ + 1023) / 1024;
+    constexpr int WPC = WTILE / 1024;     // 1-KiB DMA pieces per weight tile: 10 / 6
+    constexpr int NWP = (WPC + 3) / 4;    // pieces per wave: 3 / 2 -- piece j of wave w is piece 4*j + w of the tile; ids beyond the tile
+                                          // (two per tile) are issued through an empty descriptor into a dump area, so that every wave
+                                          // issues the same number of DMA instructions WITHOUT a divergent branch (a `lane < 32` half piece,
+                                          // as conv_halo.hip splits its tiles, made hipcc merge the branch tails here and hoist the M0 of a
+                                          // waterfall loop: half of a piece landed 1 KiB off)
     constexpr int NM = NG * NF;
     constexpr int NR = NF + NG;
     constexpr int NSW = 3;
@@ -146,16 +151,17 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
     }
     const bool partial = (a.Cs & 31) != 0;
     const int xls = (lane & 3) ^ ((lane >> 4) & 3);
-    const unsigned wvoff = (unsigned)(wave * WQ + lane * 16);
+    unsigned char* const wdump = wbase + 3 * WTILE;  // 1 KiB nobody reads
     const unsigned wtile0 = (unsigned)cblk * (unsigned)(a.nchunk * 9) * (unsigned)WTILE;  // both weight operands are 9-tap packs
 
     // weight tile of (chunk, step position u) -> ring stage; chunks beyond the end go through an EMPTY descriptor (zeros, same count)
     auto dma_w1 = [&](int chunk, int wt, int stage, int j) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, chunk < a.nchunk ? (int)a.w_bytes : 0, 0x00020000);
-        unsigned char* dst = wbase + stage * WTILE + wave * WQ + j * 1024;
+        const int id = 4 * j + wave;  // wave-uniform
+        const bool real = id < WPC;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (real && chunk < a.nchunk) ? (int)a.w_bytes : 0, 0x00020000);
+        unsigned char* dst = real ? wbase + stage * WTILE + id * 1024 : wdump;
         const unsigned soff = wtile0 + (unsigned)(chunk * 9 + wt) * (unsigned)WTILE;
-        if (j < NWP - 1) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);
-        else if (j == NWP - 1 && lane < 32) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);
+        dma16(rs, (unsigned)((real ? id : 0) * 1024 + lane * 16), soff, dst);
     };
     // pixel piece i of this wave: channels of `chunk`, plane offset `poff` (bytes) -> pixel buffer xb
     auto dma_x = [&](int i, int chunk, unsigned poff, int xb) {
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
         //   the weight tile of st + 2 (issued in phase B of st - 1)                                     NWP
         //   + the pixel pieces of phase A of this step and of the previous one, unless the plane that starts at st + 1 is among them
         //     (then everything up to its last piece has to land, which leaves only what was issued after it)
+        if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (FWD) {
             // u: newest needed            issued after it
             // 0: W(st+1) [B of u7 prev]   X(P11') was in front of W there; A(u8) none; B(u8) W; A(u0) 5 pieces        -> NWP + 5
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
                 const int w2s = xb_ ? (NM >= 10 ? 9 : 5) : (NM >= 10 ? 6 : 4);
                 if (i == w0s) dma_w1(c3, wt3, st3, 0);
                 if (i == w1s) dma_w1(c3, wt3, st3, 1);
-                if (i == w2s && NWP > 2) dma_w1(c3, wt3, st3, 2);
+                if (NWP > 2 && i == w2s) dma_w1(c3, wt3, st3, 2);
                 if (i >= 1 && 2 * (i - 1) < NR) frag(wsn, bo_nxt, 0, 2 * (i - 1), a0, b0);
                 if (i >= 1 && 2 * (i - 1) + 1 < NR) frag(wsn, bo_nxt, 0, 2 * (i - 1) + 1, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -352,6 +359,10 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) bo_cur[g] = bo_nxt[g];
+        if (a.dbg & 2) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     };
 
     // The ring stage of a step is st % 3; the loops are unrolled over the least common period of (NT, 3) so that it is a constant.
@@ -526,7 +537,7 @@ static VtPlan vt_plan(const cdet_conv_desc* d, bool dgrad) {
     const int rb = pl.nf * 32;
     const int64_t wb = (int64_t)div_up(d->Cd, rb) * div_up(d->Cs, 32) * 9 * rb * HROW;
     if (wb >= 0xC0000000ll) return pl;
-    pl.lds = (size_t)HZERO + 2 * (size_t)VT_XR * HROW + 3 * (size_t)rb * HROW;
+    pl.lds = (size_t)HZERO + 2 * (size_t)VT_XR * HROW + 3 * (size_t)rb * HROW + 1024;  // + the dump piece
     const size_t epi = (size_t)HZERO + VEPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16) + 4 * 32 * sizeof(int);
     if (pl.lds < epi) pl.lds = epi;
     pl.ok = true;
@@ -592,6 +603,7 @@ static void vt_fill(VtArgs& a, const cdet_conv_desc* d, const VtPlan& pl, bool d
     a.cp = a.cq = 0;
     a.x_bytes = (unsigned)((int64_t)d->N * d->Hs * d->Ws * d->src_ld * 2);
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * 9 * rb * HROW);
+    a.dbg = getenv("CDET_VT_DBG") ? atoi(getenv("CDET_VT_DBG")) : 0;
 }
 
 extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
