@@ -816,64 +816,3 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     return 0;
 }
 
-// The (0, 0) parity class of a stride-2 3x3 data gradient (conv_vt.hip): dX(2y, 2x) = sum_co dY(y, x) w[co, ci, 1, 1] -- a 1x1 convolution of
-// dY with the centre tap of the 9-tap DGRAD operand, written to every other pixel of every other row of dX (residual = the gradient
-// already there, same addressing). d: the CDET_CONV_DGRAD descriptor of the stride-2 convolution (source = dY, destination = dX).
-namespace cdet {
-template <int DT, int NF, int NG>
-static void launch_class00(const HaloArgs& a, bool full, size_t lds, int nblocks, hipStream_t s) {
-    if (full) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, 1, NF, HEPI_FULL, 3, false, NG, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
-        hipLaunchKernelGGL((conv_halo_kernel<DT, 1, NF, HEPI_FULL, 3, false, NG, 0, true>), dim3(nblocks), dim3(256), lds, s, a);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, 1, NF, HEPI_RAW, 3, false, NG, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
-        hipLaunchKernelGGL((conv_halo_kernel<DT, 1, NF, HEPI_RAW, 3, false, NG, 0, true>), dim3(nblocks), dim3(256), lds, s, a);
-    }
-}
-
-int halo_launch_class00(const cdet_conv_desc* d, const void* dy, const void* w_dgrad_tiled, const void* residual, void* dx, hipStream_t s) {
-    cdet_conv_desc d1 = *d;
-    d1.kh = d1.kw = 1; d1.stride = 1; d1.pad = 0; d1.mode = CDET_CONV_FWD;
-    d1.Hd = d->Hs; d1.Wd = d->Ws;  // the 1x1 convolution's own output grid = dY's; the strided mapping is applied by the kernel
-    const HaloPlan pl = halo_plan(&d1);
-    CDET_CHECK_ARG(pl.ok && !pl.patch, "cdet_conv2d_s2_tiled_dgrad: the (0, 0) class does not fit the 1x1 kernel");
-    const int rb = pl.nf * 32;
-    HaloArgs a;
-    a.x = (const uint16_t*)dy; a.w = (const uint16_t*)w_dgrad_tiled; a.scale = nullptr; a.bias = nullptr; a.res = (const uint16_t*)residual;
-    a.y = dx; a.stats = nullptr;
-    a.H = d->Hs; a.W = d->Ws; a.Cd = d->Cd;
-    a.M = d->N * d->Hs * d->Ws;
-    a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;
-    a.res_ld = d->res_ld; a.res_coff = d->res_coff;
-    a.nchunk = div_up(d->Cs, 32);
-    a.Cs = d->Cs;
-    a.n_pblk = div_up(a.M, pl.hp);
-    a.n_cblk = div_up(d->Cd, rb);
-    a.act = CDET_ACT_NONE;
-    a.XH = pl.XH;
-    a.tiles_x = a.tiles_per_img = 1;
-    a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
-    a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * 9 * rb * HROW);
-    a.wts = 9; a.wt0 = 4; a.Hd = d->Hd; a.Wd = d->Wd; a.cp = 0; a.cq = 0;
-    const bool full = residual != nullptr;
-    const int nblocks = a.n_pblk * a.n_cblk;
-    const bool bf = d->dtype == CDET_BF16;
-    if (pl.nf == 5) {
-        if (pl.ng == 2) { if (bf) launch_class00<CDET_BF16, 5, 2>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 5, 2>(a, full, pl.lds, nblocks, s); }
-        else { if (bf) launch_class00<CDET_BF16, 5, 1>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 5, 1>(a, full, pl.lds, nblocks, s); }
-    } else {
-        if (pl.ng == 2) { if (bf) launch_class00<CDET_BF16, 3, 2>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 3, 2>(a, full, pl.lds, nblocks, s); }
-        else { if (bf) launch_class00<CDET_BF16, 3, 1>(a, full, pl.lds, nblocks, s); else launch_class00<CDET_F16, 3, 1>(a, full, pl.lds, nblocks, s); }
-    }
-    CDET_LAUNCH_CHECK();
-    return 0;
-}
-}  // namespace cdet

@@ -44,7 +44,7 @@ struct VtArgs {
     int dbg;
 };
 
-constexpr int VT_S2FWD = 0, VT_CLASS11 = 1, VT_CLASS10 = 2, VT_CLASS01 = 3;
+constexpr int VT_S2FWD = 0, VT_CLASS11 = 1, VT_CLASS10 = 2, VT_CLASS01 = 3, VT_CLASS00 = 4;
 constexpr int VT_XR = 320;            // rows per pixel buffer: 5 pieces of 16 rows per wave (17 x 17 = 289, 256 + W + 1 <= 297 for W <= 40)
 constexpr int VT_NXP = 5;             // pixel DMA pieces per wave and virtual chunk (pieces beyond the halo fetch zeros)
 constexpr int VT_HPW = PATCH_W + 1;   // patch mode: halo pitch 17
@@ -56,6 +56,7 @@ template <> struct VtMode<VT_S2FWD> { static constexpr int NT = 9; };
 template <> struct VtMode<VT_CLASS11> { static constexpr int NT = 4; };
 template <> struct VtMode<VT_CLASS10> { static constexpr int NT = 2; };
 template <> struct VtMode<VT_CLASS01> { static constexpr int NT = 2; };
+template <> struct VtMode<VT_CLASS00> { static constexpr int NT = 1; };
 
 // (ky, kx) of step u
 template <int MODE>
@@ -63,20 +64,21 @@ __device__ __forceinline__ constexpr int vt_ky(int u) {
     if (MODE == VT_S2FWD) return u < 4 ? (u >> 1) * 2 : (u < 6 ? (u - 4) * 2 : 1);
     if (MODE == VT_CLASS11) return (u >> 1) * 2;
     if (MODE == VT_CLASS10) return u * 2;
-    return 1;
+    return 1;  // CLASS01, CLASS00
 }
 template <int MODE>
 __device__ __forceinline__ constexpr int vt_kx(int u) {
     if (MODE == VT_S2FWD) return u < 4 ? (u & 1) * 2 : (u < 6 ? 1 : (u < 8 ? (u - 6) * 2 : 1));
     if (MODE == VT_CLASS11) return (u & 1) * 2;
-    if (MODE == VT_CLASS10) return 1;
+    if (MODE == VT_CLASS10 || MODE == VT_CLASS00) return 1;
     return u * 2;
 }
 // forward: plane index of step u (0 = P11, 1 = P10, 2 = P01, 3 = P00) and whether u is the plane's first step
 __device__ __forceinline__ constexpr int vt_plane(int u) { return u < 4 ? 0 : (u < 6 ? 1 : (u < 8 ? 2 : 3)); }
 
+// One workgroup's tile: pixel block pblk, cout block cblk; cp / cq = the parity class a CLASS mode writes.
 template <int DT, int NF, int EPI, int MODE, bool PATCH>
-__global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
+__device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const int cblk, const int cp, const int cq) {
     constexpr int NG = 2;
     constexpr int NT = VtMode<MODE>::NT;
     constexpr bool FWD = MODE == VT_S2FWD;
@@ -98,14 +100,6 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 
-    int L;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x;
-        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int cblk = L % a.n_cblk;
-    const int pblk = L / a.n_cblk;
     const int c0 = cblk * HC;
     const int Wp = a.Wp;
     const int pitch = PATCH ? VT_HPW : Wp;  // halo row pitch of one tile-space row
@@ -210,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
             const int r = p - n * (a.Hp * Wp);
             y = r / Wp; x = r - y * Wp;
         }
-        return FWD ? (n * a.Hd + y) * a.Wd + x : (n * a.Hd + 2 * y + a.cp) * a.Wd + 2 * x + a.cq;
+        return FWD ? (n * a.Hd + y) * a.Wd + x : (n * a.Hd + 2 * y + cp) * a.Wd + 2 * x + cq;
     };
 
     f32x16 acc[NF][NG];
@@ -224,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
     // ---- prologue: the first virtual chunk's pixels, weight tiles of steps 0 .. 2 ---------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < VT_NXP; ++i) dma_x(i, 0, plane_off(0), 0);
+    if (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < VT_NXP; ++i) dma_x(i, 1, 0u, 1);
+    }
 #pragma unroll
     for (int s_ = 0; s_ < NSW; ++s_) {
         const int wt = FWD ? vt_ky<MODE>(s_ % NT) * 3 + vt_kx<MODE>(s_ % NT) : 8 - (vt_ky<MODE>(s_ % NT) * 3 + vt_kx<MODE>(s_ % NT));
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
         const int un = (u + 1) % NT;
         const int chunkn = chunk + (u + 1 == NT ? 1 : 0);
         // pixel pieces issued in phase A / phase B of this step
-        const bool xa = FWD ? (u == 0 || u == 4 || u == 6) : (u == 0);
-        const bool xb_ = FWD && u == 7;
+        const bool xa = FWD ? (u == 0 || u == 4 || u == 6) : (NT > 1 && u == 0);
+        const bool xb_ = (FWD && u == 7) || NT == 1;  // NT == 1: chunk + 2 goes into this chunk's buffer as soon as its last read is done
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
@@ -324,10 +322,13 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
             // 2: W(st+1) [B of u0]        B(u1) W -> NWP                  3: W(st+1), next chunk [A of u0]  B(u2) W -> NWP
             if (u < 2) wait_vm_lgkm0<NWP + VT_NXP>();
             else wait_vm_lgkm0<NWP>();
-        } else {
+        } else if (NT == 2) {
             // 0: W(st+1) [B of u0 prev]   B(u1 prev) W; A(u0) 5 -> NWP + 5     1: next chunk [A of u0]  B(u0) W -> NWP
             if (u == 0) wait_vm_lgkm0<NWP + VT_NXP>();
             else wait_vm_lgkm0<NWP>();
+        } else {
+            // NT == 1: the pixels of chunk st + 1 were issued in phase B of st - 1, in front of that phase's W -> NWP
+            wait_vm_lgkm0<NWP>();
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -338,12 +339,13 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
-                if (xb_) {  // the next chunk's P11 first (needed one step from now), two pieces per slot when there are only six slots
+                if (xb_) {  // the next chunk's P11 (NT == 1: chunk + 2) first: needed one step from now; two pieces per slot when there are only six slots
+                    const int xc = NT == 1 ? chunk + 2 : chunk + 1, xbf = NT == 1 ? (chunk & 1) : 0;
                     if (NM >= 10) {
-                        if (i < VT_NXP) dma_x(i, chunk + 1, plane_off(0), 0);
+                        if (i < VT_NXP) dma_x(i, xc, plane_off(0), xbf);
                     } else {
-                        if (2 * i < VT_NXP) dma_x(2 * i, chunk + 1, plane_off(0), 0);
-                        if (2 * i + 1 < VT_NXP) dma_x(2 * i + 1, chunk + 1, plane_off(0), 0);
+                        if (2 * i < VT_NXP) dma_x(2 * i, xc, plane_off(0), xbf);
+                        if (2 * i + 1 < VT_NXP) dma_x(2 * i + 1, xc, plane_off(0), xbf);
                     }
                 }
                 const int w0s = xb_ ? (NM >= 10 ? 5 : 3) : 0;
@@ -377,11 +379,17 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
             for (int k = 0; k < 12; ++k)
                 if (c3 + k / 4 < a.nchunk) run_step(c3 + k / 4, k % 4, k % 3);
         }
-    } else {
+    } else if (NT == 2) {
         for (int c3 = 0; c3 < a.nchunk; c3 += 3) {
 #pragma unroll
             for (int k = 0; k < 6; ++k)
                 if (c3 + k / 2 < a.nchunk) run_step(c3 + k / 2, k % 2, k % 3);
+        }
+    } else {
+        for (int c3 = 0; c3 < a.nchunk; c3 += 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (c3 + k < a.nchunk) run_step(c3 + k, 0, k);
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
@@ -507,6 +515,34 @@ __global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
     }
 }
 
+// XCD-aware remap (bijective): consecutive logical ids run on ONE XCD
+__device__ __forceinline__ int vt_logical_id() {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7, j = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <int DT, int NF, int EPI, int MODE, bool PATCH>
+__global__ __launch_bounds__(256, 2) void conv_vt_kernel(const VtArgs a) {
+    const int L = vt_logical_id();
+    vt_body<DT, NF, EPI, MODE, PATCH>(a, L / a.n_cblk, L % a.n_cblk, a.cp, a.cq);
+}
+
+// The four parity classes of a stride-2 data gradient in ONE launch: logical id = (pixel tile, class, cout block), so the four classes
+// of a dY tile (and its cout blocks) run next to each other on one XCD and three of the four reads of the tile come out of its L2 --
+// as four launches every class streamed all of dY from HBM again (dX 320 x 320 x 80: 1.05 GB of reads for 0.26 GB of dY).
+template <int DT, int NF, int EPI, bool PATCH>
+__global__ __launch_bounds__(256, 2) void conv_vt_dgrad4_kernel(const VtArgs a) {
+    const int L = vt_logical_id();
+    const int cblk = L % a.n_cblk;
+    const int r = L / a.n_cblk;
+    const int cls = r & 3, pblk = r >> 2;
+    if (cls == 0) vt_body<DT, NF, EPI, VT_CLASS11, PATCH>(a, pblk, cblk, 1, 1);
+    else if (cls == 1) vt_body<DT, NF, EPI, VT_CLASS10, PATCH>(a, pblk, cblk, 1, 0);
+    else if (cls == 2) vt_body<DT, NF, EPI, VT_CLASS01, PATCH>(a, pblk, cblk, 0, 1);
+    else vt_body<DT, NF, EPI, VT_CLASS00, PATCH>(a, pblk, cblk, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 struct VtPlan {
     bool ok, patch;
@@ -571,6 +607,31 @@ static void dispatch_vt(const VtArgs& a, int nf, bool full, bool patch, size_t l
     else dispatch_vt2<DT, 3, MODE>(a, full, patch, lds, nblocks, s);
 }
 
+template <int DT, int NF, int EPI, bool PATCH>
+static void launch_dgrad4(const VtArgs& a, size_t lds, int nblocks, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_vt_dgrad4_kernel<DT, NF, EPI, PATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_vt_dgrad4_kernel<DT, NF, EPI, PATCH>), dim3(nblocks), dim3(256), lds, s, a);
+}
+
+template <int DT>
+static void dispatch_dgrad4(const VtArgs& a, int nf, bool full, bool patch, size_t lds, int nblocks, hipStream_t s) {
+#define CDET_D4(NF_, EPI_)                                                   \
+    do {                                                                     \
+        if (patch) launch_dgrad4<DT, NF_, EPI_, true>(a, lds, nblocks, s);   \
+        else launch_dgrad4<DT, NF_, EPI_, false>(a, lds, nblocks, s);        \
+    } while (0)
+    if (nf == 5) {
+        if (full) CDET_D4(5, HEPI_FULL); else CDET_D4(5, HEPI_RAW);
+    } else {
+        if (full) CDET_D4(3, HEPI_FULL); else CDET_D4(3, HEPI_RAW);
+    }
+#undef CDET_D4
+}
+
 }  // namespace cdet
 
 using namespace cdet;
@@ -625,11 +686,6 @@ extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, cons
     return 0;
 }
 
-// the (0, 0) class is a 1x1 convolution of dY with the centre tap: conv_halo.hip's 1x1 kernel with a strided destination
-namespace cdet {
-int halo_launch_class00(const cdet_conv_desc* d, const void* dy, const void* w_dgrad_tiled, const void* residual, void* dx, hipStream_t s);
-}
-
 extern "C" int cdet_conv2d_s2_tiled_dgrad(const cdet_conv_desc* d, const void* dy, const void* w_dgrad_tiled, const float* scale, const float* bias,
                                           const void* residual, void* dx, float* stats, void* stream) {
     CDET_CHECK_ARG(d && dy && w_dgrad_tiled && dx, "cdet_conv2d_s2_tiled_dgrad: null pointer");
@@ -642,17 +698,9 @@ extern "C" int cdet_conv2d_s2_tiled_dgrad(const cdet_conv_desc* d, const void* d
     VtArgs a;
     vt_fill(a, d, pl, true, dy, w_dgrad_tiled, nullptr, nullptr, residual, dx, nullptr);
     const bool full = residual != nullptr;
-    const int nblocks = a.n_pblk * a.n_cblk;
-    const bool bf = d->dtype == CDET_BF16;
-    a.cp = 1; a.cq = 1;
-    if (bf) dispatch_vt<CDET_BF16, VT_CLASS11>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
-    else dispatch_vt<CDET_F16, VT_CLASS11>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
-    a.cp = 1; a.cq = 0;
-    if (bf) dispatch_vt<CDET_BF16, VT_CLASS10>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
-    else dispatch_vt<CDET_F16, VT_CLASS10>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
-    a.cp = 0; a.cq = 1;
-    if (bf) dispatch_vt<CDET_BF16, VT_CLASS01>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
-    else dispatch_vt<CDET_F16, VT_CLASS01>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
+    const int nblocks = a.n_pblk * 4 * a.n_cblk;  // (pixel tile, class, cout block)
+    if (d->dtype == CDET_BF16) dispatch_dgrad4<CDET_BF16>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
+    else dispatch_dgrad4<CDET_F16>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
     CDET_LAUNCH_CHECK();
-    return halo_launch_class00(d, dy, w_dgrad_tiled, residual, dx, s);
+    return 0;
 }

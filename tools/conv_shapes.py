@@ -34,7 +34,8 @@ def main():
     groups = OrderedDict()
     for fn, args in calls:
         name = getattr(fn, "__name__", "")
-        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad"):
+        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad",
+                        "cdet_conv2d_s2_tiled", "cdet_conv2d_s2_tiled_dgrad"):
             continue
         d = args[0]._obj
         if name == "cdet_conv2d_wgrad_grouped":  # n = layers; the timed call is the whole group (ms and TF/s are per group launch)
@@ -43,7 +44,10 @@ def main():
             g["n"] += 1
             continue
         kind = "wgrad" if name == "cdet_conv2d_wgrad" else ("dgrad" if (d.mode == L.CONV_DGRAD or name.endswith("dgrad")) else "fwd")
-        if name.endswith("tiled_dgrad"):
+        if name == "cdet_conv2d_s2_tiled_dgrad":
+            key = (kind, d.Hd, d.Wd, d.Cd, d.Cs, d.kh, 2)
+            flops = 2.0 * d.N * d.Hs * d.Ws * d.Cs * d.Cd * d.kh * d.kw
+        elif name.endswith("tiled_dgrad"):
             key = (kind, d.Hd, d.Wd, d.Cd, d.Cs, d.kh, 1)
             flops = 2.0 * d.N * d.Hs * d.Ws * d.Cs * d.Cd * d.kh * d.kw
         elif kind == "dgrad":
