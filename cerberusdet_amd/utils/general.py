@@ -69,18 +69,30 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),
                         max_det=300, nm=0) -> List[torch.Tensor]:
     """Same contract as the reference: prediction [bs, 4+nc, A] (or the eval tuple (y, feats)) -> list of [k,6] fp32
-    tensors (x1,y1,x2,y2,conf,cls) on the prediction's device. Not reproduced on purpose: the wall-clock `time_limit`
-    bail-out (general.py:417,477-479) and a-priori `labels` / mask channels (`nm`), which the hot path never uses."""
+    tensors (x1,y1,x2,y2,conf,cls) on the prediction's device. `labels` (autolabelling, general.py:430-436): per image a [n, 5]
+    tensor (cls, x, y, w, h) whose rows join the candidates with confidence 1.0 -- here as extra anchors behind the model's, which is
+    where the reference's `torch.cat((x, v), 0)` puts them (the order decides ties). Not reproduced on purpose: the wall-clock
+    `time_limit` bail-out (general.py:417,477-479) and mask channels (`nm`; CerberusDet has no mask head)."""
     from .. import ops
 
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
-    if nm != 0 or (labels and any(len(lb) for lb in labels)):
-        raise NotImplementedError("cerberusdet_amd NMS: nm and a-priori labels are not part of the detection hot path")
+    if nm != 0:
+        raise NotImplementedError("cerberusdet_amd NMS: mask channels (nm) are not supported (CerberusDet has no mask head)")
     if not prediction.is_cuda:
         raise RuntimeError("cerberusdet_amd.non_max_suppression needs a tensor on the MI355X (no CPU path)")
+    if labels and any(len(lb) for lb in labels):
+        bs, no, _ = prediction.shape
+        n_lab = max(len(lb) for lb in labels)
+        extra = torch.zeros((bs, no, n_lab), dtype=prediction.dtype, device=prediction.device)  # zero scores: never candidates
+        for xi, lb in enumerate(labels):
+            if len(lb):
+                lb = torch.as_tensor(lb, device=prediction.device).float()
+                extra[xi, :4, :len(lb)] = lb[:, 1:5].T.to(prediction.dtype)
+                extra[xi, 4 + lb[:, 0].long(), torch.arange(len(lb), device=prediction.device)] = 1.0
+        prediction = torch.cat((prediction, extra), 2)
     rows, cnt = ops.nms_batched(prediction.contiguous(), conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
     counts = cnt.tolist()  # the only host sync of the call
     return [rows[i, :k] for i, k in enumerate(counts)]

@@ -251,3 +251,29 @@ def test_autograd_bridge_refuses_backward_after_a_newer_forward():
     out2[0].float().sum().backward()  # the newest forward may go backward
     with pytest.raises(RuntimeError, match="has run forward again"):
         out1[0].float().sum().backward()
+
+
+def test_nms_apriori_labels_join_the_candidates_like_the_reference():
+    """non_max_suppression(labels=...) (reference general.py:430-436, autolabelling): label rows (cls, x, y, w, h) become candidates
+    with confidence 1.0 behind the model's own -- bit-exact against the oracle run on the concatenated candidates."""
+    from cerberusdet_amd.utils.general import non_max_suppression
+    from oracle import nms as on
+
+    g = torch.Generator().manual_seed(5)
+    bs, nc, A = 3, 6, 400
+    y = torch.zeros(bs, 4 + nc, A)
+    y[:, 0:2] = torch.rand(bs, 2, A, generator=g) * 200
+    y[:, 2:4] = torch.rand(bs, 2, A, generator=g) * 40 + 10
+    y[:, 4:] = torch.rand(bs, nc, A, generator=g) * 0.6
+    labels = [torch.tensor([[2.0, 50, 60, 30, 30], [4.0, 120, 80, 25, 40]]), torch.zeros((0, 5)), torch.tensor([[0.0, 100, 100, 50, 50]])]
+    got = non_max_suppression(y.to(DEV), 0.25, 0.45, labels=labels)
+    ycat = torch.cat((y, torch.zeros(bs, 4 + nc, 2)), 2)
+    for xi, lb in enumerate(labels):
+        for j, r in enumerate(lb):
+            ycat[xi, :4, A + j] = r[1:5]
+            ycat[xi, 4 + int(r[0]), A + j] = 1.0
+    want = on.non_max_suppression(ycat.numpy(), conf_thres=0.25, iou_thres=0.45, max_det=300)
+    for xi in range(bs):
+        assert np.array_equal(got[xi].cpu().numpy(), want[xi]), xi
+        if len(labels[xi]):  # a label row survives with confidence 1.0 at the top
+            assert float(got[xi][0, 4]) == 1.0
