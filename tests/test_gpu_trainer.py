@@ -82,7 +82,7 @@ def test_one_pass_vs_well_conditioned_reference_golden():
     <= 40 %; cosine: 98 % above 0.93, 90 % above 0.97; the single worst tensor only loosely, see util.py) -- the same bounds the bf16-emulating fp32 oracle meets on this fixture (CPU test
     test_train_wc_fixture_oracle_matches_reference_and_is_well_conditioned). Reference: trainers/averaging.py:142-168, utils/loss.py:133-181."""
     from cerberusdet_amd.trainers import Averaging
-    from util import WC_BOUNDS, update_error, wc_check
+    from util import WC_BOUNDS, update_error, wc_check, wc_compare, wc_emulation_errors
 
     arrays, meta = load_golden("train_wc")
     m = _wc_model(meta)
@@ -111,6 +111,8 @@ def test_one_pass_vs_well_conditioned_reference_golden():
         for k in keys:
             errs.append(update_error(synth.sample(named[k].grad.float().cpu().numpy()), arrays[f"A/{t}/grad/{k}"]) + (f"{t}:{k}",))
     print("[train_wc/HIP] " + wc_check(errs, "gradients of one pass per task"))
+    # and against the measured price of 16-bit storage: the fp32 oracle with bf16 storage emulated, on the same fixture (CPU, ~5 s)
+    print("[train_wc/HIP vs emulation] " + wc_compare(errs, wc_emulation_errors(arrays, meta), "gradients of one pass per task"))
 
 
 def test_two_iterations_vs_well_conditioned_reference_golden():

@@ -280,24 +280,7 @@ def test_val_matcher_and_ap_match_reference_golden():
         assert np.allclose(np.asarray(v, np.float64), g[f"ap/{k}"].astype(np.float64), rtol=1e-9, atol=1e-12), k
 
 
-def _wc_pass(g, w, meta, ti, seeds, emulate=False):
-    """One task pass of the train_wc fixture through the oracle: (maps, items, scalar, grads, bn updates)."""
-    t, nc = meta["tasks"][ti], meta["nc"]
-    x = torch.from_numpy(synth.det_image(seeds[0] + ti, meta["bs"], meta["imgsz"]))
-    batch = {k: torch.from_numpy(v) for k, v in synth.make_batch(meta["bs"], meta["boxes_per_img"], nc[ti], seeds[1] + ti).items()}
-    wt = {k: (v.clone().requires_grad_(True) if oo.is_trainable(k) else v) for k, v in w.items()}
-    rnd = None
-    wf = wt
-    if emulate:  # 16-bit storage of activations and GEMM operands, as the HIP path keeps them
-        rnd = lambda y: y.to(torch.bfloat16).float()  # noqa: E731
-        wf = {k: (v.to(torch.bfloat16).float() if k.endswith(("conv.weight", ".2.weight")) and "dfl" not in k else v) for k, v in wt.items()}
-    upd = {}
-    feats = og.forward(g, wf, x, t, training=True, bn_updates=upd, act_round=rnd)
-    hyp = meta["hyp"]
-    scalar, items = ol.detection_loss(feats, batch, nc[ti], dict(box=hyp["box"][ti], cls=hyp["cls"][ti], dfl=hyp["dfl"][ti]))
-    scalar.backward()
-    grads = {k: v.grad for k, v in wt.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
-    return [f.detach() for f in feats], items.detach(), float(scalar), grads, upd
+from util import wc_pass as _wc_pass  # noqa: E402
 
 
 def test_train_wc_fixture_oracle_matches_reference_and_is_well_conditioned():
