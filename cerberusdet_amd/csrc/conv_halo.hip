@@ -735,6 +735,13 @@ static void dispatch_halo(const HaloArgs& a, int k, bool full, const HaloPlan& p
 
 }  // namespace cdet
 
+namespace cdet {
+// csrc/conv_pair.hip: 1x1 layers with an even number of 160-cout blocks -- two blocks share the staged pixel tile
+bool pair_plan_ok(const cdet_conv_desc* d);
+int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
+                float* stats, hipStream_t s);
+}  // namespace cdet
+
 using namespace cdet;
 
 #ifdef CDET_PROFILING
@@ -788,6 +795,11 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
                           "3x3: W <= 95 or H, W multiples of 16)");
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_tiled: the data gradient is a FWD call on the DGRAD operand of cdet_pack_weights_tiled");
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_tiled: residual ld/coff must be multiples of 8");
+    if (pl.nf == 5 && pl.ng == 2 && pair_plan_ok(d)) {
+        const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream);
+        CDET_LAUNCH_CHECK();
+        return rc;
+    }
     const int rb = pl.nf * 32;
     HaloArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_tiled; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;

@@ -136,3 +136,70 @@ def test_tiled_matches_generic_kernel_on_dominant_shape():
     ops.conv2d_tiled(src, ops.pack_weight_tiled(w, dtype)[0], b, k)
     torch.cuda.synchronize()
     _close(b.torch(), a.torch(), 2 ** -6, 2e-3)
+
+
+PAIR_CASES = [
+    # N, H, W, Cin, Cout, dtype: 1x1 layers with an even number of 160-cout blocks (csrc/conv_pair.hip: two blocks share the pixel tile)
+    (3, 17, 13, 96, 640, torch.bfloat16),    # M = 663: tiles straddle images, last tile mostly empty; two pairs
+    (1, 12, 12, 416, 320, torch.float16),    # fp16, 13 chunks, one pair
+    (2, 20, 20, 80, 320, torch.bfloat16),    # partial last chunk (Cin = 80)
+    (1, 40, 40, 1600, 600, torch.bfloat16),  # Cout not a multiple of 160 (4 blocks, the last one 120 wide), 50 chunks
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_pair_kernel_forward_epilogue_stats_and_data_gradient(case, monkeypatch):
+    """The shared-pixel-tile 1x1 kernel on small shapes (CDET_CONV_PAIR=2 takes it whenever the geometry allows; the library itself uses it
+    from 256 workgroups on), through the same entry point cdet_conv2d_tiled: raw output + BN partial sums, fused epilogue into a channel
+    slice, and the data gradient (a forward launch on the DGRAD operand) incl. the fan-in form -- against F.conv2d and against the
+    4-wave kernel of conv_halo.hip on the same operands."""
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    N, H, W, Ci, Co, dtype = case
+    g = torch.Generator().manual_seed(31)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype).requires_grad_(True)
+    w = _rt(torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci), dtype)
+    ref_raw = F.conv2d(x, w)
+    dy = _rt(torch.randn(ref_raw.shape, generator=g), dtype)
+    ref_raw.backward(dy)
+    ref_raw = ref_raw.detach()
+    xb = torch.full((N, H, W, Ci + 16), float("nan"), dtype=dtype, device=DEV)
+    xb[..., 8:8 + Ci] = x.detach().permute(0, 2, 3, 1).to(dtype).to(DEV)
+    src = ops.View(xb, 8, Ci)
+    wf, wd = ops.pack_weight_tiled(w.to(DEV), dtype, fwd=True, dgrad=True)
+    scale = torch.rand(Co, generator=g) + 0.5
+    bias = torch.randn(Co, generator=g) * 0.1
+    res = _rt(torch.randn(N, Co, H, W, generator=g), dtype)
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("CDET_CONV_PAIR", mode)
+        dst = ops.new_act(N, H, W, Co, dtype)
+        nblk = ops.conv_tiled_stat_blocks(src, dst, 1)
+        stats = torch.zeros(nblk * 2 * Co, device=DEV)
+        ops.conv2d_tiled(src, wf, dst, 1, stats=stats)
+        yb = torch.full((N, H, W, Co + 16), 7.0, dtype=dtype, device=DEV)
+        dsl = ops.View(yb, 8, Co)
+        ops.conv2d_tiled(src, wf, dsl, 1, scale=scale.to(DEV), bias=bias.to(DEV), act=L.ACT_SILU, res=ops.from_nchw(res.to(DEV), dtype))
+        torch.cuda.synchronize()
+        _close(dst.nchw(), ref_raw, 2 ** -7, 1e-3)
+        st = stats.view(nblk, 2, Co).sum(0).cpu()
+        _close(st[0], ref_raw.sum((0, 2, 3)), 1e-3, 1e-2)
+        _close(st[1], (ref_raw ** 2).sum((0, 2, 3)), 1e-3, 1e-2)
+        ref = F.silu(ref_raw * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)) + res
+        _close(dsl.nchw(), ref, 2 ** -7, 2e-2)
+        assert (yb[..., :8].float() == 7.0).all() and (yb[..., 8 + Co:].float() == 7.0).all()
+        outs[mode] = (dst.torch().clone(), stats.clone())
+    assert torch.equal(outs["2"][0], outs["0"][0])  # same products, same fp32 accumulation order per output: identical bits
+    # data gradient: rows = Cin (needs an even number of 160-row blocks to take the pair kernel; otherwise this is the 4-wave kernel)
+    monkeypatch.setenv("CDET_CONV_PAIR", "2")
+    dyv = ops.from_nchw(dy.to(DEV), dtype)
+    dx = ops.new_act(N, H, W, Ci, dtype)
+    ops.conv2d_tiled(dyv, wd, dx, 1)
+    prev = ops.from_nchw(_rt(torch.randn(N, Ci, H, W, generator=g), dtype).to(DEV), dtype)
+    out = ops.new_act(N, H, W, Ci, dtype)
+    ops.conv2d_tiled(dyv, wd, out, 1, res=prev)
+    torch.cuda.synchronize()
+    tol = float(x.grad.abs().max())
+    _close(dx.nchw(), x.grad, 2 ** -7, 2e-3 * tol)
+    _close(out.nchw(), x.grad + prev.nchw().float().cpu(), 2 ** -7, 4e-3 * tol)
