@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands: the same instruction stream at far lower switching power -- if the "
+                    "rate jumps, the kernel runs against the power / clock limit, not against its own stalls (MI355X_MICROARCH.md, DVFS)")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     dev = "cuda"
@@ -40,6 +42,9 @@ def main():
         w = torch.randn(co, ci, k, k, generator=g, device=dev) / math.sqrt(ci * k * k)
         scale = torch.rand(co, generator=g, device=dev) + 0.5
         bias = torch.randn(co, generator=g, device=dev) * 0.1
+        if a.zeros:
+            x.zero_()
+            w.zero_()
         src = ops.View(x)
         y0, y1 = ops.new_act(a.bs, H, W, co, dtype), ops.new_act(a.bs, H, W, co, dtype)
         wp = ops.pack_weight(w, dtype)
