@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands: the same instruction stream at far lower switching power -- if the "
                     "rate jumps, the kernel runs against the power / clock limit, not against its own stalls (MI355X_MICROARCH.md, DVFS)")
+    ap.add_argument("--shape", action="append", default=[], help="H,W,Cin,Cout,k (repeatable): custom shapes instead of the table")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     dev = "cuda"
@@ -37,7 +38,8 @@ def main():
     tot = {"generic": 0.0, "tiled": 0.0}
     totf = 0.0
     print(f"{'shape':28s} {'generic ms':>10s} {'TF/s':>7s} {'tiled ms':>10s} {'TF/s':>7s} {'speedup':>8s}")
-    for H, W, ci, co, k, n in (SHAPES if a.only < 0 else [SHAPES[a.only]]):
+    shapes = [tuple(int(v) for v in t.split(",")) + (1,) for t in a.shape] or (SHAPES if a.only < 0 else [SHAPES[a.only]])
+    for H, W, ci, co, k, n in shapes:
         x = torch.randn(a.bs, H, W, ci, generator=g, device=dev).to(dtype)
         w = torch.randn(co, ci, k, k, generator=g, device=dev) / math.sqrt(ci * k * k)
         scale = torch.rand(co, generator=g, device=dev) + 0.5
