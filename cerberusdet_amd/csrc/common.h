@@ -103,6 +103,9 @@ static inline int tune_env(const char* name, int dflt) {
 // 1x1 layers (conv_wgrad_halo.hip, wgrad_gemm_kernel): same plan struct, slab rows of n_iblk * 288 floats
 bool wgrad_gemm_plan(const cdet_conv_desc* d, WgradHaloPlan* out);
 int wgrad_gemm_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s);
+// stride-2 3x3 layers (conv_wgrad_s2.hip): same plan struct and slab layout as the stride-1 form
+bool wgrad_s2_plan(const cdet_conv_desc* d, WgradHaloPlan* out);
+int wgrad_s2_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s);
 static inline int elem_size(int dtype) { return dtype == CDET_F32 ? 4 : (dtype == CDET_U8 ? 1 : 2); }
 
 }  // namespace cdet

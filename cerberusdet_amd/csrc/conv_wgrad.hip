@@ -644,7 +644,7 @@ using namespace cdet;
 extern "C" int64_t cdet_conv2d_wgrad_ws_elems(const cdet_conv_desc* d) {
     if (!d) return -1;
     WgradHaloPlan hp;
-    if (wgrad_halo_plan(d, &hp) || wgrad_gemm_plan(d, &hp)) return (int64_t)hp.S * hp.Cd_pad * hp.Kp;
+    if (wgrad_halo_plan(d, &hp) || wgrad_gemm_plan(d, &hp) || wgrad_s2_plan(d, &hp)) return (int64_t)hp.S * hp.Cd_pad * hp.Kp;
     const WgradPlan p = plan_wgrad(d);
     return (int64_t)p.S * p.Cd_pad * p.Kp;
 }
@@ -659,8 +659,10 @@ extern "C" int cdet_conv2d_wgrad(const cdet_conv_desc* d, const void* x, const v
     WgradHaloPlan hp;
     bool halo = wgrad_halo_plan(d, &hp);
     const bool gemm = !halo && wgrad_gemm_plan(d, &hp);
-    if (halo || gemm) {  // stride-1 3x3 / 1x1: transpose-read kernels of conv_wgrad_halo.hip, same slab layout / reduction as below
-        const int e = gemm ? wgrad_gemm_launch(d, hp, x, dy, ws, (hipStream_t)stream) : wgrad_halo_launch(d, hp, x, dy, ws, (hipStream_t)stream);
+    const bool s2 = !halo && !gemm && wgrad_s2_plan(d, &hp);
+    if (halo || gemm || s2) {  // stride-1 3x3 / 1x1 / stride-2 3x3: transpose-read kernels (conv_wgrad_halo.hip, conv_wgrad_s2.hip), same slab layout / reduction as below
+        const int e = s2 ? wgrad_s2_launch(d, hp, x, dy, ws, (hipStream_t)stream)
+                         : (gemm ? wgrad_gemm_launch(d, hp, x, dy, ws, (hipStream_t)stream) : wgrad_halo_launch(d, hp, x, dy, ws, (hipStream_t)stream));
         if (e) return e;
         halo = true;
         p.S = hp.S;

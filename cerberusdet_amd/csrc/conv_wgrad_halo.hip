@@ -26,8 +26,7 @@
 // Output: partial slab ws[layer][split][co][tap*Cs + ci] (fp32) -- the layout wgrad_reduce_kernel<3,3> of conv_wgrad.hip reduces.
 // wgrad_gemm_kernel further down is the 1x1 form of the same machinery.
 #include "common.h"
-
-#include <utility>
+#include "wgrad_tr.h"
 
 namespace cdet {
 
@@ -50,49 +49,9 @@ struct WHArgs {
 constexpr int WH_P = 128;            // pixels per stage
 constexpr int WH_DYB = 40 * 1024;    // dY bytes per stage: 8 pixel blocks of 16 x 5 cout pairs, 1 KiB each
 constexpr int WH_ZERO = 4608;        // zero region: 512 lane bytes + the largest X immediate (114 rows of 32 B)
-constexpr unsigned WH_SENT = 0xE0000000u;
 #ifndef WH_ABL  // profiling builds only (make EXTRA="-DWH_ABL=n"): 1 no DMA in the loop, 2 no stage barrier, 4 no MFMA, 8 no A reads, 16 no B reads
 #define WH_ABL 0
 #endif
-
-template <int... I, class F>
-__device__ __forceinline__ void wh_static_for(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-
-template <int OFF>
-__device__ __forceinline__ u32x2 wh_tr(int addr) {  // asynchronous: the result is valid after wh_wait<>() on it
-    u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
-// the waits take the registers they make valid as in/out operands: every use the compiler schedules comes after the wait
-template <int N>
-__device__ __forceinline__ void wh_wait(u32x2& a, u32x2& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void wh_wait_b(u32x2 (&lo)[5], u32x2 (&hi)[5], u32x2& a, u32x2& b) {
-    asm volatile("s_waitcnt lgkmcnt(%12)"
-                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]),
-                   "+v"(hi[4]), "+v"(a), "+v"(b)
-                 : "n"(N));
-}
-__device__ __forceinline__ int wh_sel(uint64_t m, int a_valid, int a_zero) {
-    int r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a_zero), "v"(a_valid), "s"(m));
-    return r;
-}
-
-template <int DT>
-__device__ __forceinline__ void wh_mfma(const u32x4& a, const u32x4& b, f32x4& c) {
-    if (DT == CDET_BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-
-__device__ __forceinline__ void wh_dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
-}
 
 // NARROW (Cout <= 96, NCI = 2): the tile is 80 couts x 32 cins; the factor two the cout halves would take goes to the pixels -- four
 // groups of two waves, each reducing 32 of the stage's 128 pixels, summed through LDS in two levels at the end.

@@ -460,30 +460,32 @@ __global__ __launch_bounds__(256) void pool5_kernel(uint16_t* __restrict__ buf, 
 }
 
 // backward of one pool stage: din[q] += sum over windows p containing q of dout[p] * [argmax_p == q], argmax_p = first
-// maximum of window p in (ky, kx) scan order, recomputed from the saved forward input slice. One block owns a 16x16 pixel
-// tile of one image for one 8-channel vector. The 24x24 input halo is decoded once into LDS (-inf outside the image, so the
-// scans need no bounds checks); the argmax is found separably (row pass: first kx per input row, column pass: first ky whose
+// maximum of window p in (ky, kx) scan order, recomputed from the saved forward input slice. One block owns a T x T pixel
+// tile of one image for one 8-channel vector (T = 20 when the whole map fits one tile -- the 20x20 level of a 640 input: four
+// 16-tiles would decode 2.9x the pixels -- else 16). The (T+8)^2 input halo is decoded once into LDS (-inf outside the image, so
+// the scans need no bounds checks); the argmax is found separably (row pass: first kx per input row, column pass: first ky whose
 // row maximum is the window maximum -- identical to the row-major scan); phase 3 gathers per pixel in fixed (wy, wx) order,
 // so the result is deterministic.
-template <int DT>
+template <int DT, int T>
 __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restrict__ buf, uint16_t* __restrict__ dbuf, int ld, int coff_in,
                                                         int coff_out, int N, int H, int W, int CV, int tiles_x, int tiles_y) {
-    __shared__ float s_in[24 * 24][8];
-    __shared__ float s_rmax[24 * 20][8];
-    __shared__ unsigned long long s_rarg[24 * 20];
-    __shared__ u32x4 s_g[20 * 20];
-    __shared__ unsigned long long s_idx[20 * 20];
+    constexpr int TI = T + 8, TW = T + 4;  // input halo / window-centre extent
+    __shared__ float s_in[TI * TI][8];
+    __shared__ float s_rmax[TI * TW][8];
+    __shared__ unsigned s_rarg[TI * TW];  // first kx of the row maximum, 4 bits per channel
+    __shared__ u32x4 s_g[TW * TW];
+    __shared__ unsigned long long s_idx[TW * TW];
     int b = blockIdx.x;
     const int c = (b % CV) * 8;
     b /= CV;
-    const int x0 = (b % tiles_x) * 16;
+    const int x0 = (b % tiles_x) * T;
     b /= tiles_x;
-    const int y0 = (b % tiles_y) * 16;
+    const int y0 = (b % tiles_y) * T;
     const int n = b / tiles_y;
     const int tid = threadIdx.x;
     const int64_t img = (int64_t)n * H * W;
-    for (int i = tid; i < 24 * 24; i += 256) {
-        const int yy = y0 - 4 + i / 24, xx = x0 - 4 + i % 24;
+    for (int i = tid; i < TI * TI; i += 256) {
+        const int yy = y0 - 4 + i / TI, xx = x0 - 4 + i % TI;
         Vec8 v;
 #pragma unroll
         for (int k = 0; k < 8; ++k) v.v[k] = -INFINITY;
@@ -491,26 +493,26 @@ __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restri
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_in[i][k] = v.v[k];
     }
-    for (int i = tid; i < 20 * 20; i += 256) {
-        const int py = y0 - 2 + i / 20, px = x0 - 2 + i % 20;
+    for (int i = tid; i < TW * TW; i += 256) {
+        const int py = y0 - 2 + i / TW, px = x0 - 2 + i % TW;
         u32x4 v = {0u, 0u, 0u, 0u};
         if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W)
             v = *reinterpret_cast<const u32x4*>(dbuf + (img + (int64_t)py * W + px) * ld + coff_out + c);
         s_g[i] = v;
     }
     __syncthreads();
-    for (int i = tid; i < 24 * 20; i += 256) {  // row pass: input row r, window column wx -> max / first kx over the 5 columns
-        const int r = i / 20, wx = i % 20;
+    for (int i = tid; i < TI * TW; i += 256) {  // row pass: input row r, window column wx -> max / first kx over the 5 columns
+        const int r = i / TW, wx = i % TW;
         float best[8];
         unsigned arg[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             best[k] = -INFINITY;
-            arg[k] = 255u;
+            arg[k] = 15u;
         }
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
-            const float* e = s_in[r * 24 + wx + kx];
+            const float* e = s_in[r * TI + wx + kx];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (e[k] > best[k]) {
@@ -518,17 +520,17 @@ __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restri
                     arg[k] = (unsigned)kx;
                 }
         }
-        unsigned long long packed = 0;
+        unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             s_rmax[i][k] = best[k];
-            packed |= (unsigned long long)arg[k] << (8 * k);
+            packed |= arg[k] << (4 * k);
         }
         s_rarg[i] = packed;
     }
     __syncthreads();
-    for (int i = tid; i < 20 * 20; i += 256) {  // column pass
-        const int wy = i / 20, wx = i % 20;
+    for (int i = tid; i < TW * TW; i += 256) {  // column pass
+        const int wy = i / TW, wx = i % TW;
         const int py = y0 - 2 + wy, px = x0 - 2 + wx;
         unsigned long long packed = ~0ull;  // windows centred outside the image never match
         if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
@@ -541,14 +543,14 @@ __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restri
             }
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) {
-                const int ri = (wy + ky) * 20 + wx;
+                const int ri = (wy + ky) * TW + wx;
                 const float* e = s_rmax[ri];
-                const unsigned long long ra = s_rarg[ri];
+                const unsigned ra = s_rarg[ri];
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (e[k] > best[k]) {
                         best[k] = e[k];
-                        arg[k] = (unsigned)(ky * 5) + ((unsigned)(ra >> (8 * k)) & 0xffu);
+                        arg[k] = (unsigned)(ky * 5) + ((ra >> (4 * k)) & 0xfu);
                     }
             }
             packed = 0;
@@ -558,27 +560,29 @@ __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restri
         s_idx[i] = packed;
     }
     __syncthreads();
-    const int qy = tid >> 4, qx = tid & 15;
-    const int y = y0 + qy, x = x0 + qx;
-    if (y >= H || x >= W) return;
-    uint16_t* dq = dbuf + (img + (int64_t)y * W + x) * ld + coff_in + c;
-    Vec8 acc = load8<DT>(dq);
+    for (int i = tid; i < T * T; i += 256) {
+        const int qy = i / T, qx = i % T;
+        const int y = y0 + qy, x = x0 + qx;
+        if (y >= H || x >= W) continue;
+        uint16_t* dq = dbuf + (img + (int64_t)y * W + x) * ld + coff_in + c;
+        Vec8 acc = load8<DT>(dq);
 #pragma unroll
-    for (int wy = 0; wy < 5; ++wy)
+        for (int wy = 0; wy < 5; ++wy)
 #pragma unroll
-        for (int wx = 0; wx < 5; ++wx) {
-            // window centre p = q + (wy-2, wx-2); q sits at (4-wy, 4-wx) inside it
-            const int wi = (qy + wy) * 20 + qx + wx;
-            const unsigned long long idx = s_idx[wi];
-            const unsigned long long want = 0x0101010101010101ull * (unsigned long long)((4 - wy) * 5 + (4 - wx));
-            const unsigned long long diff = idx ^ want;
-            if (!((diff - 0x0101010101010101ull) & ~diff & 0x8080808080808080ull)) continue;  // no zero byte -> no channel matches
-            const Vec8 g = load8<DT>(reinterpret_cast<const uint16_t*>(&s_g[wi]));
+            for (int wx = 0; wx < 5; ++wx) {
+                // window centre p = q + (wy-2, wx-2); q sits at (4-wy, 4-wx) inside it
+                const int wi = (qy + wy) * TW + qx + wx;
+                const unsigned long long idx = s_idx[wi];
+                const unsigned long long want = 0x0101010101010101ull * (unsigned long long)((4 - wy) * 5 + (4 - wx));
+                const unsigned long long diff = idx ^ want;
+                if (!((diff - 0x0101010101010101ull) & ~diff & 0x8080808080808080ull)) continue;  // no zero byte -> no channel matches
+                const Vec8 g = load8<DT>(reinterpret_cast<const uint16_t*>(&s_g[wi]));
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((((unsigned)(diff >> (8 * k))) & 0xffu) == 0u) acc.v[k] += g.v[k];
-        }
-    store8<DT>(dq, acc);
+                for (int k = 0; k < 8; ++k)
+                    if ((((unsigned)(diff >> (8 * k))) & 0xffu) == 0u) acc.v[k] += g.v[k];
+            }
+        store8<DT>(dq, acc);
+    }
 }
 
 
@@ -808,12 +812,19 @@ extern "C" int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, in
 extern "C" int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C,
                                   int32_t dtype, void* stream) {
     if (int e = check16("cdet_sppf_pool_bwd", dtype, C, ld, coff, 0, 0)) return e;
-    const int CV = C / 8, tx = div_up(W, 16), ty = div_up(H, 16);
+    const bool t20 = H > 16 && H <= 20 && W > 16 && W <= 20;  // the whole map as one tile
+    const int T = t20 ? 20 : 16;
+    const int CV = C / 8, tx = div_up(W, T), ty = div_up(H, T);
     CDET_CHECK_ARG((int64_t)N * ty * tx * CV < (1ll << 31), "cdet_sppf_pool_bwd: grid too large");
     for (int i = 2; i >= 0; --i) {
-        DISPATCH16(dtype, hipLaunchKernelGGL((pool5_bwd_kernel<DT>), dim3((unsigned)((int64_t)N * ty * tx * CV)), dim3(256), 0,
-                                             (hipStream_t)stream, (const uint16_t*)buf, (uint16_t*)dbuf, ld, coff + i * C, coff + (i + 1) * C, N, H,
-                                             W, CV, tx, ty));
+        const dim3 grid((unsigned)((int64_t)N * ty * tx * CV));
+        if (t20) {
+            DISPATCH16(dtype, hipLaunchKernelGGL((pool5_bwd_kernel<DT, 20>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)buf,
+                                                 (uint16_t*)dbuf, ld, coff + i * C, coff + (i + 1) * C, N, H, W, CV, tx, ty));
+        } else {
+            DISPATCH16(dtype, hipLaunchKernelGGL((pool5_bwd_kernel<DT, 16>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)buf,
+                                                 (uint16_t*)dbuf, ld, coff + i * C, coff + (i + 1) * C, N, H, W, CV, tx, ty));
+        }
         CDET_LAUNCH_CHECK();
     }
     return 0;

@@ -117,3 +117,55 @@ def test_s2_data_gradient_four_parity_classes(case):
     ops.conv2d(dyv, ops.pack_weight(w.to(DEV), dtype, transpose=True), alt, 3, 2, mode=L.CONV_DGRAD)
     torch.cuda.synchronize()
     _close(dx.torch(), alt.torch(), 2 ** -6, 2e-3 * tol)
+
+
+WGRAD_CASES = [
+    # N, H, W (input), Cin, Cout, dtype: all taken by csrc/conv_wgrad_s2.hip (patches of 8 x 16 outputs at least 75 % full)
+    (2, 32, 64, 64, 160, torch.bfloat16),     # output 16 x 32: full patches, two cin tiles, one cout block
+    (1, 80, 80, 80, 320, torch.bfloat16),     # output 40 x 40: ragged patch columns (40 = 2.5 x 16), half-empty last cin tile, 2 cout blocks
+    (3, 48, 32, 32, 200, torch.bfloat16),     # output 24 x 16, Cout not a multiple of 160
+    (2, 28, 60, 96, 128, torch.float16),      # output 14 x 30: ragged rows and columns, fp16
+    (1, 160, 160, 32, 160, torch.bfloat16),   # output 80 x 80: many patches per split
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_s2_weight_gradient_parity_planes(case, monkeypatch):
+    """dW of the stride-2 3x3 convolution (autograd's convolution_backward(weight) of models/common.py:57 with s = 2) against fp32 autograd
+    on the same 16-bit-rounded operands (1e-3 of the tensor scale), against the round-1 im2col kernel (1e-4), and the accumulate form."""
+    from cerberusdet_amd import _lib as L
+    from cerberusdet_amd import ops
+    import ctypes as C
+
+    N, H, W, Ci, Co, dtype = case
+    g = torch.Generator().manual_seed(33)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype)
+    Ho, Wo = H // 2, W // 2
+    dy = _rt(torch.randn(N, Co, Ho, Wo, generator=g), dtype)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, 2, 1).backward(dy)
+    want = w.grad
+    xb = torch.full((N, H, W, Ci + 16), float("nan"), dtype=dtype, device=DEV)  # the slice's neighbours are NaN: never read
+    xb[..., 8:8 + Ci] = x.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    src = ops.View(xb, 8, Ci)
+    Cp = (Co + 7) // 8 * 8
+    dyb = torch.zeros((N, Ho, Wo, Cp + 8), dtype=dtype, device=DEV)
+    dyb[..., 8:8 + Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    dyv = ops.View(dyb, 8, Cp)
+    d = ops.conv_desc(src, dyv, 3, 2)
+    d.Cd = Co
+    lib = L.load()
+    monkeypatch.setenv("CDET_WGRAD_S2", "0")
+    n_old = lib.cdet_conv2d_wgrad_ws_elems(C.byref(d))
+    old = ops.conv2d_wgrad(src, dyv, torch.empty(Co, Ci, 3, 3, device=DEV), 3, 2)
+    monkeypatch.delenv("CDET_WGRAD_S2")
+    n_new = lib.cdet_conv2d_wgrad_ws_elems(C.byref(d))
+    assert n_new != n_old or Co * Ci < 160 * 32, "the case must be taken by the parity-plane kernel (different slab plan)"
+    base = torch.randn(Co, Ci, 3, 3, generator=g).to(DEV)
+    got = ops.conv2d_wgrad(src, dyv, torch.empty(Co, Ci, 3, 3, device=DEV), 3, 2)
+    acc = ops.conv2d_wgrad(src, dyv, base.clone(), 3, 2, accumulate=True)
+    torch.cuda.synchronize()
+    sc = float(want.abs().max())
+    _close(got, want, 0, 1e-3 * sc)
+    _close(got, old, 0, 1e-4 * sc)
+    _close(acc, base.cpu() + want, 0, 1e-3 * sc)

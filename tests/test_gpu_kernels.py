@@ -366,14 +366,23 @@ def test_upsample_copy_pool():
     ops.upsample2_bwd(dbuf.slice(0, C), dx)
     torch.cuda.synchronize()
     _close(dx.nchw(), x.grad, 2 ** -7, 1e-2)
-    # SPPF pool chain fwd + bwd
-    C2 = 24
-    xs = _rt(torch.randn(N, C2, 9, 11, generator=g), dtype).requires_grad_(True)
+
+
+@pytest.mark.parametrize("hw", [(9, 11), (20, 20), (19, 17), (8, 8), (40, 40)])
+def test_sppf_pool_chain_forward_backward(hw):
+    """reference SPPF (models/common.py:230-245): three chained 5x5 max pools, their autograd routing to the first maximum.
+    (20, 20) and (19, 17) take the one-tile form of the backward kernel, the others the 16x16 tiles."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    N, C2 = 2, 24
+    Hm, Wm = hw
+    xs = _rt(torch.randn(N, C2, Hm, Wm, generator=g), dtype).requires_grad_(True)
     y1 = F.max_pool2d(xs, 5, 1, 2)
     y2 = F.max_pool2d(y1, 5, 1, 2)
     y3 = F.max_pool2d(y2, 5, 1, 2)
     catp = torch.cat((xs, y1, y2, y3), 1)
-    pb = ops.new_act(N, 9, 11, 4 * C2, dtype, zero=True)
+    pb = ops.new_act(N, Hm, Wm, 4 * C2, dtype, zero=True)
     ops.copy_channels(ops.from_nchw(xs.detach().to(DEV), dtype), pb.slice(0, C2))
     ops.sppf_pool(pb, C2)
     torch.cuda.synchronize()
@@ -383,7 +392,8 @@ def test_upsample_copy_pool():
     dpb = ops.from_nchw(dcp.to(DEV), dtype)
     ops.sppf_pool_bwd(pb, dpb, C2)
     torch.cuda.synchronize()
-    _close(dpb.slice(0, C2).nchw(), xs.grad, 2 ** -6, 3e-2)
+    # the three stages accumulate into the 16-bit gradient buffer: one rounding of the running sum (2^-9 of ITS size) per stage
+    _close(dpb.slice(0, C2).nchw(), xs.grad, 2 ** -6, 2 ** -7 * float(xs.grad.abs().max()))
 
 
 def test_detect_decode_matches_oracle():
