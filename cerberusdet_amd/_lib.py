@@ -103,6 +103,8 @@ _SIGS = {
     "cdet_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "cdet_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32,
                                      i64, i32, i32, i64, vp]),
+    "cdet_bn_silu_bwd_apply_add": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32,
+                                         i64, i32, i32, i64, vp, i32, i32, vp]),
     "cdet_bn_bwd_sums": (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
     "cdet_copy_channels": (i32, [vp, i32, i32, vp, i32, i32, i64, i32, i32, i32, vp]),
     "cdet_colsum": (i32, [vp, i32, i32, i64, i32, i32, i32, vp, i32, vp, vp]),

@@ -295,13 +295,17 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_sums_kernel(const float
 }
 
 // pass 2b: dz = gamma*invstd*(dact - mean(dact) - xhat*mean(dact*xhat))
-template <int DT>
+// ALSO: the same pass adds dy into a second gradient slice, also[r][c] += dy[r][c] -- the shortcut addend of a Bottleneck
+// (x + cv2(cv1(x)), models/common.py:107-117): the gradient of the sum goes to both addends, and cv2's backward is the pass that
+// has it in registers (a separate add kernel re-read it: 3 tensor passes instead of 2).
+template <int DT, bool ALSO>
 __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ dy, int dy_ld, int dy_coff,
                                                                 const uint16_t* __restrict__ z, int z_ld, int z_coff,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ sums, float inv_count,
-                                                                uint16_t* __restrict__ dz, int dz_ld, int dz_coff, int64_t M, int C, int CV, int rev) {
+                                                                uint16_t* __restrict__ dz, int dz_ld, int dz_coff, int64_t M, int C, int CV, int rev,
+                                                                uint16_t* __restrict__ also, int also_ld, int also_coff) {
     const ColMap cm = col_map(CV);
     if (!cm.active) return;
     const int c = cm.cv * 8;
@@ -322,6 +326,17 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
             g[u] = load8<DT>(dy + R(r + u * step) * dy_ld + dy_coff + c);
             x[u] = load8<DT>(z + R(r + u * step) * z_ld + z_coff + c);
         }
+        if (ALSO) {
+            Vec8 s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] = load8<DT>(also + R(r + u * step) * also_ld + also_coff + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[u].v[i] += g[u].v[i];
+                store8<DT>(also + R(r + u * step) * also_ld + also_coff + c, s[u]);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             Vec8 o;
@@ -337,6 +352,12 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
     for (; r < M; r += step) {
         const Vec8 g = load8<DT>(dy + R(r) * dy_ld + dy_coff + c);
         const Vec8 x = load8<DT>(z + R(r) * z_ld + z_coff + c);
+        if (ALSO) {
+            Vec8 s = load8<DT>(also + R(r) * also_ld + also_coff + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s.v[i] += g.v[i];
+            store8<DT>(also + R(r) * also_ld + also_coff + c, s);
+        }
         Vec8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -733,12 +754,13 @@ extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy
     return 0;
 }
 
-extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
-                                      const float* mean, const float* invstd, const float* gamma, const float* beta, const float* part,
-                                      int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate, void* dz, int32_t dz_ld, int32_t dz_coff,
-                                      int64_t M, int32_t C, int32_t dtype, int64_t count, void* stream) {
-    if (int e = check16("cdet_bn_silu_bwd_apply", dtype, C, dy_ld, dy_coff, z_ld, z_coff)) return e;
-    CDET_CHECK_ARG(dz_ld % 8 == 0 && dz_coff % 8 == 0 && part && nblk >= 0, "cdet_bn_silu_bwd_apply: bad arguments");
+static int bn_silu_bwd_apply_impl(const char* fn, const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                  const float* mean, const float* invstd, const float* gamma, const float* beta, const float* part, int32_t nblk,
+                                  float* dgamma, float* dbeta, int32_t accumulate, void* dz, int32_t dz_ld, int32_t dz_coff, int64_t M, int32_t C,
+                                  int32_t dtype, int64_t count, void* also, int32_t also_ld, int32_t also_coff, void* stream) {
+    if (int e = check16(fn, dtype, C, dy_ld, dy_coff, z_ld, z_coff)) return e;
+    CDET_CHECK_ARG(dz_ld % 8 == 0 && dz_coff % 8 == 0 && part && nblk >= 0, "%s: bad arguments", fn);
+    CDET_CHECK_ARG(also_ld % 8 == 0 && also_coff % 8 == 0, "%s: the second gradient slice needs ld / coff in multiples of 8", fn);
     // nblk > 0: reduce the partials first, the sums live behind them: part[nblk*2*C .. nblk*2*C + 2*C)
     // nblk == 0 (SyncBatchNorm): `part` already holds the (all-reduced) sums [2C]; dgamma/dbeta were produced by cdet_bn_bwd_sums
     float* sums = const_cast<float*>(part) + (int64_t)nblk * 2 * C;
@@ -749,11 +771,35 @@ extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_
     const int64_t cnt = count > 0 ? count : M;
     const int CV = C / 8, rpp = 256 / CV;
     const int grid = grid_for(M, rpp * 8);
-    DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, dy_ld,
-                                         dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
-                                         (uint16_t*)dz, dz_ld, dz_coff, M, C, CV, (bn_rev() >> 1) & 1));
+    if (also) {
+        DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy,
+                                             dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
+                                             (uint16_t*)dz, dz_ld, dz_coff, M, C, CV, (bn_rev() >> 1) & 1, (uint16_t*)also, also_ld, also_coff));
+    } else {
+        DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy,
+                                             dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
+                                             (uint16_t*)dz, dz_ld, dz_coff, M, C, CV, (bn_rev() >> 1) & 1, (uint16_t*)nullptr, 0, 0));
+    }
     CDET_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta, const float* part,
+                                      int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate, void* dz, int32_t dz_ld, int32_t dz_coff,
+                                      int64_t M, int32_t C, int32_t dtype, int64_t count, void* stream) {
+    return bn_silu_bwd_apply_impl("cdet_bn_silu_bwd_apply", dy, dy_ld, dy_coff, z, z_ld, z_coff, mean, invstd, gamma, beta, part, nblk, dgamma, dbeta,
+                                  accumulate, dz, dz_ld, dz_coff, M, C, dtype, count, nullptr, 0, 0, stream);
+}
+
+extern "C" int cdet_bn_silu_bwd_apply_add(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta, const float* part,
+                                          int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate, void* dz, int32_t dz_ld, int32_t dz_coff,
+                                          int64_t M, int32_t C, int32_t dtype, int64_t count, void* also, int32_t also_ld, int32_t also_coff,
+                                          void* stream) {
+    CDET_CHECK_ARG(also, "cdet_bn_silu_bwd_apply_add: null pointer");
+    return bn_silu_bwd_apply_impl("cdet_bn_silu_bwd_apply_add", dy, dy_ld, dy_coff, z, z_ld, z_coff, mean, invstd, gamma, beta, part, nblk, dgamma,
+                                  dbeta, accumulate, dz, dz_ld, dz_coff, M, C, dtype, count, also, also_ld, also_coff, stream);
 }
 
 extern "C" int cdet_copy_channels(const void* src, int32_t src_ld, int32_t src_coff, void* dst, int32_t dst_ld, int32_t dst_coff, int64_t M,

@@ -233,6 +233,14 @@ int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* part, int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate,
                            void* dz, int32_t dz_ld, int32_t dz_coff, int64_t M, int32_t C, int32_t dtype, int64_t count, void* stream);
+/* The same pass with the Bottleneck shortcut folded in (models/common.py:107-117, x + cv2(cv1(x))): dy is the gradient of the sum, so
+ * besides dz the pass accumulates it into the shortcut addend's gradient slice: also[r][c] += dy[r][c] (also: [M, C] 16-bit with strides;
+ * replaces a separate cdet_add_channels over the same tensors). */
+int cdet_bn_silu_bwd_apply_add(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               const float* part, int32_t nblk, float* dgamma, float* dbeta, int32_t accumulate,
+                               void* dz, int32_t dz_ld, int32_t dz_coff, int64_t M, int32_t C, int32_t dtype, int64_t count,
+                               void* also, int32_t also_ld, int32_t also_coff, void* stream);
 /* SyncBatchNorm support (train.py:140-143 of the reference): reduce [nblk][2][C] partials (conv statistics or the backward
  * partials) to sums[2C] so that the host can all-reduce them between kernels; then cdet_bn_finalize(sums, nblk = 1, count =
  * global count) / cdet_bn_silu_bwd_apply(part = sums, nblk = 0, count = global count). `count` <= 0 means M. */

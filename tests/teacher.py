@@ -102,6 +102,8 @@ def _snap(rec, plan):
         if rec["gx"] is not None and rec["gx_acc"]:
             s["gx"] = rec["gx"].torch().clone()
         s["gw"], s["gb"] = m.bn.weight.grad.clone(), m.bn.bias.grad.clone()
+        if rec.get("also") is not None:
+            s["also"] = rec["also"].torch().clone()
         if not rec["grouped"]:
             s["cw"] = m.conv.weight.grad.clone()
     elif kind == "bias":
@@ -109,8 +111,6 @@ def _snap(rec, plan):
         if rec["gx_acc"]:
             s["gx"] = rec["gx"].torch().clone()
         s["cw"], s["cb"] = m.weight.grad.clone(), m.bias.grad.clone()
-    elif kind == "add":
-        s["gs"] = rec["gs"].torch().clone()
     elif kind in ("up", "copy"):
         if rec["acc"]:
             s["gs"] = rec["gs"].torch().clone()
@@ -141,6 +141,8 @@ def _check_bwd(rec, s, plan, rep, tol16, stash):
         rep.add("conv", "dz", rec, dz_e, dz_ref, tol16, name)
         rep.add("conv", "dgamma", rec, bn.weight.grad - s["gw"], dg_ref, 2e-3, name)
         rep.add("conv", "dbeta", rec, bn.bias.grad - s["gb"], db_ref, 2e-3, name)
+        if rec.get("also") is not None:  # Bottleneck shortcut: the same pass adds grad(y) into the other addend's gradient slice
+            rep.add("conv", "shortcut", rec, _f(rec["also"]), s["also"].float() + gy, tol16, name)
         w = _w_rounded(m.conv.weight, plan.dtype)
         if rec["gx"] is not None:
             ref = R.conv_dgrad(dz_e, w, m.s, x.H, x.W)
@@ -163,8 +165,6 @@ def _check_bwd(rec, s, plan, rep, tol16, stash):
         rep.add("bias", "gx+" if rec["gx_acc"] else "gx", rec, _f(rec["gx"]), ref, tol16, f"{x.C}->{O}")
         rep.add("bias", "dw", rec, m.weight.grad - s["cw"], R.conv_wgrad(_f(x), d, 1, 1), 1e-3, f"{x.C}->{O}")
         rep.add("bias", "db", rec, m.bias.grad - s["cb"], d.sum((0, 1, 2)), 1e-3, f"{x.C}->{O}")
-    elif kind == "add":
-        rep.add("add", "gs", rec, _f(rec["gs"]), s["gs"].float() + _f(rec["gd"]), tol16)
     elif kind == "up":
         gd = _f(rec["gd"])
         N, H2, W2, Cn = gd.shape
