@@ -23,6 +23,8 @@
 
 #include "halo_common.h"
 
+#include <type_traits>
+
 namespace cdet {
 
 struct HaloArgs {
@@ -46,6 +48,7 @@ struct HaloArgs {
     int wts, wt0;  // weight tile of K step `step` = tile step * wts + wt0 of the packed operand (1, 0: the operand's own order; 9, 4: the centre
                    // tap of a 9-tap operand -- the (0, 0) parity class of a stride-2 data gradient, conv_vt.hip)
     int Hd, Wd, cp, cq;  // OMAP: tile pixel (n, y, x) is written to pixel (2y + cp, 2x + cq) of an Hd x Wd destination
+    int halfk;  // 3x3 only: the last 32-channel chunk holds at most 16 channels (Cs = 80): its second k16 half is all zeros and is skipped
 };
 
 constexpr int HEPI_STAGE_OFF = 6912;  // epilogue LDS map (after HZERO): statistics scratch [4][2][HC] fp32, scale/bias [2][HC] fp32, then the store staging
@@ -290,7 +293,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     // One K step. `u` is the step's position inside the unrolled group (3x3: the tap, 9 per chunk; 1x1: 3 chunks per group), a
     // compile-time constant after unrolling, so the tap offsets, the ring stage (NSW == 3) and the pixel-piece schedule fold away;
     // `chunk` is the step's channel chunk, `st` its index.
-    auto step = [&](int st, int chunk, int u) {
+    auto step = [&](int st, int chunk, int u, auto HK) {
+        constexpr bool halfk = decltype(HK)::value;  // the step's second k16 half holds zero channels only: no reads, no MFMAs for it
         const int sc = NSW == 3 ? u % 3 : (st & 1);           // ring stage of this step's tile (compile-time for NSW == 3)
         const int sn = NSW == 3 ? (u + 1) % 3 : ((st + 1) & 1);
         const unsigned char* ws = wbase + sc * WTILE;
@@ -307,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             if (!(ABL & 4)) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
             // two fragment reads per MFMA slot: they are all in flight after the first half of the phase, so the lgkmcnt(0) at its
             // end waits for LDS latency that the second half has already covered (one read per slot left ~140 clocks per step exposed)
-            if (2 * i < NR) frag(ws, bo_cur, 1, 2 * i, a1, b1);
-            if (2 * i + 1 < NR) frag(ws, bo_cur, 1, 2 * i + 1, a1, b1);
+            if (!halfk && 2 * i < NR) frag(ws, bo_cur, 1, 2 * i, a1, b1);
+            if (!halfk && 2 * i + 1 < NR) frag(ws, bo_cur, 1, 2 * i + 1, a1, b1);
             if (i == NM - 1) b_offsets(HZERO + xbn * XHB, tapn, bo_nxt);
             if (!(ABL & 1)) {
                 if (NT == 9) {
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         //      (st+1, k16 #0) in their shadow
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (!(ABL & 4)) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+            if (!(ABL & 4) && !halfk) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
             if (!(ABL & 1)) {
                 if (i == 0) dma_w1(st + NSW, sc, 0);
                 if (i == (NM >= 10 ? 3 : (NM >= 6 ? 2 : 1))) dma_w1(st + NSW, sc, 1);
@@ -369,15 +373,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 
     if (ABL & 16) {
     } else if (NT == 9) {
-        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        const int nfull = a.halfk ? a.nchunk - 1 : a.nchunk;
+        for (int chunk = 0; chunk < nfull; ++chunk) {
 #pragma unroll
-            for (int u = 0; u < 9; ++u) step(chunk * 9 + u, chunk, u);
+            for (int u = 0; u < 9; ++u) step(chunk * 9 + u, chunk, u, std::false_type{});
+        }
+        if (a.halfk) {
+#pragma unroll
+            for (int u = 0; u < 9; ++u) step(nfull * 9 + u, nfull, u, std::true_type{});
         }
     } else {
         for (int c3 = 0; c3 < a.nchunk; c3 += 3) {
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                if (c3 + u < a.nchunk) step(c3 + u, c3 + u, u);
+                if (c3 + u < a.nchunk) step(c3 + u, c3 + u, u, std::false_type{});
         }
     }
     CDET_HALO_STAMP(4);
@@ -809,6 +818,7 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;
     a.res_ld = d->res_ld; a.res_coff = d->res_coff;
     a.nchunk = div_up(d->Cs, 32);
+    a.halfk = (d->kh == 3 && d->Cs % 32 != 0 && d->Cs % 32 <= 16 && tune_env("CDET_HALO_HALFK", 1)) ? 1 : 0;
     a.Cs = d->Cs;
     a.n_pblk = div_up(a.M, pl.hp);
     a.n_cblk = div_up(d->Cd, rb);
