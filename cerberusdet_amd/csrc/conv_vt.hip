@@ -41,7 +41,6 @@ struct VtArgs {
     int tiles_x, tiles_per_img;
     int cp, cq;  // class parity: the class writes dX(2y' + cp, 2x' + cq)
     unsigned x_bytes, w_bytes;
-    int dbg;
 };
 
 constexpr int VT_S2FWD = 0, VT_CLASS11 = 1, VT_CLASS10 = 2, VT_CLASS01 = 3, VT_CLASS00 = 4;
@@ -303,7 +302,6 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
         //   the weight tile of st + 2 (issued in phase B of st - 1)                                     NWP
         //   + the pixel pieces of phase A of this step and of the previous one, unless the plane that starts at st + 1 is among them
         //     (then everything up to its last piece has to land, which leaves only what was issued after it)
-        if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (FWD) {
             // u: newest needed            issued after it
             // 0: W(st+1) [B of u7 prev]   X(P11') was in front of W there; A(u8) none; B(u8) W; A(u0) 5 pieces        -> NWP + 5
@@ -361,10 +359,6 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) bo_cur[g] = bo_nxt[g];
-        if (a.dbg & 2) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
     };
 
     // The ring stage of a step is st % 3; the loops are unrolled over the least common period of (NT, 3) so that it is a constant.
@@ -664,7 +658,6 @@ static void vt_fill(VtArgs& a, const cdet_conv_desc* d, const VtPlan& pl, bool d
     a.cp = a.cq = 0;
     a.x_bytes = (unsigned)((int64_t)d->N * d->Hs * d->Ws * d->src_ld * 2);
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * 9 * rb * HROW);
-    a.dbg = getenv("CDET_VT_DBG") ? atoi(getenv("CDET_VT_DBG")) : 0;
 }
 
 extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
