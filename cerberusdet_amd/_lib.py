@@ -94,7 +94,8 @@ _SIGS = {
     "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "cdet_image_to_nhwc8": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_stem_conv_stat_blocks": (i32, [i32, i32, i32]),
-    "cdet_stem_conv_wgrad": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "cdet_stem_conv_wgrad_ws_elems": (i64, [i32, i32, i32]),
+    "cdet_stem_conv_wgrad": (i32, [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     "cdet_fold_padded_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "cdet_letterbox_batch": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_bn_finalize": (i32, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),

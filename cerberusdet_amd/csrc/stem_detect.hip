@@ -1,85 +1,8 @@
-// Stem weight gradient (Cin = 3, direct kernel reading the reference's NCHW image; the forward lives in stem_mfma.hip) and the
-// Detect head's eval-mode decode (DFL softmax-expectation + dist2bbox + sigmoid, writes the reference's [N,4+nc,A]).
+// The Detect head's eval-mode decode (DFL softmax-expectation + dist2bbox + sigmoid, writes the reference's [N,4+nc,A]) and the fold of
+// a channel-padded weight gradient (the stem's forward lives in stem_mfma.hip, its weight gradient in stem_wgrad.hip).
 #include "common.h"
 
 namespace cdet {
-
-constexpr int STEM_TPB = 256;
-constexpr int STEM_MAX_COUT = 128;
-
-__device__ __forceinline__ float load_img(const void* img, int64_t i, int dtype) {
-    if (dtype == CDET_U8) return (float)((const uint8_t*)img)[i] * (1.0f / 255.0f);
-    return load_elem(img, i, dtype);
-}
-
-// dW[co][c][kh][kw] += sum_p dy[p][co] * in[p][c,kh,kw]; thread (co, c) owns the 9 taps of one input channel.
-// Pixels are staged through LDS in tiles of 64; one fp32 atomicAdd per output per block at the end.
-constexpr int SW_TILE = 64;
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const void* __restrict__ img, int img_dtype, const void* __restrict__ dy, int dtype,
-                                                        float* __restrict__ dw, int N, int H, int W, int Cout, int pix_per_block) {
-    __shared__ float s_in[SW_TILE][28];
-    __shared__ float s_dy[SW_TILE][STEM_MAX_COUT + 1];
-    const int Ho = H / 2, Wo = W / 2;
-    const int64_t M = (int64_t)N * Ho * Wo;
-    const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block;
-    const int64_t p_end = p_begin + pix_per_block < M ? p_begin + pix_per_block : M;
-    const int t = threadIdx.x;
-    float acc[3][9];  // a thread may own up to 3 (co, c) pairs when 3*Cout > 256
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc[s][k] = 0.f;
-    const int n_pairs = 3 * Cout;
-    for (int64_t p0 = p_begin; p0 < p_end; p0 += SW_TILE) {
-        __syncthreads();
-        for (int i = t; i < SW_TILE * 27; i += 256) {
-            const int lp = i / 27, k = i - lp * 27;
-            const int64_t p = p0 + lp;
-            float v = 0.f;
-            if (p < p_end) {
-                const int ox = (int)(p % Wo);
-                const int64_t tt = p / Wo;
-                const int oy = (int)(tt % Ho);
-                const int n = (int)(tt / Ho);
-                const int c = k / 9, kh = (k % 9) / 3, kw = k % 3;
-                const int iy = oy * 2 - 1 + kh, ix = ox * 2 - 1 + kw;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = load_img(img, (((int64_t)n * 3 + c) * H + iy) * W + ix, img_dtype);
-            }
-            s_in[lp][k] = v;
-        }
-        for (int i = t; i < SW_TILE * Cout; i += 256) {
-            const int lp = i / Cout, co = i - lp * Cout;
-            const int64_t p = p0 + lp;
-            s_dy[lp][co] = p < p_end ? load_elem(dy, p * Cout + co, dtype) : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int pair = t + s * 256;
-            if (pair < n_pairs) {
-                const int c = pair / Cout, co = pair - c * Cout;
-                for (int lp = 0; lp < SW_TILE; ++lp) {
-                    const float g = s_dy[lp][co];
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) acc[s][k] = fmaf(g, s_in[lp][c * 9 + k], acc[s][k]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int pair = t + s * 256;
-        if (pair < n_pairs) {
-            const int c = pair / Cout, co = pair - c * Cout;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) atomicAdd(dw + (co * 3 + c) * 9 + k, acc[s][k]);
-        }
-    }
-}
-
-__global__ void zero_f32_kernel(float* p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Detect decode: one thread per (image, anchor)
@@ -160,27 +83,6 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N,
 }  // namespace cdet
 
 using namespace cdet;
-
-extern "C" int cdet_stem_conv_wgrad(const void* img, int32_t img_dtype, const void* dy, int32_t dtype, float* dw, int32_t N, int32_t H, int32_t W,
-                                    int32_t Cout, int32_t accumulate, void* stream) {
-    CDET_CHECK_ARG(img && dy && dw, "cdet_stem_conv_wgrad: null pointer");
-    CDET_CHECK_ARG(Cout <= STEM_MAX_COUT && 3 * Cout <= 768, "cdet_stem_conv_wgrad: Cout too large");
-    hipStream_t s = (hipStream_t)stream;
-    if (!accumulate) {
-        hipLaunchKernelGGL(zero_f32_kernel, dim3(4), dim3(256), 0, s, dw, (int64_t)Cout * 27);
-        CDET_LAUNCH_CHECK();
-    }
-    const int64_t M = (int64_t)N * (H / 2) * (W / 2);
-    int blocks = (int)((M + 2047) / 2048);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    int ppb = (int)((M + blocks - 1) / blocks);
-    ppb = (ppb + SW_TILE - 1) / SW_TILE * SW_TILE;
-    blocks = (int)((M + ppb - 1) / ppb);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, s, img, img_dtype, dy, dtype, dw, N, H, W, Cout, ppb);
-    CDET_LAUNCH_CHECK();
-    return 0;
-}
 
 __global__ void fold_padded_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int Ip, int I, int taps, int accumulate) {
     const int n = O * I * taps;

@@ -216,9 +216,10 @@ def stem_stat_blocks(N, H, W) -> int:
 def stem_conv_wgrad(img, dy: View, dw, accumulate=False):
     lib = L.load()
     N, c, H, W = img.shape
-    assert dy.coff == 0 and dy.ld == dy.C
-    L.check(lib.cdet_stem_conv_wgrad(ptr(img), dt(img.dtype), ptr(dy), dt(dy.dtype), ptr(dw), N, H, W, dy.C, int(accumulate), stream()),
-            "cdet_stem_conv_wgrad")
+    assert dy.coff == 0 and c == 3 and img.is_contiguous()
+    ws = torch.empty(lib.cdet_stem_conv_wgrad_ws_elems(N, H, W), dtype=torch.float32, device=dw.device)
+    L.check(lib.cdet_stem_conv_wgrad(ptr(img), dt(img.dtype), ptr(dy), dy.ld, dt(dy.dtype), ptr(dw), N, H, W, dy.C, int(accumulate), ptr(ws),
+                                     stream()), "cdet_stem_conv_wgrad")
     return dw
 
 

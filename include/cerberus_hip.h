@@ -187,9 +187,12 @@ int cdet_stem_conv_stat_blocks(int32_t N, int32_t H, int32_t W);
  * zero-padded to 8, 16-bit. (trainers/base_trainer.py:61-63 preprocess + the implicit NCHW->channels-last copy.) */
 int cdet_image_to_nhwc8(const void* img_nchw, int32_t img_dtype, void* out_nhwc8, int32_t N, int32_t H, int32_t W, int32_t dtype,
                         void* stream);
-/* d(stem weight) from dy (NHWC, dtype) and the image; accumulates into fp32 OIHW [Cout,3,3,3]. */
-int cdet_stem_conv_wgrad(const void* img_nchw, int32_t img_dtype, const void* dy, int32_t dtype, float* dw_oihw,
-                         int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t accumulate, void* stream);
+/* d(stem weight) (autograd's convolution_backward(weight) of the first Conv, models/common.py:57) from dy ([N,H/2,W/2,Cout] rows of
+ * dy_ld elements, bf16/f16) and the NCHW image itself (uint8 * 1/255, or float): MFMA kernel, per-workgroup fp32 partials in `ws`
+ * (cdet_stem_conv_wgrad_ws_elems floats), fixed-order finish; (+)= into fp32 OIHW [Cout,3,3,3]. Cout % 8 == 0, <= 80; H, W even. */
+int64_t cdet_stem_conv_wgrad_ws_elems(int32_t N, int32_t H, int32_t W);
+int cdet_stem_conv_wgrad(const void* img_nchw, int32_t img_dtype, const void* dy, int32_t dy_ld, int32_t dtype, float* dw_oihw,
+                         int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t accumulate, float* ws, void* stream);
 /* Weight gradient of the stem computed on the channel-padded image copy (cdet_image_to_nhwc8 + cdet_conv2d_wgrad): fold the
  * first I_real input channels of dw_pad [O, I_pad, kh, kw] into dw [O, I_real, kh, kw] (+= when accumulate). Completes
  * `loss.backward()` for models/common.py:57's first Conv without leaving the launch list. */

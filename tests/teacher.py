@@ -48,6 +48,13 @@ def _w_rounded(w, dtype):
     return w.detach().to(dtype).float()
 
 
+def _stem_input(plan):
+    """The stem reads the NCHW image itself (uint8 scaled by 1/255, or float), rounded to the compute dtype: its NHWC fp32 view."""
+    img = plan._img
+    v = img.float() * (1.0 / 255.0) if img.dtype == torch.uint8 else img.float()
+    return v.to(plan.dtype).float().permute(0, 2, 3, 1).contiguous()
+
+
 def _conv_name(m, x):
     return f"{x.H}x{x.W} {x.C}->{m.c2} k{m.k} s{m.s}" if x is not None else f"stem ->{m.c2}"
 
@@ -60,9 +67,9 @@ def check_forward(plan, rep, tol16=2.0 ** -7):
             m, x, z, y, res = rec["m"], rec["x"], rec["z"], rec["y"], rec["res"]
             name = _conv_name(m, x)
             w = _w_rounded(m.conv.weight, plan.dtype)
-            if getattr(m, "_stem8", False):
+            if x is not None and getattr(m, "_stem8", False):
                 w = F.pad(w, (0, 0, 0, 0, 0, x.C - w.shape[1]))
-            z_ref = R.conv_fwd(_f(x), w, m.s)
+            z_ref = R.conv_fwd(_f(x) if x is not None else _stem_input(plan), w, m.s)
             rep.add("conv", "z", rec, _f(z), z_ref, tol16, name)
             mean_ref = z_ref.mean((0, 1, 2))
             var_ref = z_ref.var((0, 1, 2), unbiased=False)
@@ -149,7 +156,7 @@ def _check_bwd(rec, s, plan, rep, tol16, stash):
             if rec["gx_acc"]:
                 ref = ref + s["gx"].float()
             rep.add("conv", "gx+" if rec["gx_acc"] else "gx", rec, _f(rec["gx"]), ref, tol16, name)
-        dw_ref = R.conv_wgrad(_f(x), dz_e, m.k, m.s)[:, :m.conv.weight.shape[1]]
+        dw_ref = R.conv_wgrad(_f(x) if x is not None else _stem_input(plan), dz_e, m.k, m.s)[:, :m.conv.weight.shape[1]]
         if rec["grouped"]:
             stash.append((rec, dw_ref, name))
         else:
