@@ -321,10 +321,11 @@ bool pair_plan_ok(const cdet_conv_desc* d) {
     const int n_cblk = div_up(d->Cd, 160);
     if (n_cblk % 2 != 0) return false;
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
-    // Measured (tools/conv_tiled_bench.py, batch 32): 40 x 40 1600 -> 640 936 -> 1038 TF/s, but 80 x 80 960 / 800 -> 320 unchanged and
-    // 80 x 80 320 -> 320 (10 K steps) 562 -> 508: sharing the pixel tile pays where the K loop is long enough to amortise the lock-step
-    // of eight waves on one barrier; five pixel buffers (four steps of lead) changed nothing -- the short layers are not latency-bound.
-    return mode == 2 || (d->Cs >= 1024 && div_up(M, HP) * (n_cblk / 2) >= 256);
+    // Measured (tools/conv_tiled_bench.py, batch 32): 40 x 40 1600 -> 640 936 -> 1038 TF/s, 40 x 40 960 -> 640 799 -> 832, 640 -> 640 685 -> 714,
+    // 80 x 80 960 -> 320 722 -> 741, but 80 x 80 320 -> 320 (10 K steps) 562 -> 508: sharing the pixel tile pays where the K loop is long
+    // enough to amortise the lock-step of eight waves on one barrier; five pixel buffers (four steps of lead) changed nothing -- the short
+    // layers are not latency-bound.
+    return mode == 2 || (d->Cs >= 640 && div_up(M, HP) * (n_cblk / 2) >= 256);
 }
 
 int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
