@@ -122,6 +122,7 @@ _SIGS = {
     "cdet_match_predictions": (i32, [C.POINTER(MatchDesc), vp, vp, vp, vp, vp, vp, vp]),
     "cdet_merge_tasks": (i32, [C.POINTER(MergeDesc), vp, vp, vp, vp]),
     "cdet_nms_batched": (i32, [C.POINTER(NmsDesc), vp, vp, vp, vp, vp]),
+    "cdet_nms_batched_idx": (i32, [C.POINTER(NmsDesc), vp, vp, vp, vp, vp, vp]),
     "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp]),
     "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, C.POINTER(f32), i32, f32, f32, vp]),
 }

@@ -22,7 +22,7 @@ constexpr float MAX_WH = 7680.0f;  // general.py:413
 
 struct Cand {        // 32 bytes
     float x1, y1, x2, y2, conf, cls;
-    uint32_t pos, pad;
+    uint32_t pos, anchor;  // position in the compacted list; the anchor the row came from (mask coefficients are gathered by it)
 };
 
 __device__ __forceinline__ float round_to(float v, int dtype) {
@@ -68,6 +68,7 @@ struct NmsArgs {
     int* count;             // [N]
     float* out_rows;
     int* out_count;
+    int* out_anchor;        // optional [N][max_det]
 };
 
 __device__ __forceinline__ bool class_allowed(const NmsArgs& a, int c) {
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs a) {
             cd.y1 = round_to(cy - hh, a.dtype);
             cd.x2 = round_to(cx + hw, a.dtype);
             cd.y2 = round_to(cy + hh, a.dtype);
-            cd.pad = 0;
+            cd.anchor = (uint32_t)an;
             int slot = base + excl;
             if (a.multi_label) {
                 for (int c = 0; c < nc; ++c) {
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64) void nms_greedy_kernel(const NmsArgs a) {
             }
             float* r = rows + (int64_t)slot * 6;
             r[0] = c.x1; r[1] = c.y1; r[2] = c.x2; r[3] = c.y2; r[4] = c.conf; r[5] = c.cls;
+            if (a.out_anchor != nullptr) a.out_anchor[(int64_t)n * a.max_det + slot] = (int)c.anchor;
         }
         nkept += kept_here;
         __syncthreads();
@@ -445,7 +447,8 @@ extern "C" int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d) {
     return align256((int64_t)d->N * d->max_cand * sizeof(Cand)) + align256((int64_t)d->N * cap2 * 8) + align256((int64_t)d->N * 4);
 }
 
-extern "C" int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, void* ws, void* stream) {
+extern "C" int cdet_nms_batched_idx(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, int32_t* out_anchor, void* ws,
+                                    void* stream) {
     CDET_CHECK_ARG(d && pred && out_rows && out_count && ws, "cdet_nms_batched: null pointer");
     CDET_CHECK_ARG(d->conf_thres >= 0.f && d->conf_thres <= 1.f, "Invalid Confidence threshold %f, valid values are between 0.0 and 1.0", d->conf_thres);
     CDET_CHECK_ARG(d->iou_thres >= 0.f && d->iou_thres <= 1.f, "Invalid IoU %f, valid values are between 0.0 and 1.0", d->iou_thres);
@@ -462,7 +465,7 @@ extern "C" int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float*
     a.cand = (Cand*)p; p += align256((int64_t)d->N * d->max_cand * sizeof(Cand));
     a.keys = (unsigned long long*)p; p += align256((int64_t)d->N * a.cap2 * 8);
     a.count = (int*)p;
-    a.out_rows = out_rows; a.out_count = out_count;
+    a.out_rows = out_rows; a.out_count = out_count; a.out_anchor = out_anchor;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_filter_kernel, dim3(d->N), dim3(256), 0, s, a);
     CDET_LAUNCH_CHECK();
@@ -471,6 +474,10 @@ extern "C" int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float*
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(d->N), dim3(64), 0, s, a);
     CDET_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, void* ws, void* stream) {
+    return cdet_nms_batched_idx(d, pred, out_rows, out_count, nullptr, ws, stream);
 }
 
 extern "C" int cdet_merge_tasks(const cdet_merge_desc* d, const float* scale, float* out_rows, int32_t* out_count, void* stream) {

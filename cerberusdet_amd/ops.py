@@ -339,8 +339,8 @@ def det_loss(feats, gt, nc, gains, strides, grad_scale=1.0, grad_dtype=None, wan
 
 
 def nms_batched(pred: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
-                max_nms=30000):
-    """pred [N, 4+nc, A] -> (rows [N,max_det,6] fp32, counts [N] i32)."""
+                max_nms=30000, return_anchor=False):
+    """pred [N, 4+nc, A] -> (rows [N,max_det,6] fp32, counts [N] i32[, anchor [N,max_det] i32: where every kept row came from])."""
     lib = L.load()
     assert pred.is_contiguous()
     N, no, A = pred.shape
@@ -357,6 +357,10 @@ def nms_batched(pred: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=Non
     ws = torch.empty(lib.cdet_nms_ws_bytes(C.byref(d)), dtype=torch.uint8, device=pred.device)
     rows = torch.zeros((N, max_det, 6), dtype=torch.float32, device=pred.device)
     cnt = torch.zeros(N, dtype=torch.int32, device=pred.device)
+    if return_anchor:
+        anchor = torch.zeros((N, max_det), dtype=torch.int32, device=pred.device)
+        L.check(lib.cdet_nms_batched_idx(C.byref(d), ptr(pred), ptr(rows), ptr(cnt), ptr(anchor), ptr(ws), stream()), "cdet_nms_batched_idx")
+        return rows, cnt, anchor
     L.check(lib.cdet_nms_batched(C.byref(d), ptr(pred), ptr(rows), ptr(cnt), ptr(ws), stream()), "cdet_nms_batched")
     return rows, cnt
 

@@ -68,21 +68,28 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),
                         max_det=300, nm=0) -> List[torch.Tensor]:
-    """Same contract as the reference: prediction [bs, 4+nc, A] (or the eval tuple (y, feats)) -> list of [k,6] fp32
-    tensors (x1,y1,x2,y2,conf,cls) on the prediction's device. `labels` (autolabelling, general.py:430-436): per image a [n, 5]
-    tensor (cls, x, y, w, h) whose rows join the candidates with confidence 1.0 -- here as extra anchors behind the model's, which is
-    where the reference's `torch.cat((x, v), 0)` puts them (the order decides ties). Not reproduced on purpose: the wall-clock
-    `time_limit` bail-out (general.py:417,477-479) and mask channels (`nm`; CerberusDet has no mask head)."""
+    """Same contract as the reference: prediction [bs, 4+nc+nm, A] (or the eval tuple (y, feats)) -> list of [k, 6+nm] fp32
+    tensors (x1,y1,x2,y2,conf,cls[,mask coefficients]) on the prediction's device. `labels` (autolabelling, general.py:430-436): per
+    image a [n, 5] tensor (cls, x, y, w, h) whose rows join the candidates with confidence 1.0 -- here as extra anchors behind the
+    model's, which is where the reference's `torch.cat((x, v), 0)` puts them (the order decides ties; the reference's own branch raises as
+    written -- it builds the rows nc + nm + 5 columns wide, a YOLOv5 leftover, against candidates of nc + nm + 4 -- so this is its
+    intent). `nm` (general.py:410,443-449):
+    the last nm channels are mask coefficients that take no part in the suppression and ride along with the kept boxes (zeros for label
+    rows). Not reproduced on purpose: the wall-clock `time_limit` bail-out (general.py:417,477-479)."""
     from .. import ops
 
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
-    if nm != 0:
-        raise NotImplementedError("cerberusdet_amd NMS: mask channels (nm) are not supported (CerberusDet has no mask head)")
     if not prediction.is_cuda:
         raise RuntimeError("cerberusdet_amd.non_max_suppression needs a tensor on the MI355X (no CPU path)")
+    masks = None
+    if nm:
+        mi = prediction.shape[1] - nm  # mask start index = 4 + nc
+        assert nm > 0 and mi > 4, f"nm = {nm} leaves no class channel in a prediction of {prediction.shape[1]} channels"
+        prediction, masks = prediction[:, :mi], prediction[:, mi:]
+    A = prediction.shape[2]
     if labels and any(len(lb) for lb in labels):
         bs, no, _ = prediction.shape
         n_lab = max(len(lb) for lb in labels)
@@ -93,9 +100,19 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
                 extra[xi, :4, :len(lb)] = lb[:, 1:5].T.to(prediction.dtype)
                 extra[xi, 4 + lb[:, 0].long(), torch.arange(len(lb), device=prediction.device)] = 1.0
         prediction = torch.cat((prediction, extra), 2)
-    rows, cnt = ops.nms_batched(prediction.contiguous(), conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
-    counts = cnt.tolist()  # the only host sync of the call
-    return [rows[i, :k] for i, k in enumerate(counts)]
+    if masks is None:
+        rows, cnt = ops.nms_batched(prediction.contiguous(), conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
+        counts = cnt.tolist()  # the only host sync of the call
+        return [rows[i, :k] for i, k in enumerate(counts)]
+    rows, cnt, anchor = ops.nms_batched(prediction.contiguous(), conf_thres, iou_thres, classes, agnostic, multi_label, max_det, return_anchor=True)
+    counts = cnt.tolist()
+    out = []
+    for i, k in enumerate(counts):
+        idx = anchor[i, :k].long()
+        m = masks[i].float().T[idx.clamp(max=A - 1)]  # [k, nm]
+        m = m * (idx < A).unsqueeze(1)                # label rows carry zero coefficients (general.py:432)
+        out.append(torch.cat((rows[i, :k], m), 1))
+    return out
 
 
 def box_iou(box1, box2, eps=1e-7):

@@ -334,6 +334,10 @@ typedef struct {
 } cdet_nms_desc;
 int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d);
 int cdet_nms_batched(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, void* ws, void* stream);
+/* The same, and out_anchor [N, max_det] i32 (may be NULL) = the anchor index every kept row came from: what the reference's mask
+ * branch (general.py:410,443-449, `nm` > 0) needs to carry the mask coefficients x[:, 4+nc:] of the kept boxes along. */
+int cdet_nms_batched_idx(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, int32_t* out_anchor, void* ws,
+                         void* stream);
 
 /* Cross-task merge after the per-task NMS -- everything between non_max_suppression and the result dicts of
  * CerberusDetInference.predict (cerberusdet_inference.py:72-83, 140-177; utils/general.py:484-554 nms_between_tasks, 313-357

@@ -69,39 +69,43 @@ def xywh2xyxy(x: np.ndarray) -> np.ndarray:
 
 
 def non_max_suppression(prediction: np.ndarray, conf_thres=0.25, iou_thres=0.45, classes: Optional[Sequence[int]] = None,
-                        agnostic=False, multi_label=False, max_det=300) -> List[np.ndarray]:
-    """utils/general.py:360-481 (nm=0, labels=()). prediction [bs, 4+nc, A] (any float dtype; the
+                        agnostic=False, multi_label=False, max_det=300, nm=0) -> List[np.ndarray]:
+    """utils/general.py:360-481 (labels=()). prediction [bs, 4+nc+nm, A] (any float dtype; the
     reference promotes to fp32 through `j.float()` in the cat, general.py:446-449, so everything after
-    the candidate filter is fp32). Returns list of [k,6] fp32 rows (x1,y1,x2,y2,conf,cls)."""
+    the candidate filter is fp32). Returns list of [k,6+nm] fp32 rows (x1,y1,x2,y2,conf,cls[,mask coefficients]):
+    the nm channels behind the class scores (general.py:410-411 `mi = 4 + nc`, :443 `x.split((4, nc, nm), 1)`) take no part
+    in the suppression and are concatenated to the kept rows (:447, :450)."""
     assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1
     bs, no, _ = prediction.shape
-    nc = no - 4
+    nc = no - nm - 4
+    mi = 4 + nc
     multi_label = multi_label and nc > 1
     thr = prediction.dtype.type(conf_thres)
     out = []
     for xi in range(bs):
-        x = prediction[xi].T  # [A, 4+nc]
-        xc = x[:, 4:].max(1) > thr
+        x = prediction[xi].T  # [A, 4+nc+nm]
+        xc = x[:, 4:mi].max(1) > thr
         x = x[xc]
         if not x.shape[0]:
-            out.append(np.zeros((0, 6), np.float32))
+            out.append(np.zeros((0, 6 + nm), np.float32))
             continue
         box = xywh2xyxy(x[:, :4])
-        cls = x[:, 4:]
+        cls = x[:, 4:mi]
+        mask = x[:, mi:].astype(np.float32)
         if multi_label:
             i, j = np.nonzero(cls > thr)
             rows = np.concatenate((box[i].astype(np.float32), cls[i, j, None].astype(np.float32),
-                                   j[:, None].astype(np.float32)), 1)
+                                   j[:, None].astype(np.float32), mask[i]), 1)
         else:
             j = cls.argmax(1)  # first max on ties, like torch.max(1)
             conf = cls[np.arange(cls.shape[0]), j]
             rows = np.concatenate((box.astype(np.float32), conf[:, None].astype(np.float32),
-                                   j[:, None].astype(np.float32)), 1)
+                                   j[:, None].astype(np.float32), mask), 1)
             rows = rows[conf > thr]
         if classes is not None:
             rows = rows[np.isin(rows[:, 5], np.asarray(classes, np.float32))]
         if not rows.shape[0]:
-            out.append(np.zeros((0, 6), np.float32))
+            out.append(np.zeros((0, 6 + nm), np.float32))
             continue
         order = np.argsort(-rows[:, 4], kind="stable")[:MAX_NMS]
         rows = rows[order]

@@ -156,6 +156,21 @@ def nms_case_input(name):
     return synth_pred(c["bs"], c["nc"], c["na"], c["n_obj"], c["seed"], np.dtype(c["dtype"]))
 
 
+NMS_MASK_CASES = {
+    # the reference's mask branch (general.py:410,443-449): nm coefficient channels behind the class scores ride along with the kept boxes
+    "masks": dict(bs=2, nc=20, na=2100, n_obj=120, nm=4, seed=31, kw=dict(conf_thres=0.25, iou_thres=0.45, nm=4)),
+    "masks_multilabel": dict(bs=2, nc=6, na=525, n_obj=60, nm=3, seed=32, kw=dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, nm=3)),
+    "masks_fp16_maxdet": dict(bs=1, nc=12, na=2100, n_obj=300, nm=8, seed=33, kw=dict(conf_thres=0.25, iou_thres=0.45, max_det=40, nm=8)),
+}
+
+
+def nms_mask_input(name):
+    c = NMS_MASK_CASES[name]
+    y = synth_pred(c["bs"], c["nc"], c["na"], c["n_obj"], c["seed"], np.dtype("float32"))
+    m = np.random.RandomState(c["seed"] + 1000).uniform(-1, 1, (c["bs"], c["nm"], c["na"])).astype(np.float32)
+    return np.concatenate((y, m), 1)
+
+
 def ties_input():
     """Ties / touching boxes: IoU == thr must be kept (suppression is strict '>')."""
     y = np.zeros((1, 4 + 2, 8), np.float32)

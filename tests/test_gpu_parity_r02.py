@@ -277,3 +277,50 @@ def test_nms_apriori_labels_join_the_candidates_like_the_reference():
         assert np.array_equal(got[xi].cpu().numpy(), want[xi]), xi
         if len(labels[xi]):  # a label row survives with confidence 1.0 at the top
             assert float(got[xi][0, 4]) == 1.0
+
+
+@pytest.mark.parametrize("name", list(synth.NMS_MASK_CASES))
+def test_nms_mask_coefficients_ride_along_like_the_reference(name):
+    """non_max_suppression(nm=k) (reference general.py:410,443-449) against the fixture written by the real reference: rows [k, 6 + nm],
+    boxes / scores / classes / coefficients bit-exact (cdet_nms_batched_idx returns the anchor of every kept row, the coefficients are
+    gathered by it)."""
+    from cerberusdet_amd.utils.general import non_max_suppression
+    from util import load_golden
+
+    arrays, meta = load_golden("nms_masks")
+    c = synth.NMS_MASK_CASES[name]
+    y = torch.from_numpy(synth.nms_mask_input(name)).to(DEV)
+    got = non_max_suppression(y, **c["kw"])
+    assert [int(o.shape[0]) for o in got] == meta[name]["counts"]
+    for i, o in enumerate(got):
+        o, want = o.cpu().numpy(), arrays[f"{name}/out{i}"]
+        assert o.shape == want.shape and o.dtype == np.float32
+        assert np.array_equal(o[:, 4], want[:, 4])
+        key = lambda r: r[np.lexsort((r[:, 5], r[:, 3], r[:, 2], r[:, 1], r[:, 0], -r[:, 4]))]  # noqa: E731  (equal scores: unstable argsort in the reference)
+        assert np.array_equal(key(o), key(want)), name
+
+
+def test_nms_masks_with_apriori_labels():
+    """nm together with labels=: label rows carry zero coefficients (the reference's intent at general.py:432; its own branch cannot run --
+    it builds rows one column too wide and torch.cat raises) -- against the oracle on the concatenated candidates."""
+    from cerberusdet_amd.utils.general import non_max_suppression
+    from oracle import nms as on
+
+    g = torch.Generator().manual_seed(9)
+    bs, nc, nm, A = 2, 5, 3, 300
+    y = torch.zeros(bs, 4 + nc + nm, A)
+    y[:, 0:2] = torch.rand(bs, 2, A, generator=g) * 200
+    y[:, 2:4] = torch.rand(bs, 2, A, generator=g) * 40 + 10
+    y[:, 4:4 + nc] = torch.rand(bs, nc, A, generator=g) * 0.6
+    y[:, 4 + nc:] = torch.rand(bs, nm, A, generator=g) * 2 - 1
+    labels = [torch.tensor([[2.0, 50, 60, 30, 30], [4.0, 120, 80, 25, 40]]), torch.zeros((0, 5))]
+    got = non_max_suppression(y.to(DEV), 0.25, 0.45, labels=labels, nm=nm)
+    ycat = torch.cat((y, torch.zeros(bs, 4 + nc + nm, 2)), 2)
+    for xi, lb in enumerate(labels):
+        for j, r in enumerate(lb):
+            ycat[xi, :4, A + j] = r[1:5]
+            ycat[xi, 4 + int(r[0]), A + j] = 1.0
+    want = on.non_max_suppression(ycat.numpy(), conf_thres=0.25, iou_thres=0.45, max_det=300, nm=nm)
+    for xi in range(bs):
+        assert np.array_equal(got[xi].cpu().numpy(), want[xi]), xi
+    assert float(got[0][0, 4]) == 1.0 and float(got[0][0, 6:].abs().sum()) == 0.0

@@ -191,6 +191,19 @@ def test_nms(name):
         assert np.array_equal(o, want), name  # kept rows, order and values bit-exact
 
 
+@pytest.mark.parametrize("name", list(synth.NMS_MASK_CASES))
+def test_nms_mask_branch(name):
+    """nm > 0 (reference general.py:410,443-449): the coefficient channels ride along with the kept rows -- fixture from the real reference."""
+    arrays, meta = load_golden("nms_masks")
+    c = synth.NMS_MASK_CASES[name]
+    out = on.non_max_suppression(synth.nms_mask_input(name), **c["kw"])
+    assert [o.shape[0] for o in out] == meta[name]["counts"] and out[0].shape[1] == meta[name]["cols"] == 6 + c["nm"]
+    for i, o in enumerate(out):
+        want = arrays[f"{name}/out{i}"]
+        assert np.array_equal(o[:, 4], want[:, 4])
+        assert np.array_equal(_canon_ties(o), _canon_ties(want)), name
+
+
 def test_nms_between_tasks_and_predict():
     arrays, meta = load_golden("nms")
     ya, yb, names, shapes = synth.predict_inputs()

@@ -307,6 +307,24 @@ def gen_loss_fixtures():
     json.dump(meta, open(OUT / "loss.json", "w"), indent=1)
 
 
+def gen_nms_mask_fixture():
+    """non_max_suppression with nm > 0 from the real reference. (Its `labels=` branch cannot be run: general.py:432 builds the label rows
+    nc + nm + 5 columns wide -- a YOLOv5 leftover -- and the torch.cat with the nc + nm + 4 wide candidates raises.)"""
+    import cerberusdet.utils.general as G
+    from cerberusdet.utils.general import non_max_suppression
+
+    G.time = types.SimpleNamespace(time=lambda: 0.0)
+    arrays, meta = {}, {}
+    for name, c in synth.NMS_MASK_CASES.items():
+        y = synth.nms_mask_input(name)
+        out = non_max_suppression(torch.from_numpy(y), **c["kw"])
+        for i, o in enumerate(out):
+            arrays[f"{name}/out{i}"] = o.numpy()
+        meta[name] = dict(counts=[int(o.shape[0]) for o in out], cols=int(out[0].shape[1]))
+    np.savez_compressed(OUT / "nms_masks.npz", **arrays)
+    json.dump(meta, open(OUT / "nms_masks.json", "w"), indent=1)
+
+
 def gen_nms_fixtures():
     import cerberusdet.utils.general as G
     from cerberusdet.utils.general import nms_between_tasks, non_max_suppression
@@ -487,6 +505,10 @@ def main():
     sys.path.insert(0, str(REF))
     torch.set_num_threads(8)
     torch.manual_seed(0)
+    if sys.argv[1:] == ["nms_masks"]:  # only the mask-branch NMS fixture
+        gen_nms_mask_fixture()
+        print("nms_masks done", json.load(open(OUT / "nms_masks.json")))
+        return
     if sys.argv[1:] == ["train_wc"]:  # only the well-conditioned train fixture (the others are untouched)
         gen_train_wc_fixture()
         print("train_wc done", (OUT / "train_wc.npz").stat().st_size // 1024, "KiB")
@@ -502,6 +524,7 @@ def main():
     gen_loss_fixtures()
     print("loss done")
     gen_nms_fixtures()
+    gen_nms_mask_fixture()
     print("nms done")
     gen_trainer_fixture(m, tasks, nc, cfg)
     print("trainer done")
