@@ -50,6 +50,16 @@ class LetterboxItem(C.Structure):
     _fields_ = [("img", vp), ("h", i32), ("w", i32), ("pitch", i32), ("new_w", i32), ("new_h", i32), ("top", i32), ("left", i32)]
 
 
+class AugTile(C.Structure):
+    _fields_ = [("img", vp), ("h0", i32), ("w0", i32), ("pitch", i32), ("h", i32), ("w", i32), ("x1a", i32), ("y1a", i32), ("x2a", i32),
+                ("y2a", i32), ("x1b", i32), ("y1b", i32), ("reserved", i32)]
+
+
+class AugSample(C.Structure):
+    _fields_ = [("tiles", AugTile * 8), ("minv", C.c_double * 12), ("mix_ratio", C.c_double), ("n_mosaic", i32), ("flipud", i32),
+                ("fliplr", i32), ("use_hsv", i32), ("lut", C.c_uint8 * 768)]
+
+
 class MergeDesc(C.Structure):
     _fields_ = [("N", i32), ("T", i32), ("max_det", i32), ("iou_thres", f32), ("rows", vp * 8), ("counts", vp * 8), ("cls_offset", i32 * 8)]
 
@@ -98,6 +108,7 @@ _SIGS = {
     "cdet_stem_conv_wgrad": (i32, [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     "cdet_fold_padded_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "cdet_letterbox_batch": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
+    "cdet_mosaic_augment_batch": (i32, [vp, i32, vp, i32, vp]),
     "cdet_bn_finalize": (i32, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),
     "cdet_bn_silu_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, i32, vp]),
     "cdet_bn_bwd_blocks": (i32, [i64]),

@@ -9,8 +9,8 @@
 
 namespace cdet {
 
-__device__ __forceinline__ void lin_coef(int d, float scale, int src, int& s, int& a0, int& a1) {
-    float f = (d + 0.5f) * scale - 0.5f;
+__device__ __forceinline__ void lin_coef(int d, double scale, int src, int& s, int& a0, int& a1) {
+    float f = (float)((d + 0.5) * scale - 0.5);  // OpenCV evaluates the source coordinate in double and keeps it as a float
     s = (int)floorf(f);
     f -= (float)s;
     if (s < 0) {
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const cdet_letterbox_ite
             for (int c = 0; c < 3; ++c) v[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
         } else {
             int sx, xa0, xa1, sy, ya0, ya1;
-            lin_coef(rx, (float)((double)it.w / it.new_w), it.w, sx, xa0, xa1);
-            lin_coef(ry, (float)((double)it.h / it.new_h), it.h, sy, ya0, ya1);
+            lin_coef(rx, (double)it.w / it.new_w, it.w, sx, xa0, xa1);
+            lin_coef(ry, (double)it.h / it.new_h, it.h, sy, ya0, ya1);
             const int sx1 = min(sx + 1, it.w - 1), sy1 = min(sy + 1, it.h - 1);
             const unsigned char* r0 = src + (int64_t)sy * it.pitch;
             const unsigned char* r1 = src + (int64_t)sy1 * it.pitch;

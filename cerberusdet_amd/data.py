@@ -11,14 +11,17 @@ Dataset YAML = the reference's (data/voc_obj365_animals.yaml): `train` / `val`: 
 `nc`, `names`, `task_ids`. Label files sit next to the images with /images/ replaced by /labels/ (datasets.py:90-103); a row is
 `cls x y w h` or `cls prob x y w h` (datasets.py:654-666).
 
-Not reproduced (SURVEY.md section 8f.4 "later"): mosaic / mixup / affine / HSV / flips, the label cache, BalancedBatchSampler.
+`augment=True` (train.py --augment): the reference's training augmentation -- mosaic of four images, random affine, mixup, HSV, flips
+(data/datasets.py:361-438, 483-542; data/augmentations.py:43-211) -- with every random draw and the label geometry on the host
+(cerberusdet_amd/augment.py, pinned against the reference's own functions) and the pixels rendered by ONE kernel per batch straight from
+the decoded originals (csrc/augment.hip). Not reproduced: the label cache, BalancedBatchSampler, Albumentations, rectangular batches.
 Shards: rank r takes samples r, r + world, ... of the (per-epoch, seeded) permutation, like a DistributedSampler.
 """
 from __future__ import annotations
 
 import os
 from pathlib import Path
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -88,11 +91,22 @@ class TaskDataset:
     """Iterable over one task's batches for one rank; `len()` = batches per epoch. Every `iter()` starts a new epoch."""
 
     def __init__(self, path: str, imgsz: int, batch_size: int, nc: int, device, rank: int = 0, world_size: int = 1, shuffle: bool = True,
-                 seed: int = 0):
+                 seed: int = 0, augment: bool = False, hyp: Optional[dict] = None):
         self.files = list_images(path)
         self.labels = [read_labels(img2label_path(f), nc) for f in self.files]
         self.imgsz, self.bs, self.nc, self.device = imgsz, batch_size, nc, torch.device(device)
         self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
+        self.augment = augment
+        if augment:
+            from PIL import Image
+
+            from .augment import HYP_DEFAULT
+
+            self.hyp = dict(HYP_DEFAULT, **{k: v for k, v in (hyp or {}).items() if k in HYP_DEFAULT})
+            self.sizes = []
+            for f in self.files:  # header reads only: the mosaic geometry needs every image's size before any pixel is decoded
+                with Image.open(f) as im:
+                    self.sizes.append((im.size[1], im.size[0]))
         per_rank = (len(self.files) + world_size - 1) // world_size
         self.nb = max((per_rank + batch_size - 1) // batch_size, 1)
 
@@ -106,6 +120,32 @@ class TaskDataset:
         idx = np.concatenate((idx, idx[:pad])) if pad else idx
         return idx[self.rank::self.world]
 
+    def _iter_augmented(self, order):
+        """Mosaic / affine / mixup / HSV / flip batches (the reference's `__getitem__` with augment=True + `collate_fn`)."""
+        import random
+
+        from PIL import Image
+
+        from . import augment as A
+
+        S, n = self.imgsz, len(self.files)
+        key = (self.seed * 1000003 + self.epoch) * 64 + self.rank
+        rng, nprng = random.Random(key), np.random.RandomState(key % (2 ** 32))
+        for b0 in range(0, len(order), self.bs):
+            ids = order[b0:b0 + self.bs]
+            plans = [A.sample_plan(rng, nprng, int(i), range(n), self.sizes, self.labels, S, self.hyp) for i in ids]
+            need = sorted({t.index for p in plans for m in p.mosaics for t in m.tiles})
+            images = {}
+            for i in need:  # cv2.imread order: BGR
+                images[i] = torch.from_numpy(np.ascontiguousarray(np.asarray(Image.open(self.files[i]).convert("RGB"))[:, :, ::-1])).to(self.device, non_blocking=True)
+            img = A.render_batch(plans, images, S, self.device)
+            lab = [p.labels for p in plans]
+            cat = lambda col, w: torch.from_numpy(np.concatenate([lb[:, col] for lb in lab], 0).reshape(-1, w).astype(np.float32)).to(self.device)  # noqa: E731
+            bidx = np.concatenate([np.full(len(lb), j, np.float32) for j, lb in enumerate(lab)], 0)
+            yield {"img": img, "cls": cat(slice(0, 1), 1), "prob": cat(slice(1, 2), 1), "bboxes": cat(slice(2, 6), 4),
+                   "batch_idx": torch.from_numpy(bidx).to(self.device), "im_file": tuple(self.files[int(i)] for i in ids),
+                   "ori_shape": tuple(None for _ in ids), "ratio_pad": tuple(None for _ in ids)}
+
     def __iter__(self):
         from PIL import Image
 
@@ -114,6 +154,9 @@ class TaskDataset:
         lib = L.load()
         order = self._order()
         self.epoch += 1
+        if self.augment:
+            yield from self._iter_augmented(order)
+            return
         S = self.imgsz
         for b0 in range(0, len(order), self.bs):
             ids = order[b0:b0 + self.bs]
@@ -142,7 +185,7 @@ class TaskDataset:
 
 
 def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: Sequence[int], imgsz: int, device="cuda", rank: int = 0,
-                       world_size: int = 1):
+                       world_size: int = 1, augment: bool = False, hyp: Optional[dict] = None):
     """-> (train {task: TaskDataset}, val {task: TaskDataset} (rank 0 validates, unsharded), names {task: [str]})."""
     import yaml
 
@@ -155,7 +198,8 @@ def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: S
     def res(p):
         return str(p if os.path.isabs(p) else root / p)
 
-    train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i) for i, t in enumerate(ids)}
+    train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i, augment=augment, hyp=hyp)
+             for i, t in enumerate(ids)}
     val = {t: TaskDataset(res(d["val"][i]), imgsz, bs[i], nc[i], device, 0, 1, shuffle=False) for i, t in enumerate(ids)} if d.get("val") else None
     names = {t: [str(n) for n in d["names"][i]] for i, t in enumerate(ids)} if d.get("names") else None
     return train, val, names

@@ -51,6 +51,8 @@ def parse_opt(known=False):
     p.add_argument("--resume", nargs="?", const=True, default=False)
     p.add_argument("--nosave", action="store_true")
     p.add_argument("--noval", action="store_true", help="only validate the final epoch")
+    p.add_argument("--augment", action="store_true", help="--data <yaml>: the reference's training augmentation (mosaic, random affine, mixup, HSV, "
+                   "flips; hyper-parameters from --hyp), rendered on the GPU (cerberusdet_amd/augment.py)")
     p.add_argument("--device", default="")
     p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm: per-layer statistics all-reduced over the ranks")
     p.add_argument("--workers", type=int, default=8, help="accepted for CLI compatibility: batches come from the caller's iterables / the synthetic generator")
@@ -153,7 +155,8 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         else:
             from cerberusdet_amd import data as cdata
 
-            train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE)
+            train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE,
+                                                                           augment=getattr(opt, "augment", False), hyp=hyp)
             val_dataset = val_dataset if val_dataset is not None else val_dataset_y
             nb = max(len(d) for d in train_dataset.values())
     else:

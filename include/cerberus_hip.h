@@ -214,6 +214,29 @@ typedef struct {
 int cdet_letterbox_batch(const cdet_letterbox_item* items, int32_t B, void* out_nchw, int32_t H, int32_t W, int32_t out_dtype,
                          int32_t pad_value, void* stream);
 
+/* Training-time augmentation, rendered in one launch per batch from the ORIGINAL decoded images: mosaic of four images
+ * (data/datasets.py:483-527 load_mosaic, incl. the cv2.resize of load_image 470-477), cv2.warpAffine of random_perspective
+ * (data/augmentations.py:151), mixup with a second mosaic (205-211), augment_hsv (43-57), flips, BGR->RGB, HWC->CHW
+ * (datasets.py:420-438). The host samples every random parameter in the reference's order and transforms the labels
+ * (cerberusdet_amd/augment.py); this call only renders. out: [B, 3, s, s] uint8 RGB. */
+typedef struct {
+    const void* img;               /* uint8 HWC BGR original image on the device                       */
+    int32_t h0, w0, pitch;         /* its size, bytes per row                                          */
+    int32_t h, w;                  /* size after load_image (long side -> s)                           */
+    int32_t x1a, y1a, x2a, y2a;    /* destination rectangle on the 2s x 2s canvas                      */
+    int32_t x1b, y1b;              /* origin of the pasted part in the resized image                   */
+    int32_t reserved;
+} cdet_aug_tile;
+typedef struct {
+    cdet_aug_tile tiles[8];        /* mosaic 0: tiles 0..3; the mixup partner: tiles 4..7              */
+    double minv[12];               /* per mosaic a11 a12 b1 a21 a22 b2: output -> canvas, the inverse cv2.warpAffine derives */
+    double mix_ratio;              /* weight of mosaic 0 (np.random.beta(32, 32))                      */
+    int32_t n_mosaic;              /* 1, or 2 with mixup                                               */
+    int32_t flipud, fliplr, use_hsv;
+    uint8_t lut[768];              /* augment_hsv's hue / sat / val lookup tables                      */
+} cdet_aug_sample;
+int cdet_mosaic_augment_batch(const cdet_aug_sample* samples, int32_t B, void* out_u8_nchw, int32_t s, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Train-mode BatchNorm2d(eps 1e-3, momentum 0.03) + SiLU around the conv (common.py:61, torch_utils.py:184-186)
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,123 @@
+"""CPU restatement (numpy) of the PIXEL side of the reference's training augmentation -- TEST INFRASTRUCTURE, never imported by the product.
+
+Follows, image by image, what a reference DataLoader worker does with cv2 (data/datasets.py:470-477 load_image, 483-527 load_mosaic,
+data/augmentations.py:151 cv2.warpAffine inside random_perspective, 205-211 mixup, 43-57 augment_hsv, datasets.py:420-438 flips and the
+final transpose), materialising every intermediate image the way the reference does -- the HIP kernel (csrc/augment.hip) computes the
+same values on the fly and must equal this bit for bit.
+
+cv2 is not installable here: its 8-bit algorithms are restated from OpenCV's published sources (resize.cpp INTER_LINEAR, imgwarp.cpp
+warpAffine / remapBilinear, color_hsv.cpp RGB2HSV_b / HSV2RGB_f). **Parity unpinned** at the pixel level; the random parameters and the label
+geometry are pinned separately against the reference's own functions (tests/golden/augment.json).
+"""
+import numpy as np
+
+from .preprocess import resize_linear_u8
+
+
+def resized_hw(hw0, s):  # datasets.py:470-477
+    h0, w0 = hw0
+    r = s / max(h0, w0)
+    return (int(h0 * r), int(w0 * r)) if r != 1 else (h0, w0)
+
+
+def build_canvas(tiles, images, s):
+    """load_mosaic's img4: tiles = [(index, (x1a, y1a, x2a, y2a), (x1b, y1b))], images[index] uint8 HWC BGR originals."""
+    img4 = np.full((2 * s, 2 * s, 3), 114, np.uint8)
+    for idx, (x1a, y1a, x2a, y2a), (x1b, y1b) in tiles:
+        im = images[idx]
+        h, w = resized_hw(im.shape[:2], s)
+        im = resize_linear_u8(im, (w, h))
+        img4[y1a:y2a, x1a:x2a] = im[y1b:y1b + (y2a - y1a), x1b:x1b + (x2a - x1a)]
+    return img4
+
+
+def _round_sat(x):
+    return np.clip(np.rint(x), -2147483648.0, 2147483647.0).astype(np.int64)
+
+
+def warp_affine_u8(src, M, dsize, border=114):
+    """cv2.warpAffine(src, M[:2], dsize, borderValue=(114,)*3): INTER_LINEAR, BORDER_CONSTANT, 8-bit 3-channel."""
+    A = np.asarray(M, np.float64)[:2]
+    D = A[0, 0] * A[1, 1] - A[0, 1] * A[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    a11, a22 = A[1, 1] * D, A[0, 0] * D
+    a12, a21 = -A[0, 1] * D, -A[1, 0] * D
+    b1 = -a11 * A[0, 2] - a12 * A[1, 2]
+    b2 = -a21 * A[0, 2] - a22 * A[1, 2]
+    width, height = dsize
+    xs, ys = np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64)
+    adelta, bdelta = _round_sat(a11 * xs * 1024.0), _round_sat(a21 * xs * 1024.0)
+    X0 = _round_sat((a12 * ys + b1) * 1024.0) + 16
+    Y0 = _round_sat((a22 * ys + b2) * 1024.0) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    H, W = src.shape[:2]
+
+    def tap(xx, yy):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.int64)
+        v[~ok] = border
+        return v
+
+    w00, w01, w10, w11 = (32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32
+    out = (tap(sx, sy) * w00[..., None] + tap(sx + 1, sy) * w01[..., None] + tap(sx, sy + 1) * w10[..., None] + tap(sx + 1, sy + 1) * w11[..., None] + (1 << 14)) >> 15
+    return out.astype(np.uint8)
+
+
+def bgr2hsv_u8(im):
+    b, g, r = (im[..., i].astype(np.int64) for i in range(3))
+    v = np.maximum(b, np.maximum(g, r))
+    diff = v - np.minimum(b, np.minimum(g, r))
+    sdiv = np.where(v > 0, _round_sat((255 << 12) / np.maximum(v, 1).astype(np.float64)), 0)
+    hdiv = np.where(diff > 0, _round_sat((180 << 12) / (6.0 * np.maximum(diff, 1))), 0)
+    s = (diff * sdiv + (1 << 11)) >> 12
+    vr, vg = v == r, v == g
+    h = np.where(vr, g - b, np.where(vg, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv + (1 << 11)) >> 12
+    h = np.where(h < 0, h + 180, h)
+    return h, s, v
+
+
+def hsv2bgr_u8(h, s, v):
+    f = np.float32
+    sf, vf = s.astype(f) * f(1.0 / 255.0), v.astype(f) * f(1.0 / 255.0)
+    hf = h.astype(f) * f(6.0 / 180.0)
+    hf = np.where(hf >= f(6), hf - f(6), hf)
+    sector = np.floor(hf).astype(np.int64)
+    hf = (hf - sector.astype(f)).astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    hf = np.where(bad, f(0), hf).astype(f)
+    one = f(1)
+    tab = np.stack((vf, (vf * (one - sf)).astype(f), (vf * (one - (sf * hf).astype(f)).astype(f)).astype(f),
+                    (vf * (one - (sf * (one - hf).astype(f)).astype(f)).astype(f)).astype(f)), -1)
+    sb, sg, sr = np.array([1, 1, 3, 0, 0, 2]), np.array([3, 0, 0, 2, 1, 1]), np.array([0, 2, 1, 1, 3, 0])
+    pick = lambda sel: np.take_along_axis(tab, sel[sector][..., None], -1)[..., 0]  # noqa: E731
+    b, g, r = pick(sb), pick(sg), pick(sr)
+    gray = s == 0
+    b, g, r = np.where(gray, vf, b), np.where(gray, vf, g), np.where(gray, vf, r)
+    out = np.stack([np.clip(np.rint((c * f(255)).astype(f)), 0, 255) for c in (b, g, r)], -1)
+    return out.astype(np.uint8)
+
+
+def augment_hsv(im, lut):
+    """augmentations.py:43-57 with the three lookup tables already drawn (lut [3, 256] uint8)."""
+    h, s, v = bgr2hsv_u8(im)
+    return hsv2bgr_u8(lut[0][h].astype(np.int64), lut[1][s].astype(np.int64), lut[2][v].astype(np.int64))
+
+
+def render(mosaics, mix_ratio, lut, flipud, fliplr, images, s):
+    """mosaics: [(tiles, M)] (one, or two with mixup) -> uint8 [3, s, s] RGB exactly as `__getitem__` returns it."""
+    ims = [warp_affine_u8(build_canvas(tiles, images, s), M, (s, s)) for tiles, M in mosaics]
+    im = ims[0]
+    if len(ims) > 1:
+        im = (im * mix_ratio + ims[1] * (1 - mix_ratio)).astype(np.uint8)
+    if lut is not None:
+        im = augment_hsv(im, lut)
+    if flipud:
+        im = np.flipud(im)
+    if fliplr:
+        im = np.fliplr(im)
+    return np.ascontiguousarray(im.transpose((2, 0, 1))[::-1])

@@ -234,3 +234,55 @@ def val_case(seed, n, m, nc):
                 det[i, 5] = rng.integers(0, nc)
         det[:, 4] = np.sort(rng.uniform(0.01, 0.99, n).astype(np.float32))[::-1]
     return det, lab
+
+
+# ---- training augmentation (tools/make_golden_aug.py, tests/test_augment_cpu.py, tests/test_gpu_augment.py) ------------------------
+_AUG_HYP = dict(hsv_h=0.0124, hsv_s=0.696, hsv_v=0.287, degrees=0.299, translate=0.211, scale=0.846, scaleup=0.0, shear=0.717, perspective=0.0,
+                flipud=0.00983, fliplr=0.5, mosaic=1.0, mixup=0.285)  # data/hyps/hyp.cerber-voc_obj365.yaml
+AUG_CASES = {
+    "hyp_default": dict(seed=41, n=12, s=640, samples=12, hyp=_AUG_HYP),
+    "rotate_flip_mix": dict(seed=42, n=9, s=320, samples=10, hyp=dict(_AUG_HYP, degrees=10.0, shear=5.0, flipud=0.5, mixup=0.7, scaleup=0.6)),
+    "no_hsv_no_mix": dict(seed=43, n=6, s=256, samples=6, hyp=dict(_AUG_HYP, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, mixup=0.0, fliplr=0.0, flipud=0.0)),
+}
+
+
+def aug_resized(hw0, s):
+    """reference load_image (data/datasets.py:470-477): long side -> s, truncated sizes."""
+    h0, w0 = hw0
+    r = s / max(h0, w0)
+    return (int(h0 * r), int(w0 * r)) if r != 1 else (h0, w0)
+
+
+def aug_dataset(seed, n, s):
+    """n images of assorted sizes (some larger, some smaller than s, one exactly 2s on its long side, one equal to s) with 0..5 labels
+    each: (sizes [(h0, w0)], labels [k, 6] float32 (cls, prob, x, y, w, h) normalised)."""
+    rng = np.random.RandomState(seed)
+    sizes, labels = [], []
+    for i in range(n):
+        if i == 0:
+            hw = (2 * s, 2 * s - 2 * (s // 8))  # the exact 2x shrink in one direction only -> the bilinear path
+        elif i == 1:
+            hw = (2 * s, 2 * s)                 # exact 2x shrink: cv2's area fast path
+        elif i == 2:
+            hw = (s, s - s // 4)                # no resize
+        else:
+            hw = (int(rng.randint(s // 3, 2 * s)), int(rng.randint(s // 3, 2 * s)))
+        sizes.append(hw)
+        k = int(rng.randint(0, 6))
+        cx, cy = rng.uniform(0.15, 0.85, k), rng.uniform(0.15, 0.85, k)
+        w, h = rng.uniform(0.05, 0.28, k), rng.uniform(0.05, 0.28, k)
+        lb = np.stack((rng.randint(0, 20, k).astype(np.float64), np.ones(k), cx, cy, w, h), 1).astype(np.float32)
+        labels.append(lb.reshape(-1, 6))
+    return sizes, labels
+
+
+def aug_images(seed, sizes):
+    """uint8 HWC BGR images with structure (gradients + blocks + noise) for the pixel tests."""
+    out = []
+    for i, (h, w) in enumerate(sizes):
+        rng = np.random.RandomState(seed * 100 + i)
+        yy, xx = np.mgrid[0:h, 0:w]
+        im = np.stack(((xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx // 16 + yy // 16) % 2) * 200 + 20), -1).astype(np.int64)
+        im = (im + rng.randint(-25, 26, im.shape)).clip(0, 255).astype(np.uint8)
+        out.append(np.ascontiguousarray(im))
+    return out

@@ -100,3 +100,7 @@ def test_yolo_txt_dataset_trains_and_validates(tmp_path):
     res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds"))
     assert epoch == 1 and (tmp_path / "ds" / "weights" / "last.pt").exists()
     assert all(np.isfinite(v) for r in res.values() for v in r)
+    # the same with the reference's training augmentation (mosaic / affine / mixup / HSV / flips rendered on the GPU)
+    res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds_aug", augment=True))
+    assert epoch == 1 and (tmp_path / "ds_aug" / "weights" / "last.pt").exists()
+    assert all(np.isfinite(v) for r in res.values() for v in r)
