@@ -18,6 +18,7 @@ kernel is bit-exact against `oracle/augment.py`, the numpy restatement of the sa
 
 Not reproduced: Albumentations (a no-op in the reference when the package is missing, augmentations.py:16-40), `perspective` != 0 (the
 shipped hyper-parameters use 0.0: warpPerspective is not implemented), rectangular training, image weights, the label cache.
+Both branches of `__getitem__` are covered: the mosaic (probability hyp["mosaic"], with mixup) and the single letterboxed image.
 """
 from __future__ import annotations
 
@@ -47,6 +48,8 @@ class Mosaic:
     tiles: List[Tile]
     M: np.ndarray            # 3x3 forward matrix (canvas -> output), float64
     labels: np.ndarray       # [n, 6] (cls, prob, x1, y1, x2, y2) in output pixels, after the candidate filter
+    canvas: int = 0          # side of the square the tiles are pasted on: 2s for a mosaic, s for the single letterboxed image
+    shapes: Optional[tuple] = None  # single image: ((h0, w0), ((h / h0, w / w0), (dw, dh))) like the reference's `shapes`
 
 
 @dataclass
@@ -178,7 +181,27 @@ def sample_mosaic(rng: random.Random, index, indices: Sequence[int], sizes, labe
     lab4 = np.concatenate(lab4, 0)
     np.clip(lab4[:, 2:], 0, 2 * s, out=lab4[:, 2:])
     M, sc, width, height = sample_affine(rng, (2 * s, 2 * s), hyp, border)
-    return Mosaic(tiles, M, warp_labels(lab4, M, sc, width, height))
+    return Mosaic(tiles, M, warp_labels(lab4, M, sc, width, height), canvas=2 * s)
+
+
+def sample_single(rng: random.Random, index, sizes, labels, s, hyp) -> Mosaic:
+    """The non-mosaic branch of __getitem__ (datasets.py:376-402): load_image, letterbox(auto=False, scaleup=True), random_perspective
+    without border. (When load_image's truncation leaves the long side at s - 1 the reference resizes a second time inside letterbox;
+    here the original is resized once to that final size -- the labels are the reference's either way.)"""
+    if hyp["perspective"]:
+        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not implemented; the shipped hyper-parameters use 0.0")
+    h0, w0 = sizes[index]
+    h, w = resized_hw((h0, w0), s)
+    r = min(s / h, s / w)
+    new_w, new_h = int(round(w * r)), int(round(h * r))
+    dw, dh = (s - new_w) / 2, (s - new_h) / 2
+    top, left = int(round(dh - 0.1)), int(round(dw - 0.1))
+    tile = Tile(int(index), (int(h0), int(w0)), (new_h, new_w), (left, top, left + new_w, top + new_h), (0, 0))
+    lb = np.array(labels[index]).reshape(-1, 6).copy()
+    if lb.size:
+        lb[:, 2:] = xywhn2xyxy(lb[:, 2:], r * w, r * h, padw=dw, padh=dh)
+    M, sc, width, height = sample_affine(rng, (s, s), hyp)
+    return Mosaic([tile], M, warp_labels(lb, M, sc, width, height), canvas=s, shapes=((h0, w0), ((h / h0, w / w0), (dw, dh))))
 
 
 def hsv_luts(nprng: np.random.RandomState, hyp):
@@ -192,15 +215,16 @@ def hsv_luts(nprng: np.random.RandomState, hyp):
 
 
 def sample_plan(rng: random.Random, nprng: np.random.RandomState, index, indices, sizes, labels, s, hyp) -> AugPlan:
-    """One training sample of the augmenting dataset, mosaic branch (datasets.py:364-418), draws in the reference's order."""
+    """One training sample of the augmenting dataset (datasets.py:364-418, both branches), draws in the reference's order."""
     n = len(sizes)
-    if not (rng.random() < hyp["mosaic"]):
-        raise NotImplementedError("mosaic probability < 1: the letterbox + affine branch of __getitem__ is not implemented")
-    mosaics = [sample_mosaic(rng, index, indices, sizes, labels, s, hyp)]
     ratio = None
-    if rng.random() < hyp["mixup"]:
-        mosaics.append(sample_mosaic(rng, rng.randint(0, n - 1), indices, sizes, labels, s, hyp))
-        ratio = float(nprng.beta(32.0, 32.0))
+    if rng.random() < hyp["mosaic"]:
+        mosaics = [sample_mosaic(rng, index, indices, sizes, labels, s, hyp)]
+        if rng.random() < hyp["mixup"]:
+            mosaics.append(sample_mosaic(rng, rng.randint(0, n - 1), indices, sizes, labels, s, hyp))
+            ratio = float(nprng.beta(32.0, 32.0))
+    else:
+        mosaics = [sample_single(rng, index, sizes, labels, s, hyp)]
     lab = np.concatenate([m.labels for m in mosaics], 0)
     if len(lab):
         lab[:, 2:6] = xyxy2xywhn(lab[:, 2:6], w=s, h=s, clip=True, eps=1e-3)
@@ -244,6 +268,7 @@ def render_batch(plans: Sequence[AugPlan], images, s, device):
     for b, p in enumerate(plans):
         sm = samples[b]
         sm.n_mosaic = len(p.mosaics)
+        sm.canvas = p.mosaics[0].canvas
         sm.mix_ratio = p.mix_ratio if p.mix_ratio is not None else 1.0
         sm.flipud, sm.fliplr = int(p.flipud), int(p.fliplr)
         sm.use_hsv = int(p.hsv_lut is not None)

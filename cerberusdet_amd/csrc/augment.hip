@@ -64,7 +64,8 @@ __device__ __forceinline__ void aug_resized_pixel(const cdet_aug_tile& t, int rx
     }
 }
 
-// pixel (cx, cy) of the virtual 2s x 2s mosaic canvas (114 where no tile was pasted, and outside: warpAffine's border value)
+// pixel (cx, cy) of the virtual canvas -- 2s x 2s for a mosaic, s x s for the single letterboxed image -- 114 where no tile was pasted
+// (letterbox's border colour is the same 114) and outside (warpAffine's border value)
 __device__ __forceinline__ void aug_canvas_pixel(const cdet_aug_tile* tiles, int s2, int cx, int cy, int v[3]) {
     v[0] = v[1] = v[2] = 114;
     if ((unsigned)cx >= (unsigned)s2 || (unsigned)cy >= (unsigned)s2) return;
@@ -84,7 +85,7 @@ __device__ __forceinline__ int aug_round_sat(double x) {  // saturate_cast<int>(
 }
 
 // cv2.warpAffine(canvas, M, (s, s), borderValue=114) at (x, y)
-__device__ __forceinline__ void aug_warp_pixel(const cdet_aug_tile* tiles, const double* m, int s, int x, int y, int v[3]) {
+__device__ __forceinline__ void aug_warp_pixel(const cdet_aug_tile* tiles, const double* m, int canvas, int x, int y, int v[3]) {
     const int adelta = aug_round_sat(m[0] * x * 1024.0), bdelta = aug_round_sat(m[3] * x * 1024.0);
     const int X0 = aug_round_sat((m[1] * y + m[2]) * 1024.0) + 16, Y0 = aug_round_sat((m[4] * y + m[5]) * 1024.0) + 16;
     const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
@@ -94,10 +95,10 @@ __device__ __forceinline__ void aug_warp_pixel(const cdet_aug_tile* tiles, const
     const int fx = X & 31, fy = Y & 31;
     const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
     int p00[3], p01[3], p10[3], p11[3];
-    aug_canvas_pixel(tiles, 2 * s, sx, sy, p00);
-    aug_canvas_pixel(tiles, 2 * s, sx + 1, sy, p01);
-    aug_canvas_pixel(tiles, 2 * s, sx, sy + 1, p10);
-    aug_canvas_pixel(tiles, 2 * s, sx + 1, sy + 1, p11);
+    aug_canvas_pixel(tiles, canvas, sx, sy, p00);
+    aug_canvas_pixel(tiles, canvas, sx + 1, sy, p01);
+    aug_canvas_pixel(tiles, canvas, sx, sy + 1, p10);
+    aug_canvas_pixel(tiles, canvas, sx + 1, sy + 1, p11);
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = (p00[c] * w00 + p01[c] * w01 + p10[c] * w10 + p11[c] * w11 + (1 << 14)) >> 15;
 }
@@ -155,10 +156,10 @@ __global__ __launch_bounds__(256) void mosaic_augment_kernel(const cdet_aug_samp
     // output pixel (x, y) = pixel (xs, ys) of the image before np.flipud / np.fliplr
     const int xs = sm.fliplr ? s - 1 - x : x, ys = sm.flipud ? s - 1 - y : y;
     int v[3];
-    aug_warp_pixel(sm.tiles, sm.minv, s, xs, ys, v);
+    aug_warp_pixel(sm.tiles, sm.minv, sm.canvas, xs, ys, v);
     if (sm.n_mosaic > 1) {  // mixup: (im * r + im2 * (1 - r)).astype(np.uint8) in float64
         int v2[3];
-        aug_warp_pixel(sm.tiles + 4, sm.minv + 6, s, xs, ys, v2);
+        aug_warp_pixel(sm.tiles + 4, sm.minv + 6, sm.canvas, xs, ys, v2);
         const double r = sm.mix_ratio;
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = (int)((double)v[c] * r + (double)v2[c] * (1.0 - r));

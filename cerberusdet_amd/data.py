@@ -144,7 +144,8 @@ class TaskDataset:
             bidx = np.concatenate([np.full(len(lb), j, np.float32) for j, lb in enumerate(lab)], 0)
             yield {"img": img, "cls": cat(slice(0, 1), 1), "prob": cat(slice(1, 2), 1), "bboxes": cat(slice(2, 6), 4),
                    "batch_idx": torch.from_numpy(bidx).to(self.device), "im_file": tuple(self.files[int(i)] for i in ids),
-                   "ori_shape": tuple(None for _ in ids), "ratio_pad": tuple(None for _ in ids)}
+                   "ori_shape": tuple((p.mosaics[0].shapes[0] if p.mosaics[0].shapes else None) for p in plans),
+                   "ratio_pad": tuple((p.mosaics[0].shapes[1] if p.mosaics[0].shapes else None) for p in plans)}
 
     def __iter__(self):
         from PIL import Image

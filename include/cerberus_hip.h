@@ -233,6 +233,8 @@ typedef struct {
     double mix_ratio;              /* weight of mosaic 0 (np.random.beta(32, 32))                      */
     int32_t n_mosaic;              /* 1, or 2 with mixup                                               */
     int32_t flipud, fliplr, use_hsv;
+    int32_t canvas;                /* side of the square the tiles sit on: 2s (mosaic) or s (one letterboxed image, tile 0 only) */
+    int32_t reserved;
     uint8_t lut[768];              /* augment_hsv's hue / sat / val lookup tables                      */
 } cdet_aug_sample;
 int cdet_mosaic_augment_batch(const cdet_aug_sample* samples, int32_t B, void* out_u8_nchw, int32_t s, void* stream);

@@ -20,13 +20,12 @@ def resized_hw(hw0, s):  # datasets.py:470-477
     return (int(h0 * r), int(w0 * r)) if r != 1 else (h0, w0)
 
 
-def build_canvas(tiles, images, s):
-    """load_mosaic's img4: tiles = [(index, (x1a, y1a, x2a, y2a), (x1b, y1b))], images[index] uint8 HWC BGR originals."""
-    img4 = np.full((2 * s, 2 * s, 3), 114, np.uint8)
-    for idx, (x1a, y1a, x2a, y2a), (x1b, y1b) in tiles:
-        im = images[idx]
-        h, w = resized_hw(im.shape[:2], s)
-        im = resize_linear_u8(im, (w, h))
+def build_canvas(tiles, images, canvas):
+    """load_mosaic's img4 (canvas = 2s), or the letterboxed single image (canvas = s: letterbox's border colour is the same 114):
+    tiles = [(index, (h, w) after the resize, (x1a, y1a, x2a, y2a), (x1b, y1b))], images[index] uint8 HWC BGR originals."""
+    img4 = np.full((canvas, canvas, 3), 114, np.uint8)
+    for idx, (h, w), (x1a, y1a, x2a, y2a), (x1b, y1b) in tiles:
+        im = resize_linear_u8(images[idx], (w, h))
         img4[y1a:y2a, x1a:x2a] = im[y1b:y1b + (y2a - y1a), x1b:x1b + (x2a - x1a)]
     return img4
 
@@ -109,8 +108,8 @@ def augment_hsv(im, lut):
 
 
 def render(mosaics, mix_ratio, lut, flipud, fliplr, images, s):
-    """mosaics: [(tiles, M)] (one, or two with mixup) -> uint8 [3, s, s] RGB exactly as `__getitem__` returns it."""
-    ims = [warp_affine_u8(build_canvas(tiles, images, s), M, (s, s)) for tiles, M in mosaics]
+    """mosaics: [(tiles, M, canvas)] (one, or two with mixup) -> uint8 [3, s, s] RGB exactly as `__getitem__` returns it."""
+    ims = [warp_affine_u8(build_canvas(tiles, images, canvas), M, (s, s)) for tiles, M, canvas in mosaics]
     im = ims[0]
     if len(ims) > 1:
         im = (im * mix_ratio + ims[1] * (1 - mix_ratio)).astype(np.uint8)

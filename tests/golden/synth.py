@@ -242,6 +242,7 @@ _AUG_HYP = dict(hsv_h=0.0124, hsv_s=0.696, hsv_v=0.287, degrees=0.299, translate
 AUG_CASES = {
     "hyp_default": dict(seed=41, n=12, s=640, samples=12, hyp=_AUG_HYP),
     "rotate_flip_mix": dict(seed=42, n=9, s=320, samples=10, hyp=dict(_AUG_HYP, degrees=10.0, shear=5.0, flipud=0.5, mixup=0.7, scaleup=0.6)),
+    "half_mosaic": dict(seed=44, n=8, s=192, samples=10, hyp=dict(_AUG_HYP, mosaic=0.5, degrees=5.0)),  # both branches of __getitem__
     "no_hsv_no_mix": dict(seed=43, n=6, s=256, samples=6, hyp=dict(_AUG_HYP, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, mixup=0.0, fliplr=0.0, flipud=0.0)),
 }
 

@@ -34,6 +34,14 @@ def test_parameters_and_labels_equal_the_reference(name):
                 (x1a, y1a, x2a, y2a), (x1b, y1b) = t.dst, t.src
                 assert 0 <= x1a <= x2a <= 2 * c["s"] and 0 <= y1a <= y2a <= 2 * c["s"]
                 assert 0 <= x1b and x1b + (x2a - x1a) <= t.hw[1] and 0 <= y1b and y1b + (y2a - y1a) <= t.hw[0]
+        if want.get("shapes") is None:
+            assert plan.mosaics[0].shapes is None and plan.mosaics[0].canvas == 2 * c["s"]
+        else:  # the single-image branch: the reference's `shapes` entry, and letterbox's integer border = where the tile sits
+            (h0, w0), ((rh, rw), (dw, dh)) = plan.mosaics[0].shapes
+            assert [[h0, w0], [[rh, rw], [dw, dh]]] == want["shapes"] and plan.mosaics[0].canvas == c["s"] and len(plan.mosaics) == 1
+            t = plan.mosaics[0].tiles[0]
+            top, bottom, left, right = want["border"][0]
+            assert t.dst == (left, top, c["s"] - right, c["s"] - bottom) and t.src == (0, 0)
         if want["lut"] is None:
             assert plan.hsv_lut is None
         else:

@@ -40,7 +40,7 @@ def test_rendered_batch_equals_the_numpy_restatement(name):
     assert got.shape == (len(plans), 3, c["s"], c["s"]) and got.dtype == np.uint8
     n_mix = n_flip = 0
     for k, p in enumerate(plans):
-        mos = [([(t.index, t.dst, t.src) for t in m.tiles], m.M) for m in p.mosaics]
+        mos = [([(t.index, t.hw, t.dst, t.src) for t in m.tiles], m.M, m.canvas) for m in p.mosaics]
         want = OA.render(mos, p.mix_ratio, p.hsv_lut, p.flipud, p.fliplr, images, c["s"])
         bad = got[k] != want
         assert not bad.any(), f"{name} sample {k}: {int(bad.sum())} of {bad.size} bytes differ, max |diff| {np.abs(got[k].astype(int) - want.astype(int)).max()}"

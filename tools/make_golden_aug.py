@@ -53,6 +53,16 @@ def _install_cv2():
         REC.setdefault("lut", []).append(np.asarray(lut).astype(int).tolist())
         return ch
 
+    def copyMakeBorder(im, top, bottom, left, right, kind, value=None):
+        REC.setdefault("border", []).append([int(top), int(bottom), int(left), int(right)])
+        return np.zeros((im.shape[0] + top + bottom, im.shape[1] + left + right, 3), np.uint8)
+
+    def resize(im, dsize, interpolation=None):
+        REC.setdefault("resize", []).append([int(dsize[0]), int(dsize[1])])
+        return np.zeros((dsize[1], dsize[0], 3), np.uint8)
+
+    cv2.copyMakeBorder, cv2.resize = copyMakeBorder, resize
+    cv2.BORDER_CONSTANT, cv2.INTER_LINEAR, cv2.INTER_AREA = 0, 1, 3
     cv2.getRotationMatrix2D = getRotationMatrix2D
     cv2.warpAffine = warpAffine
     cv2.LUT = LUT
@@ -84,8 +94,9 @@ def main():
             REC.clear()
             index = (7 * k + 3) % c["n"]
             img, labels_out, path, shapes = LoadImagesAndLabels.__getitem__(fake, index)
-            assert shapes is None and tuple(img.shape) == (3, c["s"], c["s"])
+            assert tuple(img.shape) == (3, c["s"], c["s"])
             samples.append(dict(index=index, M=REC.get("M", []), lut=REC.get("lut"), labels=labels_out[:, 1:].numpy().astype(np.float64).tolist(),
+                                shapes=None if shapes is None else [list(shapes[0]), [list(shapes[1][0]), list(shapes[1][1])]], border=REC.get("border"),
                                 draws_after=[random.random(), float(np.random.uniform())]))
         cases[name] = samples
         print(name, [len(sm["labels"]) for sm in samples], [len(sm["M"]) for sm in samples])
