@@ -8,8 +8,9 @@ Here the host only decodes the files (PIL) and parses the labels; resize + borde
 (csrc/preprocess.hip, the same kernel CerberusPreprocessor uses, uint8 output) and the batch is born on the GPU.
 
 Dataset YAML = the reference's (data/voc_obj365_animals.yaml): `train` / `val`: one image directory (or .txt list) per task,
-`nc`, `names`, `task_ids`. Label files sit next to the images with /images/ replaced by /labels/ (datasets.py:90-103); a row is
-`cls x y w h` or `cls prob x y w h` (datasets.py:654-666).
+`nc`, `names`, `task_ids`. Label files sit next to the images with /images/ replaced by /labels/ (datasets.py:90-103): txt rows
+`cls x y w h` (datasets.py:654-666), or with --labels-from-xml the reference's annotation XML incl. the per-box votes of other classes
+(--use-multi-labels / --use-soft-labels, datasets.py:545-618).
 
 `augment=True` (train.py --augment): the reference's training augmentation -- mosaic of four images, random affine, mixup, HSV, flips
 (data/datasets.py:361-438, 483-542; data/augmentations.py:43-211) -- with every random draw and the label geometry on the host
@@ -31,10 +32,10 @@ from .cerberusdet_preprocessor import letterbox_geometry
 IMG_EXT = {".bmp", ".jpg", ".jpeg", ".png", ".tif", ".tiff", ".webp"}
 
 
-def img2label_path(image_path: str) -> str:
-    """reference data/datasets.py:90-103 (txt labels)."""
+def img2label_path(image_path: str, use_xml: bool = False) -> str:
+    """reference data/datasets.py:90-103: /images/ -> /labels/, .txt or (--labels-from-xml) .xml."""
     sa, sb = os.sep + "images" + os.sep, os.sep + "labels" + os.sep
-    return sb.join(str(Path(image_path).with_suffix(".txt")).rsplit(sa, 1))
+    return sb.join(str(Path(image_path).with_suffix(".xml" if use_xml else ".txt")).rsplit(sa, 1))
 
 
 def list_images(path: str) -> List[str]:
@@ -50,21 +51,75 @@ def list_images(path: str) -> List[str]:
     return files
 
 
-def read_labels(label_path: str, nc: int) -> np.ndarray:
-    """-> [n, 6] float32 (cls, prob, x, y, w, h), duplicates removed; missing file = background image (datasets.py:654-680)."""
+def xml_annotation(label_path: str) -> dict:
+    """The reference's annotation XML (datasets.py:545-586 xml_jsonify): size, and per <object> its name, integer-truncated box and the
+    optional <minors> votes of other classes."""
+    import xml.etree.ElementTree as ET
+
+    root = ET.parse(label_path).getroot()
+    ann = dict(width=int(root.find("size").find("width").text), height=int(root.find("size").find("height").text), bounding_boxes=[])
+    for obj in root.findall("object"):
+        bbox, minors = obj.find("bndbox"), obj.find("minors")
+        ann["bounding_boxes"].append(dict(
+            cls=obj.find("name").text, x_min=int(float(bbox.find("xmin").text)), y_min=int(float(bbox.find("ymin").text)),
+            x_max=int(float(bbox.find("xmax").text)), y_max=int(float(bbox.find("ymax").text)),
+            # (`if minors` in the reference: an Element without children is falsy)
+            minors={x.find("name").text: int(x.find("votes").text) for x in minors} if minors is not None and len(minors) else None))
+    return ann
+
+
+def labels_from_annotation(ann: dict, classnames: Sequence[str], as_multi_label: bool, as_soft_label: bool) -> np.ndarray:
+    """datasets.py:589-618 convert_to_lb: one row per (box, class) -- the main class, plus the minor classes with --use-multi-labels;
+    prob = share of the annotators' votes with --use-soft-labels, else 1."""
+    lb = []
+    for bb in ann["bounding_boxes"]:
+        cx = (bb["x_max"] + bb["x_min"]) / 2 / ann["width"]
+        cy = (bb["y_max"] + bb["y_min"]) / 2 / ann["height"]
+        w = (bb["x_max"] - bb["x_min"]) / ann["width"]
+        h = (bb["y_max"] - bb["y_min"]) / ann["height"]
+        votes = dict(bb["minors"]) if bb["minors"] else {}
+        if bb["cls"] not in votes:  # the main class without a vote count of its own: one more than all minors together
+            votes[bb["cls"]] = sum(votes.values()) + 1
+        if as_soft_label:
+            tot = sum(votes.values())
+            votes = {k: v / tot for k, v in votes.items()}
+        else:
+            votes = {k: 1 for k in votes}
+        if not as_multi_label:
+            votes = {k: v for k, v in votes.items() if k == bb["cls"]}
+        for c, p in votes.items():
+            lb.append([classnames.index(c), p, cx, cy, w, h])
+    return np.array(lb, dtype=np.float32)
+
+
+def read_labels(label_path: str, nc: int, use_xml: bool = False, classnames: Optional[Sequence[str]] = None, as_multi_label: bool = False,
+                as_soft_label: bool = False) -> np.ndarray:
+    """-> [n, 6] float32 (cls, prob, x, y, w, h); missing file = background image. The label half of verify_image_label
+    (datasets.py:621-690): txt rows are `cls x y w h` (a probability column of 1.0 is inserted; rows with more columns are an "Invalid
+    annotation file"), XML files go through xml_annotation / labels_from_annotation; values must be >= 0 and coordinates <= 1; duplicate rows
+    are removed the way the reference does it (np.unique's sorted order, only when there ARE duplicates)."""
     if not os.path.isfile(label_path):
         return np.zeros((0, 6), np.float32)
-    rows = [ln.split() for ln in Path(label_path).read_text().strip().splitlines() if ln.strip()]
-    if not rows:
+    if use_xml:
+        assert classnames is not None, "XML labels name their classes: the dataset YAML needs `names`"
+        lb = labels_from_annotation(xml_annotation(label_path), list(classnames), as_multi_label, as_soft_label)
+    else:
+        rows = [ln.split() for ln in Path(label_path).read_text().strip().splitlines() if len(ln)]
+        if any(len(r) == 5 for r in rows):
+            rows = [[r[0], "1.0", *r[1:]] for r in rows]
+        elif any(len(r) > 5 for r in rows):
+            raise ValueError("Invalid annotation file")
+        lb = np.array(rows, dtype=np.float32)
+    if not len(lb):
         return np.zeros((0, 6), np.float32)
-    rows = [[r[0], "1.0"] + r[1:] if len(r) == 5 else r for r in rows]
-    lb = np.array(rows, np.float32)
-    assert lb.shape[1] == 6, f"{label_path}: labels require 5 or 6 columns each"
-    assert (lb[:, [0, 2, 3, 4, 5]] >= 0).all(), f"{label_path}: negative label values"
-    assert (lb[:, 2:] <= 1).all(), f"{label_path}: non-normalized or out of bounds coordinates"
-    assert lb[:, 0].max() < nc, f"{label_path}: class {int(lb[:, 0].max())} exceeds nc = {nc}"
-    _, keep = np.unique(lb, axis=0, return_index=True)
-    return lb[np.sort(keep)]
+    assert lb.ndim == 2 and lb.shape[1] == 6, "labels require 6 columns each"
+    assert (lb >= 0).all(), "negative labels"
+    assert (lb[:, 2:] <= 1).all(), "non-normalized or out of bounds coordinate labels"
+    assert lb[:, 0].max() < nc, f"class {int(lb[:, 0].max())} exceeds nc = {nc}"
+    _, i = np.unique(lb, axis=0, return_index=True)
+    if len(i) < len(lb):
+        lb = lb[i]
+    return lb
 
 
 def letterbox_labels(lb_xywhn: np.ndarray, shape_hw, imgsz: int):
@@ -91,9 +146,19 @@ class TaskDataset:
     """Iterable over one task's batches for one rank; `len()` = batches per epoch. Every `iter()` starts a new epoch."""
 
     def __init__(self, path: str, imgsz: int, batch_size: int, nc: int, device, rank: int = 0, world_size: int = 1, shuffle: bool = True,
-                 seed: int = 0, augment: bool = False, hyp: Optional[dict] = None):
-        self.files = list_images(path)
-        self.labels = [read_labels(img2label_path(f), nc) for f in self.files]
+                 seed: int = 0, augment: bool = False, hyp: Optional[dict] = None, labels_from_xml: bool = False, classnames=None,
+                 use_multi_labels: bool = False, use_soft_labels: bool = False):
+        self.files, self.labels = [], []
+        for f in list_images(path):  # like verify_image_label: an image whose label file does not verify is left out with a warning
+            try:
+                lb = read_labels(img2label_path(f, labels_from_xml), nc, labels_from_xml, classnames, use_multi_labels, use_soft_labels)
+            except Exception as e:  # noqa: BLE001
+                print(f"WARNING: Ignoring corrupted image and/or label {f}: {e}")
+                continue
+            self.files.append(f)
+            self.labels.append(lb)
+        if not self.files:
+            raise FileNotFoundError(f"no usable image / label pair under {path}")
         self.imgsz, self.bs, self.nc, self.device = imgsz, batch_size, nc, torch.device(device)
         self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
         self.augment = augment
@@ -186,7 +251,8 @@ class TaskDataset:
 
 
 def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: Sequence[int], imgsz: int, device="cuda", rank: int = 0,
-                       world_size: int = 1, augment: bool = False, hyp: Optional[dict] = None):
+                       world_size: int = 1, augment: bool = False, hyp: Optional[dict] = None, labels_from_xml: bool = False,
+                       use_multi_labels: bool = False, use_soft_labels: bool = False):
     """-> (train {task: TaskDataset}, val {task: TaskDataset} (rank 0 validates, unsharded), names {task: [str]})."""
     import yaml
 
@@ -199,8 +265,11 @@ def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: S
     def res(p):
         return str(p if os.path.isabs(p) else root / p)
 
-    train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i, augment=augment, hyp=hyp)
-             for i, t in enumerate(ids)}
-    val = {t: TaskDataset(res(d["val"][i]), imgsz, bs[i], nc[i], device, 0, 1, shuffle=False) for i, t in enumerate(ids)} if d.get("val") else None
     names = {t: [str(n) for n in d["names"][i]] for i, t in enumerate(ids)} if d.get("names") else None
+    lab = dict(labels_from_xml=labels_from_xml, use_multi_labels=use_multi_labels, use_soft_labels=use_soft_labels)
+    cn = (lambda t: names[t] if names else None)  # noqa: E731
+    train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i, augment=augment, hyp=hyp,
+                            classnames=cn(t), **lab) for i, t in enumerate(ids)}
+    val = ({t: TaskDataset(res(d["val"][i]), imgsz, bs[i], nc[i], device, 0, 1, shuffle=False, classnames=cn(t), **lab) for i, t in enumerate(ids)}
+           if d.get("val") else None)
     return train, val, names

@@ -51,6 +51,9 @@ def parse_opt(known=False):
     p.add_argument("--resume", nargs="?", const=True, default=False)
     p.add_argument("--nosave", action="store_true")
     p.add_argument("--noval", action="store_true", help="only validate the final epoch")
+    p.add_argument("--use-multi-labels", action="store_true", help="Loading multiple labels for boxes, if available")
+    p.add_argument("--use-soft-labels", action="store_true", help="Class probability based on annotation votes")
+    p.add_argument("--labels-from-xml", action="store_true", help="Load labels from xml files")
     p.add_argument("--augment", action="store_true", help="--data <yaml>: the reference's training augmentation (mosaic, random affine, mixup, HSV, "
                    "flips; hyper-parameters from --hyp), rendered on the GPU (cerberusdet_amd/augment.py)")
     p.add_argument("--device", default="")
@@ -156,7 +159,10 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
             from cerberusdet_amd import data as cdata
 
             train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE,
-                                                                           augment=getattr(opt, "augment", False), hyp=hyp)
+                                                                           augment=getattr(opt, "augment", False), hyp=hyp,
+                                                                           labels_from_xml=getattr(opt, "labels_from_xml", False),
+                                                                           use_multi_labels=getattr(opt, "use_multi_labels", False),
+                                                                           use_soft_labels=getattr(opt, "use_soft_labels", False))
             val_dataset = val_dataset if val_dataset is not None else val_dataset_y
             nb = max(len(d) for d in train_dataset.values())
     else:

@@ -29,12 +29,38 @@ def test_discovery_and_label_parsing(tmp_path):
     files = list_images(str(tmp_path / "images"))
     assert [f.rsplit("/", 1)[1] for f in files] == ["1.jpg", "2.png"]
     lp = img2label_path(files[0])
-    assert lp == str(tmp_path / "labels" / "a" / "1.txt")
-    open(lp, "w").write("3 0.5 0.5 0.2 0.2\n1 0.7 0.25 0.25 0.1 0.1\n3 0.5 0.5 0.2 0.2\n")
+    assert lp == str(tmp_path / "labels" / "a" / "1.txt") and img2label_path(files[0], use_xml=True).endswith("/labels/a/1.xml")
+    open(lp, "w").write("3 0.5 0.5 0.2 0.2\n1 0.25 0.25 0.1 0.1\n")
     lb = read_labels(lp, 20)
-    assert lb.shape == (2, 6) and lb[0].tolist() == pytest.approx([3, 1.0, 0.5, 0.5, 0.2, 0.2]) and lb[1][1] == pytest.approx(0.7)
+    assert lb.shape == (2, 6) and lb[0].tolist() == pytest.approx([3, 1.0, 0.5, 0.5, 0.2, 0.2])
     assert read_labels(img2label_path(files[1]), 20).shape == (0, 6)  # background image
     with pytest.raises(AssertionError):
         read_labels(lp, 3)  # class id beyond nc
     with pytest.raises(FileNotFoundError):
         list_images(str(tmp_path / "labels" / "a" / "none"))
+
+
+def test_label_files_like_the_reference_verifier(tmp_path):
+    """tests/golden/labels.json = the real reference's verify_image_label (data/datasets.py:621-690) on the same label texts: accepted
+    rows (incl. the sorted order np.unique leaves when duplicates were removed) or rejection (the reference then drops the image)."""
+    import json
+    from pathlib import Path
+
+    g = json.load(open(Path(__file__).parent / "golden" / "labels.json"))
+    for name, text in g["txt"].items():
+        f = tmp_path / f"{name}.txt"
+        f.write_text(text)
+        want = g["txt_cases"][name]
+        if want is None:
+            with pytest.raises(Exception):
+                read_labels(str(f), 20)
+        else:
+            got = read_labels(str(f), 20)
+            assert got.dtype == np.float32 and np.array_equal(got, np.array(want, np.float32).reshape(-1, 6)), name
+    x = tmp_path / "a.xml"
+    x.write_text(g["xml"])
+    for multi in (False, True):
+        for soft in (False, True):
+            got = read_labels(str(x), 3, use_xml=True, classnames=g["names"], as_multi_label=multi, as_soft_label=soft)
+            want = np.array(g["xml_cases"][f"multi{int(multi)}_soft{int(soft)}"], np.float32)
+            assert np.array_equal(got, want), (multi, soft, got, want)
