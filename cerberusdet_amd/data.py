@@ -15,7 +15,9 @@ Dataset YAML = the reference's (data/voc_obj365_animals.yaml): `train` / `val`: 
 `augment=True` (train.py --augment): the reference's training augmentation -- mosaic of four images, random affine, mixup, HSV, flips
 (data/datasets.py:361-438, 483-542; data/augmentations.py:43-211) -- with every random draw and the label geometry on the host
 (cerberusdet_amd/augment.py, pinned against the reference's own functions) and the pixels rendered by ONE kernel per batch straight from
-the decoded originals (csrc/augment.hip). Not reproduced: the label cache, BalancedBatchSampler, Albumentations, rectangular batches.
+the decoded originals (csrc/augment.hip). Training loaders draw their epoch with the reference's class-balanced sampler (`balanced_order`).
+Not reproduced: the label cache, Albumentations, rectangular batches, torch's own randperm inside DistributedSampler (a numpy permutation
+shards the balanced draw over the ranks).
 Shards: rank r takes samples r, r + world, ... of the (per-epoch, seeded) permutation, like a DistributedSampler.
 """
 from __future__ import annotations
@@ -142,12 +144,46 @@ def letterbox_labels(lb_xywhn: np.ndarray, shape_hw, imgsz: int):
     return out, ((h0, w0), ((h / h0, w / w0), (dw, dh))), (new_w, new_h, top, left)
 
 
+def balanced_order(labels: Sequence[np.ndarray], nprng: np.random.RandomState) -> np.ndarray:
+    """One epoch of the reference's BalancedBatchSampler(class_choice="least_sampled") (data/samplers.py:9-101; train.py:95 turns it on for
+    every training loader): len(dataset) draws; each picks the class with the fewest sampled labels so far -- ties at random, the first class
+    of the table twice as likely as the others, as the reference's tie list is built -- then an image of that class at random, and counts
+    all labels of the chosen image. Images without labels are never drawn. Same draws as the reference for the same generator state
+    (tests/golden/sampler.json)."""
+    per_image = [list(map(int, lb[:, 0].tolist())) for lb in labels]
+    class_indices: Dict[int, List[int]] = {}
+    for idx, cls in enumerate(per_image):
+        for c in cls:
+            class_indices.setdefault(c, []).append(idx)
+    if not class_indices:
+        return np.arange(len(labels))
+    classes = list(class_indices)
+    counts = {c: 0 for c in classes}
+    out = []
+    for _ in range(len(labels)):
+        first = classes[0]
+        lo, ties = counts[first], [first]
+        for c in classes:
+            if counts[c] < lo:
+                lo, ties = counts[c], [c]
+            if counts[c] == lo:
+                ties.append(c)
+        cls = ties[nprng.randint(0, len(ties))]
+        pool = class_indices[cls]
+        pick = pool[nprng.randint(0, len(pool))]
+        for c in per_image[pick]:
+            counts[c] += 1
+        out.append(pick)
+    return np.array(out, np.int64)
+
+
 class TaskDataset:
     """Iterable over one task's batches for one rank; `len()` = batches per epoch. Every `iter()` starts a new epoch."""
 
     def __init__(self, path: str, imgsz: int, batch_size: int, nc: int, device, rank: int = 0, world_size: int = 1, shuffle: bool = True,
                  seed: int = 0, augment: bool = False, hyp: Optional[dict] = None, labels_from_xml: bool = False, classnames=None,
-                 use_multi_labels: bool = False, use_soft_labels: bool = False):
+                 use_multi_labels: bool = False, use_soft_labels: bool = False, balanced: bool = False):
+        self.balanced = balanced
         self.files, self.labels = [], []
         for f in list_images(path):  # like verify_image_label: an image whose label file does not verify is left out with a warning
             try:
@@ -180,7 +216,13 @@ class TaskDataset:
 
     def _order(self):
         n = len(self.files)
-        idx = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        if self.balanced:  # the class-balanced draw of the epoch, then (like DistributedSamplerWrapper) a shuffle of ITS positions over the ranks
+            rs = np.random.RandomState(self.seed * 7919 + self.epoch)
+            idx = balanced_order(self.labels, rs)
+            if self.world > 1:
+                idx = idx[rs.permutation(len(idx))]
+        else:
+            idx = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
         pad = (-n) % self.world  # pad by wrapping so that every rank sees the same number of samples
         idx = np.concatenate((idx, idx[:pad])) if pad else idx
         return idx[self.rank::self.world]
@@ -269,7 +311,7 @@ def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: S
     lab = dict(labels_from_xml=labels_from_xml, use_multi_labels=use_multi_labels, use_soft_labels=use_soft_labels)
     cn = (lambda t: names[t] if names else None)  # noqa: E731
     train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i, augment=augment, hyp=hyp,
-                            classnames=cn(t), **lab) for i, t in enumerate(ids)}
+                            classnames=cn(t), balanced=True, **lab) for i, t in enumerate(ids)}  # (train.py:95 balanced_sampler=True)
     val = ({t: TaskDataset(res(d["val"][i]), imgsz, bs[i], nc[i], device, 0, 1, shuffle=False, classnames=cn(t), **lab) for i, t in enumerate(ids)}
            if d.get("val") else None)
     return train, val, names

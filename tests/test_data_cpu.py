@@ -64,3 +64,25 @@ def test_label_files_like_the_reference_verifier(tmp_path):
             got = read_labels(str(x), 3, use_xml=True, classnames=g["names"], as_multi_label=multi, as_soft_label=soft)
             want = np.array(g["xml_cases"][f"multi{int(multi)}_soft{int(soft)}"], np.float32)
             assert np.array_equal(got, want), (multi, soft, got, want)
+
+
+def test_balanced_sampler_draws_like_the_reference():
+    """tests/golden/sampler.json = the real reference's BalancedBatchSampler (data/samplers.py:9-101, np.random seeded) on the same label table:
+    identical sequence of image indices for the same generator state, images without labels never drawn."""
+    import json
+    from pathlib import Path
+
+    from cerberusdet_amd.data import balanced_order
+
+    g = json.load(open(Path(__file__).parent / "golden" / "sampler.json"))
+    labels = [np.concatenate((np.array(c, np.float32).reshape(-1, 1), np.ones((len(c), 5), np.float32)), 1) for c in g["table"]]
+    empty = {i for i, c in enumerate(g["table"]) if not c}
+    for seed, want in enumerate(g["epochs"]):
+        got = balanced_order(labels, np.random.RandomState(seed)).tolist()
+        assert got == want and len(got) == len(labels) and not (set(got) & empty)
+    per_class = np.zeros(8)
+    for i in g["epochs"][0]:
+        for c in g["table"][i]:
+            per_class[c] += 1
+    present = per_class[per_class > 0]
+    assert present.max() <= 4 * present.min()  # the point of the sampler: rare classes are drawn about as often as frequent ones

@@ -58,6 +58,24 @@ def main():
             (td / "t.txt").write_text(text)
             r = verify_image_label((str(td / "a.png"), str(td / "t.txt")), "", False, NAMES, False, False)
             out["txt_cases"][name] = None if r[1] is None else r[1].astype(np.float64).tolist()
+    # the class-balanced sampler (data/samplers.py:9-101) on a small label table, seeded
+    from cerberusdet.data.samplers import BalancedBatchSampler
+
+    rng = np.random.RandomState(5)
+    table = []
+    for i in range(40):
+        k = int(rng.randint(0, 4))
+        cls = rng.choice([0, 0, 0, 1, 1, 2, 5, 7], k)
+        table.append(np.concatenate((cls[:, None].astype(np.float32), np.ones((k, 5), np.float32)), 1).reshape(-1, 6))
+    class _DS(list):  # len() + .indices + .labels
+        indices, labels = range(len(table)), table
+
+    ds = _DS(table)
+    epochs = []
+    for seed in (0, 1):
+        np.random.seed(seed)
+        epochs.append([int(i) for i in BalancedBatchSampler(ds)])
+    json.dump(dict(table=[t[:, 0].astype(int).tolist() for t in table], epochs=epochs), open(OUT / "sampler.json", "w"))
     json.dump(out, open(OUT / "labels.json", "w"), indent=1)
     print({k: (None if v is None else len(v)) for k, v in out["txt_cases"].items()}, {k: len(v) for k, v in out["xml_cases"].items()})
 
