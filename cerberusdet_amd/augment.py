@@ -1,4 +1,4 @@
-"""Training-time augmentation for `train.py --data <yaml> --augment`: mosaic + random affine + mixup + HSV + flips.
+"""Training-time augmentation for `train.py --data <yaml>` (default; `--no-augment` turns it off): mosaic + random affine + mixup + HSV + flips.
 
 What the reference does per sample on CPU workers with cv2 (data/datasets.py:361-438 `__getitem__`, 483-542 `load_mosaic`;
 data/augmentations.py:43-57 `augment_hsv`, 93-202 `random_perspective`, 205-211 `mixup`, 214-220 `box_candidates`), split in two here:

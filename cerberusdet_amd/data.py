@@ -12,11 +12,12 @@ Dataset YAML = the reference's (data/voc_obj365_animals.yaml): `train` / `val`: 
 `cls x y w h` (datasets.py:654-666), or with --labels-from-xml the reference's annotation XML incl. the per-box votes of other classes
 (--use-multi-labels / --use-soft-labels, datasets.py:545-618).
 
-`augment=True` (train.py --augment): the reference's training augmentation -- mosaic of four images, random affine, mixup, HSV, flips
+`augment=True` (train.py's default; --no-augment turns it off): the reference's training augmentation -- mosaic of four images, random affine, mixup, HSV, flips
 (data/datasets.py:361-438, 483-542; data/augmentations.py:43-211) -- with every random draw and the label geometry on the host
 (cerberusdet_amd/augment.py, pinned against the reference's own functions) and the pixels rendered by ONE kernel per batch straight from
 the decoded originals (csrc/augment.hip). Training loaders draw their epoch with the reference's class-balanced sampler (`balanced_order`).
-Not reproduced: the label cache, Albumentations, rectangular batches, torch's own randperm inside DistributedSampler (a numpy permutation
+Validation loaders are rectangular like the reference's (`rect_batch_shapes`). Not reproduced: the label cache, Albumentations, INTER_AREA
+for shrinking non-augmented images (bilinear here), torch's own randperm inside DistributedSampler (a numpy permutation
 shards the balanced draw over the ranks).
 Shards: rank r takes samples r, r + world, ... of the (per-epoch, seeded) permutation, like a DistributedSampler.
 """
@@ -29,7 +30,6 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .cerberusdet_preprocessor import letterbox_geometry
 
 IMG_EXT = {".bmp", ".jpg", ".jpeg", ".png", ".tif", ".tiff", ".webp"}
 
@@ -124,24 +124,54 @@ def read_labels(label_path: str, nc: int, use_xml: bool = False, classnames: Opt
     return lb
 
 
-def letterbox_labels(lb_xywhn: np.ndarray, shape_hw, imgsz: int):
-    """Normalised xywh of the original image -> normalised xywh of its letterboxed `imgsz` x `imgsz` frame, plus the reference's
-    `shapes` entry ((h0, w0), ((h / h0, w / w0), (dw, dh))) that val uses to map boxes back (datasets.py:395-407, 428)."""
+def letterbox_labels(lb_xywhn: np.ndarray, shape_hw, imgsz: int, frame_hw=None, scaleup: bool = False):
+    """Normalised xywh of the original image -> normalised xywh of its letterboxed frame (`imgsz` x `imgsz`, or the rectangular
+    `frame_hw` of its validation batch), plus the reference's `shapes` entry ((h0, w0), ((h / h0, w / w0), (dw, dh))) that val uses to map
+    boxes back (datasets.py:376-407, 428): load_image brings the long side to imgsz (truncated sizes), letterbox(auto=False,
+    scaleup=augment) pads -- and shrinks once more when the frame is smaller than the resized image."""
     h0, w0 = shape_hw
-    r = imgsz / max(h0, w0)  # load_image (datasets.py:546-560): long side -> imgsz with truncated sizes, then letterbox(auto=False)
+    H, W = (imgsz, imgsz) if frame_hw is None else frame_hw
+    r = imgsz / max(h0, w0)
     h, w = (int(h0 * r), int(w0 * r)) if r != 1 else (h0, w0)
-    new_w, new_h, top, _, left, _ = letterbox_geometry((h, w), (imgsz, imgsz), False, 32)
-    dw, dh = (imgsz - new_w) / 2, (imgsz - new_h) / 2
+    r2 = min(H / h, W / w)
+    if not scaleup:
+        r2 = min(r2, 1.0)
+    new_w, new_h = int(round(w * r2)), int(round(h * r2))
+    dw, dh = (W - new_w) / 2, (H - new_h) / 2
+    top, left = int(round(dh - 0.1)), int(round(dw - 0.1))
     out = lb_xywhn.copy()
     if len(out):
         x, y, bw, bh = (lb_xywhn[:, i] for i in range(4))
-        x1, y1 = new_w * (x - bw / 2) + dw, new_h * (y - bh / 2) + dh
-        x2, y2 = new_w * (x + bw / 2) + dw, new_h * (y + bh / 2) + dh
+        x1, y1 = r2 * w * (x - bw / 2) + dw, r2 * h * (y - bh / 2) + dh
+        x2, y2 = r2 * w * (x + bw / 2) + dw, r2 * h * (y + bh / 2) + dh
         eps = 1e-3
-        x1, x2 = np.clip(x1, 0, imgsz - eps), np.clip(x2, 0, imgsz - eps)
-        y1, y2 = np.clip(y1, 0, imgsz - eps), np.clip(y2, 0, imgsz - eps)
-        out = np.stack(((x1 + x2) / 2 / imgsz, (y1 + y2) / 2 / imgsz, (x2 - x1) / imgsz, (y2 - y1) / imgsz), 1).astype(np.float32)
+        x1, x2 = np.clip(x1, 0, W - eps), np.clip(x2, 0, W - eps)
+        y1, y2 = np.clip(y1, 0, H - eps), np.clip(y2, 0, H - eps)
+        out = np.stack(((x1 + x2) / 2 / W, (y1 + y2) / 2 / H, (x2 - x1) / W, (y2 - y1) / H), 1).astype(np.float32)
     return out, ((h0, w0), ((h / h0, w / w0), (dw, dh))), (new_w, new_h, top, left)
+
+
+def rect_batch_shapes(sizes_hw: Sequence, batch_size: int, imgsz: int, stride: int = 32, pad: float = 0.5):
+    """Rectangular batches of the reference's validation loaders (datasets.py:270-289 with rect=True, pad=0.5; utils/train_utils.py:45-57):
+    images sorted by aspect ratio h / w, every batch gets the smallest stride-multiple frame that holds its images at long side imgsz.
+    -> (order [n], frames [(H, W)] per batch)."""
+    hw = np.array(sizes_hw, dtype=np.float64).reshape(-1, 2)
+    ar = hw[:, 0] / hw[:, 1]
+    order = ar.argsort()
+    ar = ar[order]
+    n = len(ar)
+    bi = np.floor(np.arange(n) / batch_size).astype(int)
+    nb = bi[-1] + 1
+    shapes = [[1, 1]] * nb
+    for i in range(nb):
+        ari = ar[bi == i]
+        mini, maxi = ari.min(), ari.max()
+        if maxi < 1:
+            shapes[i] = [maxi, 1]
+        elif mini > 1:
+            shapes[i] = [1, 1 / mini]
+    frames = np.ceil(np.array(shapes) * imgsz / stride + pad).astype(int) * stride
+    return order, [tuple(int(v) for v in f) for f in frames]
 
 
 def balanced_order(labels: Sequence[np.ndarray], nprng: np.random.RandomState) -> np.ndarray:
@@ -182,8 +212,10 @@ class TaskDataset:
 
     def __init__(self, path: str, imgsz: int, batch_size: int, nc: int, device, rank: int = 0, world_size: int = 1, shuffle: bool = True,
                  seed: int = 0, augment: bool = False, hyp: Optional[dict] = None, labels_from_xml: bool = False, classnames=None,
-                 use_multi_labels: bool = False, use_soft_labels: bool = False, balanced: bool = False):
-        self.balanced = balanced
+                 use_multi_labels: bool = False, use_soft_labels: bool = False, balanced: bool = False, rect: bool = False, stride: int = 32,
+                 pad: float = 0.5):
+        self.balanced, self.rect, self.stride, self.pad = balanced, rect, stride, pad
+        assert not (rect and (augment or shuffle or balanced or world_size > 1)), "rectangular batches are the (unsharded, ordered) validation form"
         self.files, self.labels = [], []
         for f in list_images(path):  # like verify_image_label: an image whose label file does not verify is left out with a warning
             try:
@@ -198,16 +230,23 @@ class TaskDataset:
         self.imgsz, self.bs, self.nc, self.device = imgsz, batch_size, nc, torch.device(device)
         self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
         self.augment = augment
-        if augment:
+        if augment or rect:
             from PIL import Image
 
+            self.sizes = []
+            for f in self.files:  # header reads only: mosaic geometry / batch frames need every image's size before any pixel is decoded
+                with Image.open(f) as im:
+                    self.sizes.append((im.size[1], im.size[0]))
+        if augment:
             from .augment import HYP_DEFAULT
 
             self.hyp = dict(HYP_DEFAULT, **{k: v for k, v in (hyp or {}).items() if k in HYP_DEFAULT})
-            self.sizes = []
-            for f in self.files:  # header reads only: the mosaic geometry needs every image's size before any pixel is decoded
-                with Image.open(f) as im:
-                    self.sizes.append((im.size[1], im.size[0]))
+        self.frames = None
+        if rect:
+            order, self.frames = rect_batch_shapes(self.sizes, batch_size, imgsz, stride, pad)
+            self.files = [self.files[i] for i in order]
+            self.labels = [self.labels[i] for i in order]
+            self.sizes = [self.sizes[i] for i in order]
         per_rank = (len(self.files) + world_size - 1) // world_size
         self.nb = max((per_rank + batch_size - 1) // batch_size, 1)
 
@@ -268,12 +307,13 @@ class TaskDataset:
         S = self.imgsz
         for b0 in range(0, len(order), self.bs):
             ids = order[b0:b0 + self.bs]
+            FH, FW = self.frames[b0 // self.bs] if self.frames is not None else (S, S)
             items = (L.LetterboxItem * len(ids))()
             keep, cls, prob, box, bidx, shapes, files = [], [], [], [], [], [], []
             for j, i in enumerate(ids):
                 im = np.asarray(Image.open(self.files[i]).convert("RGB"))[:, :, ::-1]  # the kernel takes cv2's BGR order
                 lb = self.labels[i]
-                xywh, shp, (new_w, new_h, top, left) = letterbox_labels(lb[:, 2:], im.shape[:2], S)
+                xywh, shp, (new_w, new_h, top, left) = letterbox_labels(lb[:, 2:], im.shape[:2], S, (FH, FW))
                 t = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=True)
                 keep.append(t)
                 it = items[j]
@@ -282,9 +322,9 @@ class TaskDataset:
                 cls.append(lb[:, 0:1]), prob.append(lb[:, 1:2]), box.append(xywh), bidx.append(np.full(len(lb), j, np.float32))
                 shapes.append(shp), files.append(self.files[i])
             tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
-            img = torch.empty((len(ids), 3, S, S), dtype=torch.uint8, device=self.device)
+            img = torch.empty((len(ids), 3, FH, FW), dtype=torch.uint8, device=self.device)
             st = torch.cuda.current_stream(self.device)
-            L.check(lib.cdet_letterbox_batch(tab.data_ptr(), len(ids), img.data_ptr(), S, S, L.U8, 114, st.cuda_stream), "cdet_letterbox_batch")
+            L.check(lib.cdet_letterbox_batch(tab.data_ptr(), len(ids), img.data_ptr(), FH, FW, L.U8, 114, st.cuda_stream), "cdet_letterbox_batch")
             for t in keep + [tab]:
                 t.record_stream(st)
             cat = lambda xs, w: torch.from_numpy(np.concatenate(xs, 0).reshape(-1, w).astype(np.float32)).to(self.device)  # noqa: E731
@@ -312,6 +352,7 @@ def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: S
     cn = (lambda t: names[t] if names else None)  # noqa: E731
     train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i, augment=augment, hyp=hyp,
                             classnames=cn(t), balanced=True, **lab) for i, t in enumerate(ids)}  # (train.py:95 balanced_sampler=True)
-    val = ({t: TaskDataset(res(d["val"][i]), imgsz, bs[i], nc[i], device, 0, 1, shuffle=False, classnames=cn(t), **lab) for i, t in enumerate(ids)}
-           if d.get("val") else None)
+    # validation loaders of the reference: rectangular batches with pad 0.5, the largest task batch size (utils/train_utils.py:45-57)
+    val = ({t: TaskDataset(res(d["val"][i]), imgsz, max(bs), nc[i], device, 0, 1, shuffle=False, classnames=cn(t), rect=True, **lab)
+            for i, t in enumerate(ids)} if d.get("val") else None)
     return train, val, names

@@ -54,8 +54,9 @@ def parse_opt(known=False):
     p.add_argument("--use-multi-labels", action="store_true", help="Loading multiple labels for boxes, if available")
     p.add_argument("--use-soft-labels", action="store_true", help="Class probability based on annotation votes")
     p.add_argument("--labels-from-xml", action="store_true", help="Load labels from xml files")
-    p.add_argument("--augment", action="store_true", help="--data <yaml>: the reference's training augmentation (mosaic, random affine, mixup, HSV, "
-                   "flips; hyper-parameters from --hyp), rendered on the GPU (cerberusdet_amd/augment.py)")
+    p.add_argument("--no-augment", action="store_true", help="--data <yaml>: plain letterboxed images instead of the reference's training augmentation "
+                   "(mosaic, random affine, mixup, HSV, flips with the hyper-parameters of --hyp; the reference always augments its training "
+                   "loaders, utils/train_utils.py:22-29), which is rendered on the GPU (cerberusdet_amd/augment.py)")
     p.add_argument("--device", default="")
     p.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm: per-layer statistics all-reduced over the ranks")
     p.add_argument("--workers", type=int, default=8, help="accepted for CLI compatibility: batches come from the caller's iterables / the synthetic generator")
@@ -159,7 +160,7 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
             from cerberusdet_amd import data as cdata
 
             train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE,
-                                                                           augment=getattr(opt, "augment", False), hyp=hyp,
+                                                                           augment=not getattr(opt, "no_augment", False), hyp=hyp,
                                                                            labels_from_xml=getattr(opt, "labels_from_xml", False),
                                                                            use_multi_labels=getattr(opt, "use_multi_labels", False),
                                                                            use_soft_labels=getattr(opt, "use_soft_labels", False))

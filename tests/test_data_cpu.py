@@ -4,7 +4,7 @@ Expected values were produced by the reference's own xywhn2xyxy / xyxy2xywhn (ut
 import numpy as np
 import pytest
 
-from cerberusdet_amd.data import img2label_path, letterbox_labels, list_images, read_labels
+from cerberusdet_amd.data import img2label_path, letterbox_labels, list_images, read_labels, rect_batch_shapes
 
 
 def test_label_geometry_matches_reference_known_answers():
@@ -86,3 +86,27 @@ def test_balanced_sampler_draws_like_the_reference():
             per_class[c] += 1
     present = per_class[per_class > 0]
     assert present.max() <= 4 * present.min()  # the point of the sampler: rare classes are drawn about as often as frequent ones
+
+
+def test_rectangular_validation_batches_like_the_reference():
+    """tests/golden/rect_val.json = the real reference's LoadImagesAndLabels(rect=True, pad=0.5, augment=False) on PNG files of these sizes
+    (the validation loaders, utils/train_utils.py:45-57): sort order, per-batch frames, and per image the letterboxed labels and the
+    `shapes` entry val uses to map boxes back."""
+    import json
+    from pathlib import Path
+
+    g = json.load(open(Path(__file__).parent / "golden" / "rect_val.json"))
+    order, frames = rect_batch_shapes(g["sizes"], g["batch"], g["imgsz"], 32, 0.5)
+    ar = [h / w for h, w in g["sizes"]]
+    # the sort is by aspect ratio with an unstable argsort: images of EQUAL ratio may swap places (they do between numpy builds), nothing else
+    assert [ar[i] for i in order] == [ar[i] for i in g["order"]] and sorted(order.tolist()) == sorted(g["order"])
+    assert [list(f) for f in frames] == g["batch_shapes"]
+    for i, want in zip(g["order"], g["items"]):
+        rows = np.array(g["label_rows"][i], np.float32).reshape(-1, 5)
+        frame = tuple(want["img_hw"])  # the frame of the batch the reference put this image in
+        got, shp, (new_w, new_h, top, left) = letterbox_labels(rows[:, 1:], tuple(g["sizes"][i]), g["imgsz"], frame)
+        (h0, w0), ((rh, rw), (dw, dh)) = shp
+        assert [[h0, w0], [[rh, rw], [dw, dh]]] == want["shapes"], (i, shp, want["shapes"])
+        ref = np.array(want["labels"], np.float32).reshape(-1, 6)
+        assert len(ref) == len(rows) and (not len(rows) or np.abs(got - ref[:, 2:]).max() < 2e-6), (i, got, ref)
+        assert 0 <= left and left + new_w <= frame[1] and 0 <= top and top + new_h <= frame[0]

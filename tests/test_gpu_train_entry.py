@@ -93,14 +93,20 @@ def test_yolo_txt_dataset_trains_and_validates(tmp_path):
     tr, va, names = datasets_from_yaml(str(root / "data.yaml"), data["task_ids"], [20, 19], [4, 4], 128)
     assert len(tr["voc"]) == 2 and names["voc"][3] == "v3"
     b = next(iter(va["voc"]))
-    assert b["img"].shape == (3, 3, 128, 128) and b["img"].dtype == torch.uint8 and b["img"].is_cuda
+    # validation loaders are rectangular like the reference's (rect=True, pad=0.5): sorted by aspect ratio, one frame per batch --
+    # here the three images span ratios below and above 1, so the frame is the square of ceil(128 / 32 + 0.5) * 32 = 160
+    assert b["img"].shape == (3, 3, 160, 160) and b["img"].dtype == torch.uint8 and b["img"].is_cuda
     assert b["bboxes"].shape[1] == 4 and b["cls"].shape[1] == 1 and b["prob"].shape[1] == 1 and b["batch_idx"].tolist() == [0, 0, 1, 1]
-    assert float(b["bboxes"].min()) >= 0 and float(b["bboxes"].max()) <= 1 and len(b["ori_shape"]) == 3 and b["ori_shape"][0] == (96, 128)
-    assert int(b["img"][0, :, 0, 0].float().mean()) == 114 and int(b["img"][1, 0, 0, 0]) != 114  # 96x128 is letterboxed, 128x128 is not
-    res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds"))
+    assert float(b["bboxes"].min()) >= 0 and float(b["bboxes"].max()) <= 1 and len(b["ori_shape"]) == 3
+    assert b["ori_shape"] == ((96, 128), (128, 128), (120, 80)) and b["ratio_pad"][1][1] == (16.0, 16.0)
+    assert int(b["img"][1, :, 0, 0].float().mean()) == 114 and int(b["img"][1, 0, 16, 16]) != 114  # 128x128 sits at (16, 16) of its 160x160 frame
+    tr_plain = datasets_from_yaml(str(root / "data.yaml"), data["task_ids"], [20, 19], [4, 4], 128, augment=False)[0]
+    bt = next(iter(tr_plain["voc"]))
+    assert bt["img"].shape[1:] == (3, 128, 128)  # training frames stay square
+    res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds", no_augment=True))
     assert epoch == 1 and (tmp_path / "ds" / "weights" / "last.pt").exists()
     assert all(np.isfinite(v) for r in res.values() for v in r)
     # the same with the reference's training augmentation (mosaic / affine / mixup / HSV / flips rendered on the GPU)
-    res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds_aug", augment=True))
+    res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds_aug"))  # the default, as in the reference
     assert epoch == 1 and (tmp_path / "ds_aug" / "weights" / "last.pt").exists()
     assert all(np.isfinite(v) for r in res.values() for v in r)

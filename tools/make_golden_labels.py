@@ -76,6 +76,41 @@ def main():
         np.random.seed(seed)
         epochs.append([int(i) for i in BalancedBatchSampler(ds)])
     json.dump(dict(table=[t[:, 0].astype(int).tolist() for t in table], epochs=epochs), open(OUT / "sampler.json", "w"))
+    # rectangular validation batches (datasets.py:270-289, 376-407 with rect=True, pad=0.5, augment=False) on real files
+    import random
+
+    import cv2  # the stub of make_golden
+
+    from cerberusdet.data.datasets import LoadImagesAndLabels
+
+    rec = {}
+    cv2.imread = lambda path: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    cv2.resize = lambda im, dsize, interpolation=None: np.zeros((dsize[1], dsize[0], 3), np.uint8)
+    cv2.copyMakeBorder = lambda im, t, b, l, r, kind, value=None: np.zeros((im.shape[0] + t + b, im.shape[1] + l + r, 3), np.uint8)
+    cv2.BORDER_CONSTANT, cv2.INTER_LINEAR, cv2.INTER_AREA = 0, 1, 3
+    sizes = [(375, 500), (500, 375), (480, 640), (333, 500), (500, 333), (640, 640), (300, 900), (900, 300), (427, 640), (360, 480), (97, 333)]
+    rect = dict(sizes=sizes, imgsz=256, batch=4, items=[])
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        (td / "images").mkdir()
+        (td / "labels").mkdir()
+        rng = np.random.RandomState(3)
+        labels = []
+        for i, (h, w) in enumerate(sizes):
+            Image.fromarray(np.zeros((h, w, 3), np.uint8)).save(td / "images" / f"{i:02d}.png")
+            k = int(rng.randint(0, 4))
+            rows = [[int(rng.randint(0, 20)), *rng.uniform(0.2, 0.8, 2), *rng.uniform(0.05, 0.3, 2)] for _ in range(k)]
+            labels.append(rows)
+            (td / "labels" / f"{i:02d}.txt").write_text("".join(f"{r[0]} {r[1]:.6f} {r[2]:.6f} {r[3]:.6f} {r[4]:.6f}\n" for r in rows))
+        rect["label_rows"] = labels
+        ds = LoadImagesAndLabels(str(td / "images"), 256, 4, augment=False, hyp=None, rect=True, stride=32, pad=0.5, classnames=[str(i) for i in range(20)])
+        rect["batch_shapes"] = ds.batch_shapes.tolist()
+        rect["order"] = [int(Path(f).stem) for f in ds.img_files]
+        for idx in range(len(ds)):
+            img, lab, path, shapes = ds[idx]
+            rect["items"].append(dict(img_hw=list(img.shape[1:]), labels=lab[:, 1:].numpy().astype(np.float64).tolist(),
+                                      shapes=[list(shapes[0]), [list(shapes[1][0]), list(shapes[1][1])]]))
+    json.dump(rect, open(OUT / "rect_val.json", "w"))
     json.dump(out, open(OUT / "labels.json", "w"), indent=1)
     print({k: (None if v is None else len(v)) for k, v in out["txt_cases"].items()}, {k: len(v) for k, v in out["xml_cases"].items()})
 
