@@ -47,7 +47,7 @@ class PackTiledItem(C.Structure):
 
 
 class LetterboxItem(C.Structure):
-    _fields_ = [("img", vp), ("h", i32), ("w", i32), ("pitch", i32), ("new_w", i32), ("new_h", i32), ("top", i32), ("left", i32)]
+    _fields_ = [("img", vp), ("h", i32), ("w", i32), ("pitch", i32), ("new_w", i32), ("new_h", i32), ("top", i32), ("left", i32), ("area", i32)]
 
 
 class AugTile(C.Structure):

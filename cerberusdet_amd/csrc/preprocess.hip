@@ -25,6 +25,81 @@ __device__ __forceinline__ void lin_coef(int d, double scale, int src, int& s, i
     a1 = (int)rintf(f * 2048.f);
 }
 
+#pragma clang fp contract(off)  // the float32 accumulation of the area resize is compared bit for bit with numpy
+
+// OpenCV computeResizeAreaTab for one destination index: first covered source cell, number of cells, and the weight of cell k
+struct AreaSpan {
+    int s0, n;
+    float a_first, a_mid, a_last;
+    bool has_first, has_last;
+    int mid0, mid1;
+};
+__device__ __forceinline__ AreaSpan area_span(int d, int src, int dst) {
+    const double scale = (double)src / dst;
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, src - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, src - 1);
+    s1 = min(s1, s2);
+    AreaSpan sp;
+    sp.has_first = s1 - f1 > 1e-3;
+    sp.has_last = f2 - s2 > 1e-3;
+    sp.a_first = (float)((s1 - f1) / cell);
+    sp.a_mid = (float)(1.0 / cell);
+    sp.a_last = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+    sp.mid0 = s1;
+    sp.mid1 = s2;
+    return sp;
+}
+
+// pixel (rx, ry) of cv2.resize(img, (new_w, new_h), INTER_AREA), both directions shrinking
+__device__ __forceinline__ void area_pixel(const unsigned char* src, int pitch, int h, int w, int new_h, int new_w, int rx, int ry, int v[3]) {
+    const double sx = (double)w / new_w, sy = (double)h / new_h;
+    const int isx = (int)rint(sx), isy = (int)rint(sy);
+    if (fabs(sx - isx) < 2.220446049250313e-16 && fabs(sy - isy) < 2.220446049250313e-16) {  // integer factors: block average
+        int sum[3] = {0, 0, 0};
+        for (int yy = 0; yy < isy; ++yy) {
+            const unsigned char* p = src + (int64_t)(ry * isy + yy) * pitch + rx * isx * 3;
+            for (int xx = 0; xx < isx; ++xx)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sum[c] += p[xx * 3 + c];
+        }
+        if (isx == 2 && isy == 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (sum[c] + 2) >> 2;
+        } else {
+            const float sc = (float)(1.0 / (isx * isy));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = min(max((int)rintf((float)sum[c] * sc), 0), 255);
+        }
+        return;
+    }
+    const AreaSpan X = area_span(rx, w, new_w), Y = area_span(ry, h, new_h);
+    float out[3] = {0.f, 0.f, 0.f};
+    bool first_row = true;
+    auto row = [&](int yy, float beta) {
+        const unsigned char* p = src + (int64_t)yy * pitch;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (X.has_first)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + (float)p[(X.mid0 - 1) * 3 + c] * X.a_first;
+        for (int xx = X.mid0; xx < X.mid1; ++xx)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + (float)p[xx * 3 + c] * X.a_mid;
+        if (X.has_last)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = acc[c] + (float)p[X.mid1 * 3 + c] * X.a_last;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = first_row ? acc[c] * beta : out[c] + acc[c] * beta;
+        first_row = false;
+    };
+    if (Y.has_first) row(Y.mid0 - 1, Y.a_first);
+    for (int yy = Y.mid0; yy < Y.mid1; ++yy) row(yy, Y.a_mid);
+    if (Y.has_last) row(Y.mid1, Y.a_last);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = min(max((int)rintf(out[c]), 0), 255);
+}
+
 __global__ __launch_bounds__(256) void letterbox_kernel(const cdet_letterbox_item* __restrict__ items, void* __restrict__ out, int B, int H, int W,
                                                         int out_dtype, int pad_value) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,6 +114,8 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const cdet_letterbox_ite
         if (it.new_h == it.h && it.new_w == it.w) {
             const unsigned char* p = src + (int64_t)ry * it.pitch + rx * 3;
             v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+        } else if (it.area && it.new_w <= it.w && it.new_h <= it.h) {
+            area_pixel(src, it.pitch, it.h, it.w, it.new_h, it.new_w, rx, ry, v);
         } else if (it.w == 2 * it.new_w && it.h == 2 * it.new_h) {  // cv::resize: exact 2x shrink -> INTER_AREA
             const unsigned char* p0 = src + (int64_t)(2 * ry) * it.pitch + 2 * rx * 3;
             const unsigned char* p1 = p0 + it.pitch;

@@ -16,8 +16,8 @@ Dataset YAML = the reference's (data/voc_obj365_animals.yaml): `train` / `val`: 
 (data/datasets.py:361-438, 483-542; data/augmentations.py:43-211) -- with every random draw and the label geometry on the host
 (cerberusdet_amd/augment.py, pinned against the reference's own functions) and the pixels rendered by ONE kernel per batch straight from
 the decoded originals (csrc/augment.hip). Training loaders draw their epoch with the reference's class-balanced sampler (`balanced_order`).
-Validation loaders are rectangular like the reference's (`rect_batch_shapes`). Not reproduced: the label cache, Albumentations, INTER_AREA
-for shrinking non-augmented images (bilinear here), torch's own randperm inside DistributedSampler (a numpy permutation
+Validation loaders are rectangular like the reference's (`rect_batch_shapes`); non-augmented images shrink with cv2.INTER_AREA's
+arithmetic like `load_image` does. Not reproduced: the label cache, Albumentations, torch's own randperm inside DistributedSampler (a numpy permutation
 shards the balanced draw over the ranks).
 Shards: rank r takes samples r, r + world, ... of the (per-epoch, seeded) permutation, like a DistributedSampler.
 """
@@ -319,6 +319,7 @@ class TaskDataset:
                 it = items[j]
                 it.img, it.h, it.w, it.pitch = t.data_ptr(), im.shape[0], im.shape[1], im.shape[1] * 3
                 it.new_w, it.new_h, it.top, it.left = new_w, new_h, top, left
+                it.area = 1  # load_image of a non-augmented loader: INTER_AREA when shrinking (the kernel keeps bilinear when enlarging)
                 cls.append(lb[:, 0:1]), prob.append(lb[:, 1:2]), box.append(xywh), bidx.append(np.full(len(lb), j, np.float32))
                 shapes.append(shp), files.append(self.files[i])
             tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)

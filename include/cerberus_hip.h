@@ -210,6 +210,8 @@ typedef struct {
     const void* img;
     int32_t h, w, pitch;
     int32_t new_w, new_h, top, left;
+    int32_t area;                  /* 0: cv2.INTER_LINEAR (letterbox(), the inference pre-processing); 1: cv2.INTER_AREA when the image shrinks
+                                      (load_image of the non-augmented loaders, data/datasets.py:473-476) -- occupies former padding */
 } cdet_letterbox_item;
 int cdet_letterbox_batch(const cdet_letterbox_item* items, int32_t B, void* out_nchw, int32_t H, int32_t W, int32_t out_dtype,
                          int32_t pad_value, void* stream);

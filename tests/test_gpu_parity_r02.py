@@ -216,6 +216,41 @@ def test_gpu_letterbox_preprocess_bit_exact_vs_oracle(half):
     assert tuple(a.shape) == w2.shape == (2, 3, 384, 640) and np.array_equal(a.cpu().numpy(), w2)
 
 
+def test_gpu_letterbox_area_resize_bit_exact_vs_oracle():
+    """cdet_letterbox_batch with `area` set (the non-augmented loaders: load_image shrinks with cv2.INTER_AREA, data/datasets.py:473-476):
+    general and integer shrink factors, the 2x2 case, one direction unchanged, a portrait image, and an ENLARGED image (stays bilinear) in a
+    rectangular frame -- equal to the numpy restatement of OpenCV's resizeArea / resizeAreaFast (oracle/preprocess.py) bit for bit."""
+    import ctypes as C
+
+    from cerberusdet_amd import _lib as L
+    from oracle import preprocess as op
+
+    lib = L.load()
+    rng = np.random.default_rng(4)
+    FH, FW = 224, 288
+    cases = [((300, 411), (150, 206)), ((448, 576), (224, 288)), ((672, 864), (224, 288)), ((224, 500), (224, 270)), ((500, 210), (200, 84)),
+             ((90, 120), (180, 240)), ((333, 777), (120, 280)), ((224, 288), (224, 288))]  # (h, w) -> (new_h, new_w)
+    items = (L.LetterboxItem * len(cases))()
+    keep, want = [], np.full((len(cases), 3, FH, FW), 114, np.uint8)
+    for j, ((h, w), (nh, nw)) in enumerate(cases):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        t = torch.from_numpy(im).to(DEV)
+        keep.append(t)
+        top, left = (FH - nh) // 2, (FW - nw) // 2
+        it = items[j]
+        it.img, it.h, it.w, it.pitch, it.new_w, it.new_h, it.top, it.left, it.area = t.data_ptr(), h, w, w * 3, nw, nh, top, left, 1
+        res = op.resize_area_u8(im, (nw, nh)) if (nw <= w and nh <= h) else op.resize_linear_u8(im, (nw, nh))
+        want[j, :, top:top + nh, left:left + nw] = res.transpose(2, 0, 1)[::-1]
+    tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
+    out = torch.empty((len(cases), 3, FH, FW), dtype=torch.uint8, device=DEV)
+    L.check(lib.cdet_letterbox_batch(tab.data_ptr(), len(cases), out.data_ptr(), FH, FW, L.U8, 114, torch.cuda.current_stream().cuda_stream), "letterbox")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for j, c in enumerate(cases):
+        d = np.abs(got[j].astype(int) - want[j].astype(int))
+        assert d.max() == 0, (c, int((d > 0).sum()), int(d.max()))
+
+
 def test_pad_targets_kernel_matches_oracle_and_counts_overflow():
     """cdet_pad_targets (one kernel, no host sync with n_max given) against the oracle's Loss.preprocess restatement: order inside an
     image, empty images, empty batch; a label beyond n_max is dropped and counted, never written over another one."""
