@@ -213,7 +213,7 @@ class TaskDataset:
     def __init__(self, path: str, imgsz: int, batch_size: int, nc: int, device, rank: int = 0, world_size: int = 1, shuffle: bool = True,
                  seed: int = 0, augment: bool = False, hyp: Optional[dict] = None, labels_from_xml: bool = False, classnames=None,
                  use_multi_labels: bool = False, use_soft_labels: bool = False, balanced: bool = False, rect: bool = False, stride: int = 32,
-                 pad: float = 0.5):
+                 pad: float = 0.5, single_cls: bool = False):
         self.balanced, self.rect, self.stride, self.pad = balanced, rect, stride, pad
         assert not (rect and (augment or shuffle or balanced or world_size > 1)), "rectangular batches are the (unsharded, ordered) validation form"
         self.files, self.labels = [], []
@@ -223,6 +223,8 @@ class TaskDataset:
             except Exception as e:  # noqa: BLE001
                 print(f"WARNING: Ignoring corrupted image and/or label {f}: {e}")
                 continue
+            if single_cls:  # datasets.py:258-260
+                lb[:, 0] = 0
             self.files.append(f)
             self.labels.append(lb)
         if not self.files:
@@ -335,7 +337,7 @@ class TaskDataset:
 
 def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: Sequence[int], imgsz: int, device="cuda", rank: int = 0,
                        world_size: int = 1, augment: bool = False, hyp: Optional[dict] = None, labels_from_xml: bool = False,
-                       use_multi_labels: bool = False, use_soft_labels: bool = False):
+                       use_multi_labels: bool = False, use_soft_labels: bool = False, single_cls: bool = False):
     """-> (train {task: TaskDataset}, val {task: TaskDataset} (rank 0 validates, unsharded), names {task: [str]})."""
     import yaml
 
@@ -349,11 +351,13 @@ def datasets_from_yaml(path: str, tasks: Sequence[str], nc: Sequence[int], bs: S
         return str(p if os.path.isabs(p) else root / p)
 
     names = {t: [str(n) for n in d["names"][i]] for i, t in enumerate(ids)} if d.get("names") else None
-    lab = dict(labels_from_xml=labels_from_xml, use_multi_labels=use_multi_labels, use_soft_labels=use_soft_labels)
-    cn = (lambda t: names[t] if names else None)  # noqa: E731
+    lab = dict(labels_from_xml=labels_from_xml, use_multi_labels=use_multi_labels, use_soft_labels=use_soft_labels, single_cls=single_cls)
+    cn = (lambda t: names[t] if names else None)  # noqa: E731  (the label files' own class names, also with --single-cls)
     train = {t: TaskDataset(res(d["train"][i]), imgsz, bs[i], nc[i], device, rank, world_size, shuffle=True, seed=i, augment=augment, hyp=hyp,
                             classnames=cn(t), balanced=True, **lab) for i, t in enumerate(ids)}  # (train.py:95 balanced_sampler=True)
     # validation loaders of the reference: rectangular batches with pad 0.5, the largest task batch size (utils/train_utils.py:45-57)
     val = ({t: TaskDataset(res(d["val"][i]), imgsz, max(bs), nc[i], device, 0, 1, shuffle=False, classnames=cn(t), rect=True, **lab)
             for i, t in enumerate(ids)} if d.get("val") else None)
+    if single_cls and names:  # utils/models_manager.py:87
+        names = {t: (["item"] if len(v) != 1 else v) for t, v in names.items()}
     return train, val, names

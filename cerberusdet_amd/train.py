@@ -130,7 +130,8 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
     from cerberusdet_amd.trainers import Averaging
 
     tasks = opt.tasks.split(",")
-    nc = [int(v) for v in opt.nc.split(",")]
+    data_nc = [int(v) for v in opt.nc.split(",")]  # classes in the label files
+    nc = [1] * len(data_nc) if opt.single_cls else data_nc  # --single-cls (utils/models_manager.py:84-87): one class "item" per task
     bs = [int(v) for v in str(opt.batch_size).split(",")]
     bs = bs * len(tasks) if len(bs) == 1 else bs
     cfg = yaml.safe_load(open(opt.cfg))
@@ -159,7 +160,8 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
         else:
             from cerberusdet_amd import data as cdata
 
-            train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE,
+            train_dataset, val_dataset_y, names = cdata.datasets_from_yaml(opt.data, tasks, data_nc, bs, opt.imgsz, rank=max(RANK, 0), world_size=WORLD_SIZE,
+                                                                           single_cls=opt.single_cls,
                                                                            augment=not getattr(opt, "no_augment", False), hyp=hyp,
                                                                            labels_from_xml=getattr(opt, "labels_from_xml", False),
                                                                            use_multi_labels=getattr(opt, "use_multi_labels", False),

@@ -108,5 +108,7 @@ def test_yolo_txt_dataset_trains_and_validates(tmp_path):
     assert all(np.isfinite(v) for r in res.values() for v in r)
     # the same with the reference's training augmentation (mosaic / affine / mixup / HSV / flips rendered on the GPU)
     res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds_aug"))  # the default, as in the reference
-    assert epoch == 1 and (tmp_path / "ds_aug" / "weights" / "last.pt").exists()
+    assert epoch == 1 and all(np.isfinite(v) for r in res.values() for v in r)
+    res, epoch = T.run(**_opts(tmp_path, data=str(root / "data.yaml"), name="ds_single", single_cls=True, epochs=1))  # --single-cls: nc = 1 heads
+    assert epoch == 0 and (tmp_path / "ds_single" / "weights" / "last.pt").exists() and (tmp_path / "ds_aug" / "weights" / "last.pt").exists()
     assert all(np.isfinite(v) for r in res.values() for v in r)
