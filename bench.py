@@ -482,6 +482,8 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm across ranks (BASELINE.json configs[2]); default: per-GPU statistics")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference + NMS section (secondary part of the metric)")
+    ap.add_argument("--host-batches", action="store_true", help="secondary measurement: the batches live in pinned HOST memory and are uploaded inside the "
+                    "timed region every step (the PCIe-inclusive rate; `value` proper keeps its inputs resident in HBM)")
     args = ap.parse_args()
     if args.dry_comm:
         print(json.dumps(dry_comm(args)))
@@ -526,6 +528,15 @@ def main():
     n_distinct = min(n_iter, 4)  # a few distinct synthetic batches, resident in HBM, cycled
     data = [{t: synth_batch(rank, ti, i, args.batch, NC[ti], args.imgsz, device) for ti, t in enumerate(TASKS)} for i in range(n_distinct)]
     n_max = 8
+    if args.host_batches:  # what a DataLoader with pin_memory=True hands over (the reference's loaders, data/dataloaders.py:36)
+        host = [{t: {k: v.cpu().pin_memory() for k, v in b.items()} for t, b in d.items()} for d in data]
+        data = None
+
+        class _Up:  # upload on access, so the copy sits inside the timed region of the step that uses it
+            def __getitem__(self, i):
+                return {t: {k: v.to(device, non_blocking=True) for k, v in b.items()} for t, b in host[i].items()}
+
+        data = _Up()
 
     def sync():
         if use_dist:
@@ -564,7 +575,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"YOLOv8x 2-task (VOC nc20 + O365-animals nc19) training iteration, batch {args.batch}/task/GPU @{args.imgsz}, "
                                    "fwd+loss+bwd per task, clip+SGD-nesterov+EMA, bf16 storage / fp32 accumulate",
-                       "cfg": args.cfg, "global_batch": imgs_per_step, "parallelism": f"dp{world}"},
+                       "cfg": args.cfg, "global_batch": imgs_per_step, "parallelism": f"dp{world}",
+                                  **({"inputs": "pinned host memory, uploaded inside every timed step (PCIe-inclusive secondary measurement)"} if args.host_batches else {})},
             "step_tflop_per_gpu": round(step_tflop, 2), "achieved_tflops_per_gpu": round(step_tflop / (ms_per_step / 1e3), 1),
             "loss_items": loss_items, "loss_finite": bool(finite),
         }
