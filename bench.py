@@ -485,8 +485,20 @@ def main():
     ap.add_argument("--host-batches", action="store_true", help="secondary measurement: the batches live in pinned HOST memory and are uploaded inside the "
                     "timed region every step (the PCIe-inclusive rate; `value` proper keeps its inputs resident in HBM)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: everything native libraries print there while the run is on (RCCL's version banner at
+    # communicator creation, for one) goes to stderr instead; the descriptor is restored for the final print
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
     if args.dry_comm:
-        print(json.dumps(dry_comm(args)))
+        emit(dry_comm(args))
         return
 
     rank = int(os.environ.get("RANK", 0))
@@ -504,6 +516,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        os.dup2(real_stdout, 1)  # the children inherit the real stdout (each of them keeps it clean the same way)
         sys.exit(subprocess.run(cmd, env=env).returncode)
     if args.gpus != world:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
@@ -626,7 +639,7 @@ def main():
             out["inference"] = inference_section(model, device)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would just wait at the barrier
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
