@@ -3,11 +3,13 @@ one process per GPU (`python -m torch.distributed.run --nproc-per-node N cerberu
 RANK / WORLD_SIZE, `train(hyp, opt, device, train_dataset=None, val_dataset=None)`, `run(**kwargs)`.
 
 Scope: the hot path -- model, loss, backward, gradient all-reduce, optimizer, and the validation arithmetic
-(val.run: NMS at the reference's val settings, device matcher, AP) -- is native here. The reference's cv2 mosaic / augmentation
-pipeline, plotting and MLflow / TensorBoard logging are out of scope; `train_dataset` / `val_dataset` are therefore per-task
-iterables that yield the reference's batch dicts ({"img": uint8 [N,3,H,W], "cls", "bboxes" (xywh in [0,1]), "batch_idx"}):
-`--data synthetic` provides the benchmark's generator, `--data <yaml>` the plain YOLO-txt loader of cerberusdet_amd.data
-(letterbox only, no augmentation).
+(val.run: NMS at the reference's val settings, device matcher, AP) -- is native here. Plotting and MLflow / TensorBoard logging
+are out of scope; `train_dataset` / `val_dataset` are per-task iterables that yield the reference's batch dicts
+({"img": uint8 [N,3,H,W], "cls", "bboxes" (xywh in [0,1]), "batch_idx"}): `--data synthetic` provides the benchmark's generator,
+`--data <yaml>` the YOLO-txt loader of cerberusdet_amd.data with the reference's training augmentation (mosaic / affine / mixup /
+HSV / flips) rendered by one GPU kernel per batch (`--no-augment`: letterbox only). That loader decodes images with PIL on the
+training thread (`--workers` is accepted and ignored): it exists for parity of the data path, its throughput is host-bound and is
+not a measured result -- the benchmark numbers are synthetic batches resident in HBM.
 
 Per epoch (reference trainers/base_trainer.py:114-194, utils/models_manager.py:262-294): rank 0 validates every task on the EMA
 weights (unless --noval, always on the final epoch), fitness = 0.1 * mAP@.5 + 0.9 * mAP@.5:.95 (utils/metrics.py:28-34) per task and
@@ -257,8 +259,8 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
                         if not opt.nosave or final_epoch:  # tracks the task's best model (not meant for resuming, base_trainer.py:158-170)
                             save_training_checkpoint(wdir / f"{t}_best.pt", model, trainer, epoch, best_fitness, best_fitness_per_task, stopper.best_epoch)
                 last_fitness = sum(fit_per_task.values()) / len(fit_per_task)
-                is_best = last_fitness > best_fitness
                 best_fitness = max(best_fitness, last_fitness)
+                is_best = best_fitness == last_fitness  # base_trainer.py:177-183: ties (fitness still 0) also write best.pt
                 stop = stopper(epoch, last_fitness)
             else:
                 is_best = False

@@ -5,8 +5,11 @@ set -e
 cd "$(dirname "$0")/../cerberusdet_amd/csrc"
 OUT=../../tools/debug/_build
 mkdir -p $OUT/obj
-for f in core conv_igemm conv_halo conv_vt conv_pair conv_wgrad conv_wgrad_halo elementwise stem_detect stem_mfma nms det_loss optim preprocess; do
-  if [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ] || [ common.h -nt $OUT/obj/$f.o ]; then
+# the source list is the Makefile's (one place to add a file)
+SRCS=$(sed -n 's/^SRCS *= *//p' Makefile)
+for s in $SRCS; do
+  f=${s%.hip}
+  if [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ] || [ common.h -nt $OUT/obj/$f.o ] || [ halo_common.h -nt $OUT/obj/$f.o ] || [ wgrad_tr.h -nt $OUT/obj/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -DCDET_PROFILING $EXTRA -c $f.hip -o $OUT/obj/$f.o &
   fi
 done
