@@ -10,14 +10,15 @@ import torch
 
 class _PlanFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, x, anchor):
+    def forward(ctx, plan, x, anchor, fresh=False):
         plan.run_forward(x)
         ctx.plan = plan
         ctx.generation = plan.generation  # the saved z / mean / invstd live in the plan's buffers: valid until its next forward
         outs = []
         for t in plan.tasks:
             nc = plan.model.get_head(t).nc
-            outs += [f[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
+            # fresh: one FLAT copy of each padded NHWC map (memcpy speed), then the NCHW-shaped view of the copy
+            outs += [(f.clone() if fresh else f)[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
         return tuple(outs)
 
     @staticmethod
@@ -38,13 +39,13 @@ class _PlanFunction(torch.autograd.Function):
                 else:
                     d[..., :64 + nc].copy_(g.permute(0, 2, 3, 1))
         plan.run_backward()
-        return None, None, None
+        return None, None, None, None
 
 
-def run_with_autograd(plan, x):
+def run_with_autograd(plan, x, fresh=False):
     # `anchor` is a leaf that requires grad so that autograd records the node even though the image does not need gradients
     anchor = plan.model._autograd_anchor()
-    outs = _PlanFunction.apply(plan, x, anchor)
+    outs = _PlanFunction.apply(plan, x, anchor, fresh)
     res, i = {}, 0
     for t in plan.tasks:
         res[t] = list(outs[i:i + 3])

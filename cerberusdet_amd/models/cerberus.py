@@ -495,7 +495,10 @@ class CerberusDet(nn.Module):
     def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False, zero_copy=False):
         """Same contract as the reference (cerberus.py:804-882): a `str` task -> that head's output, otherwise a dict.
         train mode -> list of 3 raw maps [N, 64+nc, h, w]; eval mode -> (y [N, 4+nc, A], maps).
-        Like the reference, every call returns FRESH tensors (one device copy of the head maps / `y`, ~0.1 ms at batch 32 @640).
+        Like the reference, every call returns FRESH tensors. Eval mode: the head projections and the decode kernel write straight
+        into a newly allocated output set (engine.Plan.fresh_outputs: pointer patches on the host, no device copy). Train mode: one
+        flat device copy of the padded NHWC head maps (~0.1 ms at batch 32 @640; the loss kernels keep reading the plan's own maps),
+        returned as NCHW-shaped views.
         `zero_copy=True` returns VIEWS of the compiled plan's buffers instead: the next forward of the same (tasks, shape, dtype, mode)
         overwrites them, so consume them (NMS, loss) before calling the model again -- CerberusDetInference, val.run and the trainer
         do. Either way a train-mode forward keeps ONE set of saved activations per configuration: call backward() before the next
@@ -507,20 +510,20 @@ class CerberusDet(nn.Module):
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
         x = input_tensor.contiguous()
         plan = self.get_plan(tasks, x.shape, x.dtype)
-        own = (lambda t: t) if zero_copy else (lambda t: t.clone())
         if self.training and torch.is_grad_enabled():
             from ..autograd_bridge import run_with_autograd
 
-            outs = run_with_autograd(plan, x)
-            if not zero_copy:
-                outs = {t: [own(f) for f in maps] for t, maps in outs.items()}
+            outs = run_with_autograd(plan, x, fresh=not zero_copy)
         else:
+            if not self.training:
+                plan.fresh_outputs(not zero_copy)
             plan.run_forward(x)
             outs = {}
             for t in tasks:
                 nc = self.get_head(t).nc
-                maps = [own(f[..., :64 + nc].permute(0, 3, 1, 2)) for f in plan.feats[t]]
-                outs[t] = maps if self.training else (own(plan.y[t]), maps)
+                srcs = [f.clone() for f in plan.feats[t]] if (self.training and not zero_copy) else plan.feats[t]  # flat copies
+                maps = [f[..., :64 + nc].permute(0, 3, 1, 2) for f in srcs]
+                outs[t] = maps if self.training else (plan.y[t], maps)
         return outs[task_ids] if isinstance(task_ids, str) else outs
 
     # ------------------------------------------------------------------------------------------------------ freezing

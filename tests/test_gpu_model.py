@@ -86,6 +86,68 @@ def test_eval_stream_lanes_bit_identical_to_single_stream(name, monkeypatch):
             assert torch.equal(a, b)
 
 
+def test_batch_sliced_first_stage_is_bit_identical_to_the_whole_batch_schedule(monkeypatch):
+    """engine.Plan._sliced_stage: the first backbone rows run once per slice of the image batch (their temporaries then stay in the
+    Infinity Cache). Eval-form arithmetic is per image, so the outputs must carry the same bits, also with a shorter last slice."""
+    from cerberusdet_amd import engine
+
+    arrays, meta = load_golden("model_tiny2")
+    m = _build(meta).eval()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    x = torch.cat([x, torch.flip(x, dims=[2]), torch.flip(x, dims=[3])])[:5].contiguous()
+    monkeypatch.setattr(engine, "_EVAL_SLICE_MIN_PIXELS", 0)
+    outs = {}
+    with torch.no_grad():
+        for per in (0, 2, 1):
+            monkeypatch.setenv("CDET_EVAL_SLICE", str(per))
+            m._plans.clear()
+            outs[per] = m(x)
+            plan = m.get_plan(meta["tasks"], x.shape, x.dtype)
+            assert (getattr(plan, "sliced", None) is not None) == (per > 0)
+    torch.cuda.synchronize()
+    for per in (2, 1):
+        for t in meta["tasks"]:
+            assert torch.equal(outs[per][t][0], outs[0][t][0])
+            for a, b in zip(outs[per][t][1], outs[0][t][1]):
+                assert torch.equal(a, b)
+
+
+def test_default_forward_returns_fresh_tensors_without_a_copy():
+    """Reference contract (cerberus.py:804-882): every call returns new tensors. The eval plan gets there by pointing the projection /
+    decode launches at a newly allocated output set (engine.Plan.fresh_outputs), train mode by one flat copy: results of an earlier call
+    must survive later calls (fresh or zero-copy) and carry the same bits as the zero-copy views."""
+    arrays, meta = load_golden("model_tiny2")
+    m = _build(meta).eval()
+    x1 = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    x2 = torch.flip(x1, dims=[3]).contiguous()
+    with torch.no_grad():
+        z1 = m(x1, zero_copy=True)
+        want1 = {t: (z1[t][0].clone(), [f.clone() for f in z1[t][1]]) for t in meta["tasks"]}
+        a = m(x1)
+        b = m(x2)                      # a second fresh call must not touch the first call's tensors
+        z2 = m(x2, zero_copy=True)     # nor may a zero-copy call (it goes back to the plan-owned set)
+        c = m(x1)
+        torch.cuda.synchronize()
+        plan = m.get_plan(meta["tasks"], x1.shape, x1.dtype)
+        for t in meta["tasks"]:
+            assert a[t][0].data_ptr() != b[t][0].data_ptr() != z2[t][0].data_ptr()
+            assert z2[t][0].data_ptr() == plan._home_outputs[1][t].data_ptr()
+            for got in (a, c):
+                assert torch.equal(got[t][0], want1[t][0])
+                for f, g in zip(got[t][1], want1[t][1]):
+                    assert f.shape == g.shape and torch.equal(f, g)
+            assert torch.equal(b[t][0], z2[t][0]) and not torch.equal(b[t][0], a[t][0])
+    m.train()
+    with torch.no_grad():
+        t1 = m(x1)
+        keep = {t: [f.clone() for f in t1[t]] for t in meta["tasks"]}
+        m(x2)
+        torch.cuda.synchronize()
+        for t in meta["tasks"]:
+            for f, g in zip(t1[t], keep[t]):
+                assert torch.equal(f, g)
+
+
 @pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
 def test_eval_boxes_within_1e3_of_reference_at_fp32_accuracy(name):
     """BASELINE.json's tolerance -- boxes within 1e-3 relative of the reference -- at the reference's own precision: the eval forward
