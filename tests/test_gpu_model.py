@@ -86,32 +86,6 @@ def test_eval_stream_lanes_bit_identical_to_single_stream(name, monkeypatch):
             assert torch.equal(a, b)
 
 
-def test_batch_sliced_first_stage_is_bit_identical_to_the_whole_batch_schedule(monkeypatch):
-    """engine.Plan._sliced_stage: the first backbone rows run once per slice of the image batch (their temporaries then stay in the
-    Infinity Cache). Eval-form arithmetic is per image, so the outputs must carry the same bits, also with a shorter last slice."""
-    from cerberusdet_amd import engine
-
-    arrays, meta = load_golden("model_tiny2")
-    m = _build(meta).eval()
-    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
-    x = torch.cat([x, torch.flip(x, dims=[2]), torch.flip(x, dims=[3])])[:5].contiguous()
-    monkeypatch.setattr(engine, "_EVAL_SLICE_MIN_PIXELS", 0)
-    outs = {}
-    with torch.no_grad():
-        for per in (0, 2, 1):
-            monkeypatch.setenv("CDET_EVAL_SLICE", str(per))
-            m._plans.clear()
-            outs[per] = m(x)
-            plan = m.get_plan(meta["tasks"], x.shape, x.dtype)
-            assert (getattr(plan, "sliced", None) is not None) == (per > 0)
-    torch.cuda.synchronize()
-    for per in (2, 1):
-        for t in meta["tasks"]:
-            assert torch.equal(outs[per][t][0], outs[0][t][0])
-            for a, b in zip(outs[per][t][1], outs[0][t][1]):
-                assert torch.equal(a, b)
-
-
 def test_default_forward_returns_fresh_tensors_without_a_copy():
     """Reference contract (cerberus.py:804-882): every call returns new tensors. The eval plan gets there by pointing the projection /
     decode launches at a newly allocated output set (engine.Plan.fresh_outputs), train mode by one flat copy: results of an earlier call

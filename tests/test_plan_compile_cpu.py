@@ -54,30 +54,6 @@ def test_every_task_set_compiles_in_train_and_eval_form(cfg_name, tasks):
     assert sum(1 for r in single[(True, tasks[0])].trace if r["kind"] == "copy") <= 2
 
 
-def test_batch_sliced_first_stage_compiles_per_slice_with_shared_temporaries(monkeypatch):
-    """Eval plans may run the first backbone rows once per slice of the image batch (engine.Plan._sliced_stage): same launches per
-    slice, image pointers offset by whole images, one set of temporaries, a full-batch output for the last sliced row."""
-    from cerberusdet_amd import engine
-    from cerberusdet_amd.engine import Plan
-
-    tasks = ["voc", "objects365_animals"]
-    m = _model("v8x_2task.yaml", tasks)
-    dev = torch.device("cpu")
-    monkeypatch.setattr(engine, "_EVAL_SLICE_MIN_PIXELS", 0)
-    monkeypatch.setenv("CDET_EVAL_SLICE", "0")
-    whole = Plan(m, tasks, 5, 64, 64, False, torch.bfloat16, torch.uint8, dev)
-    monkeypatch.setenv("CDET_EVAL_SLICE", "2")
-    sl = Plan(m, tasks, 5, 64, 64, False, torch.bfloat16, torch.uint8, dev)
-    assert getattr(whole, "sliced", None) is None and sl.sliced["slices"] == 3 and sl.sliced["rows"] == 3
-    n_stage = 1 + 1 + (2 + 2 * 3)  # stem, Conv, C2f(n=3): cv1, 3 x (cv1, cv2), cv2
-    assert sl.n_fwd_calls == whole.n_fwd_calls + 2 * n_stage
-    offs = sorted(sl._img_slot_off.get(id(s_), 0) for s_ in sl.img_slots)
-    assert offs == [0, 2 * 3 * 64 * 64, 4 * 3 * 64 * 64] and [s_[6] for s_ in sl.img_slots] == [2, 2, 1]
-    # a training plan never slices (BatchNorm statistics are over the whole batch)
-    tr = Plan(m, [tasks[0]], 5, 64, 64, True, torch.bfloat16, torch.uint8, dev)
-    assert getattr(tr, "sliced", None) is None
-
-
 def test_frozen_trunk_plan_compiles_without_backward_for_shared_blocks():
     from cerberusdet_amd.engine import Plan
     from cerberusdet_amd.models import CerberusDet
