@@ -189,6 +189,60 @@ def test_stride2_tiled_conv_and_data_gradient_exact_at_full_size(case):
     assert float((dw.double() * w.double()).sum()) == float((dst.torch().double() * dy.double()).sum())
 
 
+# BASELINE config 5 (CerberusDetInference: fp16, batch 128 @640): the forward launches with the largest buffers, in the eval form the
+# inference plan uses (folded-BN scale / bias in the epilogue, residual for the Bottleneck shortcut), at N = 128.
+#   (H, W, Cin, Cout, k, stride, source (ld, coff) or None)
+N128_FP16 = [(40, 40, 320, 320, 3, 1, None),          # linear 256-pixel tiles: the most frequent launch of the forward
+             (160, 160, 400, 160, 1, 1, (448, 0)),    # C2f cv2 over its 448-pitch concat buffer: 2.9 GB source, 1.3 GB destination
+             (160, 160, 80, 80, 3, 1, (448, 160)),    # 16 x 16 patches, 96-cout tile, half last chunk, source = a slice of that buffer
+             (40, 40, 1600, 640, 1, 1, None),         # pair tile (conv_pair.hip)
+             (320, 320, 80, 160, 3, 2, None)]         # stride 2 on parity planes (conv_vt.hip): 2.1 GB source
+
+
+@pytest.mark.parametrize("case", N128_FP16)
+def test_fp16_batch128_forward_exact_at_full_size(case):
+    """The tap-resident forward kernels at BASELINE config 5's size (fp16, N = 128 @640) against the plain fp32 reference
+    (tests/torchref.py): small-integer activations, sparse +-1 weights, power-of-two scales and integer biases keep every value an
+    exactly representable integer, so raw output, eval epilogue (y * scale + bias, + residual) must match bit for bit over the whole
+    tensor -- buffers of 1.3 - 2.9 GB, i.e. byte offsets beyond 2^31 inside the kernels' 32-bit buffer addressing."""
+    import torchref as R
+    from cerberusdet_amd import ops
+
+    H, W, Ci, Co, k, s, sl = case
+    N = 128
+    g = torch.Generator(device=DEV).manual_seed(31)
+    dtype = torch.float16
+    w = _sparse_pm1((Co, Ci, k, k), 40.0, max(Ci, Co) * k * k, g)
+    ld, coff = sl if sl else (Ci, 0)
+    xb = torch.full((N, H, W, ld), float("nan"), dtype=dtype, device=DEV)
+    xb[..., coff:coff + Ci] = torch.randint(-2, 3, (N, H, W, Ci), generator=g, device=DEV).to(dtype)
+    src = ops.View(xb, coff, Ci)
+    assert xb.numel() * 2 < 3 * 2 ** 30  # (the tiled kernels take sources below 3 GiB; beyond that the plan falls back, see test_c_abi)
+    Ho, Wo = H // s, W // s
+    wf, _ = ops.pack_weight_tiled(w, dtype, fwd=True, dgrad=False)
+    dst = ops.new_act(N, Ho, Wo, Co, dtype)
+    ref = R.conv_fwd(src.torch().float(), w, s)
+    assert float(ref.abs().max()) <= 200
+    if s == 1:
+        assert ops.conv2d_tiled_ok(src, dst, k, 1)
+        ops.conv2d_tiled(src, wf, dst, k)
+    else:
+        assert ops.conv2d_s2_tiled_ok(src, dst)
+        ops.conv2d_s2_tiled(src, wf, dst)
+    assert torch.equal(dst.torch().float(), ref), f"{int((dst.torch().float() != ref).sum())} of {ref.numel()} outputs differ"
+    # eval epilogue: scale in {1, 2}, integer bias, residual
+    scale = (torch.randint(0, 2, (Co,), generator=g, device=DEV) + 1).float()
+    bias = torch.randint(-3, 4, (Co,), generator=g, device=DEV).float()
+    res = torch.randint(-2, 3, (N, Ho, Wo, Co), generator=g, device=DEV).to(dtype)
+    if s == 1:
+        ops.conv2d_tiled(src, wf, dst, k, scale=scale, bias=bias, res=ops.View(res))
+    else:
+        ops.conv2d_s2_tiled(src, wf, dst, scale=scale, bias=bias, res=ops.View(res))
+    want = ref * scale + bias + res.float()
+    assert float(want.abs().max()) <= 1024
+    assert torch.equal(dst.torch().float(), want)
+
+
 @pytest.fixture(scope="module")
 def v8x_trainer():
     import bench

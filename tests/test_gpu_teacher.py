@@ -78,20 +78,22 @@ def test_half_width_train_plan_every_launch_vs_fp32_layer(which):
     assert n >= 60
 
 
-def test_v8x_full_size_train_plan_every_launch_vs_fp32_layer():
-    """YOLOv8x, batch 32 @640 (BASELINE.json config 2), one task's training plan: 97 Conv units + 6 head projections, each pinned."""
+@pytest.mark.parametrize("ti", [0, 1])
+def test_v8x_full_size_train_plan_every_launch_vs_fp32_layer(ti):
+    """YOLOv8x, batch 32 @640 (BASELINE.json config 2), each task's training plan (nc = 20 and nc = 19: the second head pads its class
+    channels to 24): 97 Conv units + 6 head projections, each pinned."""
     import bench
 
     dev = torch.device(DEV, 0)
     model, _ = bench.build_model("v8x_2task.yaml", dev)
-    t = bench.TASKS[0]
-    batch = bench.synth_batch(0, 0, 0, 32, bench.NC[0], 640, dev)
+    t = bench.TASKS[ti]
+    batch = bench.synth_batch(0, ti, 0, 32, bench.NC[ti], 640, dev)
     img = batch["img"]
     plan = model.get_plan(t, img.shape, img.dtype, training=True)
     names = [getattr(fn, "__name__", "") for _, cs in plan.bwd_groups for fn, _ in cs]
     assert names.count("cdet_conv2d_wgrad_grouped") >= 8 and names.count("cdet_conv2d_tiled_dgrad") >= 60
     assert sum(1 for fn, _ in plan.fwd if getattr(fn, "__name__", "") == "cdet_conv2d_tiled") >= 80
-    rep, n = _run(plan, img, [t], [bench.NC[0]])
-    print(f"[teacher/v8x bs32@640] {n} backward units, {len(rep.rows)} tensors: {rep.summary()}")
+    rep, n = _run(plan, img, [t], [bench.NC[ti]])
+    print(f"[teacher/v8x bs32@640 {t}] {n} backward units, {len(rep.rows)} tensors: {rep.summary()}")
     assert sum(1 for r in plan.trace if r["kind"] == "conv") == 97 and n >= 104
     assert sum(1 for r in plan.trace if r.get("also") is not None) == 18  # the backbone's Bottleneck shortcuts (3 + 6 + 6 + 3)

@@ -191,3 +191,42 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     md.N, md.T, md.max_det, md.iou_thres = 1, 9, 300, 0.8
     rc = lib.cdet_merge_tasks(C.byref(md), None, one, one, None)
     assert rc < 0 and "T <= 8" in lib.cdet_last_error().decode()
+
+
+def test_tiled_kernels_refuse_buffers_their_32_bit_addressing_cannot_reach():
+    """The tap-resident kernels address their sources through buffer descriptors with 32-bit byte offsets (conv_halo.hip, conv_vt.hip,
+    conv_pair.hip, conv_wgrad_halo.hip). A source of 3 GiB or more must be REFUSED by the geometry check (the plan compiler then takes the
+    generic kernel, which uses 64-bit addresses) -- never truncated: the descriptor's range check would zero-fill the reads silently."""
+    import ctypes as C
+
+    from cerberusdet_amd import _lib as L
+
+    lib = L.load()
+    one = C.c_void_p(16)
+
+    def desc(N, H, W, Ci, Co, k, s, ld=None):
+        d = L.ConvDesc()
+        d.N, d.Hs, d.Ws, d.Cs, d.Hd, d.Wd, d.Cd = N, H, W, Ci, H // s, W // s, Co
+        d.kh = d.kw = k
+        d.stride, d.pad, d.mode = s, k // 2, L.CONV_FWD
+        d.dtype = d.out_dtype = L.F16
+        d.src_ld, d.dst_ld = ld or Ci, Co
+        return d
+
+    # 160 x 160 x 448-pitch concat buffer: 128 images = 2.9 GB (accepted), 192 images = 4.4 GB (beyond 2^32: refused)
+    ok = desc(128, 160, 160, 400, 160, 1, 1, ld=448)
+    big = desc(192, 160, 160, 400, 160, 1, 1, ld=448)
+    assert lib.cdet_conv2d_tiled_ok(C.byref(ok)) == 1 and lib.cdet_conv2d_tiled_ok(C.byref(big)) == 0
+    rc = lib.cdet_conv2d_tiled(C.byref(big), one, one, None, None, None, one, None, None)
+    assert rc < 0 and "unsupported geometry" in lib.cdet_last_error().decode()
+    # 5 GiB source of a 3x3 stride-1 layer, and of a stride-2 layer
+    big3 = desc(1400, 160, 160, 80, 80, 3, 1)
+    assert 1400 * 160 * 160 * 80 * 2 > 5 * 2 ** 30 and lib.cdet_conv2d_tiled_ok(C.byref(big3)) == 0
+    s2ok, s2big = desc(128, 320, 320, 80, 160, 3, 2), desc(256, 320, 320, 80, 160, 3, 2)
+    assert lib.cdet_conv2d_s2_tiled_ok(C.byref(s2ok)) == 1 and lib.cdet_conv2d_s2_tiled_ok(C.byref(s2big)) == 0
+    rc = lib.cdet_conv2d_s2_tiled(C.byref(s2big), one, one, None, None, None, one, None, None)
+    assert rc < 0 and "unsupported geometry" in lib.cdet_last_error().decode()
+    # the tap-resident weight gradient (x and dY below 3 GiB each)
+    wok, wbig = desc(32, 80, 80, 320, 320, 3, 1), desc(800, 80, 80, 320, 320, 3, 1)
+    assert lib.cdet_conv2d_wgrad_ws_elems(C.byref(wok)) > 0
+    assert lib.cdet_conv2d_wgrad_groupable(C.byref(wok)) == 1 and lib.cdet_conv2d_wgrad_groupable(C.byref(wbig)) == 0
