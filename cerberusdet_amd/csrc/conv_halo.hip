@@ -49,6 +49,7 @@ struct HaloArgs {
                    // tap of a 9-tap operand -- the (0, 0) parity class of a stride-2 data gradient, conv_vt.hip)
     int Hd, Wd, cp, cq;  // OMAP: tile pixel (n, y, x) is written to pixel (2y + cp, 2x + cq) of an Hd x Wd destination
     int halfk;  // 3x3 only: the last 32-channel chunk holds at most 16 channels (Cs = 80): its second k16 half is all zeros and is skipped
+    int accum;  // HEPI_F32 only: y (fp32) += result
 };
 
 constexpr int HEPI_STAGE_OFF = 6912;  // epilogue LDS map (after HZERO): statistics scratch [4][2][HC] fp32, scale/bias [2][HC] fp32, then the store staging
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     // per-channel scale / bias of the block's couts go through LDS once: as global loads inside the unrolled epilogue they were
     // 80 dependent L2 round trips per lane (the 160 live accumulators leave no registers to prefetch them) -- 2/3 of the epilogue's time
     float* const sbl = reinterpret_cast<float*>(smem + HZERO + 5120);  // [2][HC], behind the statistics scratch
-    if (EPI == HEPI_FULL) {
+    if (EPI != HEPI_RAW) {
         if (t < HC) {
             const int c = c0 + t < a.Cd ? c0 + t : a.Cd - 1;
             sbl[t] = a.scale ? a.scale[c] : 1.f;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 }
                 const int cl = f * 32 + 8 * (q + h);
                 const int co = c0 + cl;
-                if (EPI == HEPI_FULL) {
+                if (EPI != HEPI_RAW) {
                     {
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbl + cl), s1 = *reinterpret_cast<const f32x4*>(sbl + cl + 4);
                         const f32x4 b0v = *reinterpret_cast<const f32x4*>(sbl + HC + cl), b1v = *reinterpret_cast<const f32x4*>(sbl + HC + cl + 4);
@@ -502,12 +503,29 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                         }
                     }
                 }
+                if (EPI == HEPI_F32) {
+                    // fp32 destination (Detect's biased projections, gradient fan-in, the split-operand accuracy chain of tests/hiprec.py):
+                    // 8 consecutive couts of one pixel = 32 contiguous bytes per lane, stored (or accumulated) straight from the registers --
+                    // these launches are short or run against HBM, the LDS-staged row form of the 16-bit epilogue would buy nothing
+                    if (pok && co < a.Cd) {
+                        float* const yo = reinterpret_cast<float*>(a.y) + (int64_t)p * a.dst_ld + a.dst_coff + co;
+                        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                        if (a.accum) {
+                            o0 += *reinterpret_cast<const f32x4*>(yo);
+                            o1 += *reinterpret_cast<const f32x4*>(yo + 4);
+                        }
+                        *reinterpret_cast<f32x4*>(yo) = o0;
+                        *reinterpret_cast<f32x4*>(yo + 4) = o1;
+                    }
+                    continue;
+                }
                 u32x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = hpack2<DT>(v[2 * r], v[2 * r + 1]);
                 *reinterpret_cast<u32x4*>(stg + l31 * RS + cl * 2) = pk;
             }
         }
+        if (EPI == HEPI_F32) continue;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // whole rows out: chunk id -> (pixel of this fragment, 16-byte chunk of its row)
@@ -637,7 +655,10 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     if (d->Hs != d->Hd || d->Ws != d->Wd) return pl;
     if (d->Cs % 8 != 0 || d->src_ld % 8 != 0 || d->src_coff % 8 != 0) return pl;
     if (d->Cd % 8 != 0 || d->dst_ld % 8 != 0 || d->dst_coff % 8 != 0) return pl;
-    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16) || d->out_dtype != d->dtype || d->accumulate) return pl;
+    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return pl;
+    if (d->out_dtype != d->dtype && d->out_dtype != CDET_F32) return pl;   // 16-bit in == out, or an fp32 destination (HEPI_F32)
+    if (d->accumulate && d->out_dtype != CDET_F32) return pl;              // y += result needs the fp32 destination
+    if (d->out_dtype == CDET_F32 && (int64_t)d->N * d->Hd * d->Wd * d->dst_ld >= (1ll << 31)) return pl;
     const int rb = row_block(d->Cd);
     pl.nf = rb / 32;
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
@@ -732,7 +753,12 @@ static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nbl
 }
 
 template <int DT>
-static void dispatch_halo(const HaloArgs& a, int k, bool full, const HaloPlan& pl, int nblocks, hipStream_t s) {
+static void dispatch_halo(const HaloArgs& a, int k, bool full, bool f32out, const HaloPlan& pl, int nblocks, hipStream_t s) {
+    if (f32out) {
+        if (pl.nf == 5) dispatch_halo2<DT, 5, HEPI_F32>(a, k, pl, nblocks, s);
+        else dispatch_halo2<DT, 3, HEPI_F32>(a, k, pl, nblocks, s);
+        return;
+    }
     if (pl.nf == 5) {
         if (full) dispatch_halo2<DT, 5, HEPI_FULL>(a, k, pl, nblocks, s);
         else dispatch_halo2<DT, 5, HEPI_RAW>(a, k, pl, nblocks, s);
@@ -800,11 +826,13 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
                                  const void* residual, void* y, float* stats, void* stream) {
     CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_tiled: null pointer");
     const HaloPlan pl = halo_plan(d);
-    CDET_CHECK_ARG(pl.ok, "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs/Cd/ld/coff %% 8 == 0, 16-bit in == out, "
-                          "3x3: W <= 95 or H, W multiples of 16)");
+    CDET_CHECK_ARG(pl.ok, "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs/Cd/ld/coff %% 8 == 0, 16-bit in, out = the same "
+                          "type or fp32 (accumulate: fp32 only), 3x3: W <= 95 or H, W multiples of 16)");
+    const bool f32out = d->out_dtype == CDET_F32;
+    CDET_CHECK_ARG(!(f32out && stats), "cdet_conv2d_tiled: BatchNorm partial sums go with the 16-bit raw output");
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_tiled: the data gradient is a FWD call on the DGRAD operand of cdet_pack_weights_tiled");
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_tiled: residual ld/coff must be multiples of 8");
-    if (pl.nf == 5 && pl.ng == 2 && pair_plan_ok(d)) {
+    if (!f32out && pl.nf == 5 && pl.ng == 2 && pair_plan_ok(d)) {
         const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream);
         CDET_LAUNCH_CHECK();
         return rc;
@@ -829,11 +857,12 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * d->kh * d->kw * rb * HROW);
     a.wts = 1; a.wt0 = 0; a.Hd = d->Hd; a.Wd = d->Wd; a.cp = a.cq = 0;
+    a.accum = d->accumulate ? 1 : 0;
     const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
     const int nblocks = a.n_pblk * a.n_cblk;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == CDET_BF16) dispatch_halo<CDET_BF16>(a, d->kh, full, pl, nblocks, s);
-    else dispatch_halo<CDET_F16>(a, d->kh, full, pl, nblocks, s);
+    if (d->dtype == CDET_BF16) dispatch_halo<CDET_BF16>(a, d->kh, full, f32out, pl, nblocks, s);
+    else dispatch_halo<CDET_F16>(a, d->kh, full, f32out, pl, nblocks, s);
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -41,6 +41,7 @@ struct VtArgs {
     int tiles_x, tiles_per_img;
     int cp, cq;  // class parity: the class writes dX(2y' + cp, 2x' + cq)
     unsigned x_bytes, w_bytes;
+    int accum;  // HEPI_F32 only: y (fp32) += result
 };
 
 constexpr int VT_S2FWD = 0, VT_CLASS11 = 1, VT_CLASS10 = 2, VT_CLASS01 = 3, VT_CLASS00 = 4;
@@ -429,7 +430,7 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
     // ---- epilogue (as conv_halo.hip): 8 consecutive couts per lane, scale / bias / SiLU / residual, LDS-staged whole-row stores ----------
     uint16_t* const yp = reinterpret_cast<uint16_t*>(a.y);
     float* const sbl = reinterpret_cast<float*>(smem + HZERO + 5120);
-    if (EPI == HEPI_FULL) {
+    if (EPI != HEPI_RAW) {
         if (t < HC) {
             const int c = c0 + t < a.Cd ? c0 + t : a.Cd - 1;
             sbl[t] = a.scale ? a.scale[c] : 1.f;
@@ -462,7 +463,7 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
                 }
                 const int cl = f * 32 + 8 * (q + h);
                 const int co = c0 + cl;
-                if (EPI == HEPI_FULL) {
+                if (EPI != HEPI_RAW) {
                     {
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sbl + cl), s1 = *reinterpret_cast<const f32x4*>(sbl + cl + 4);
                         const f32x4 b0v = *reinterpret_cast<const f32x4*>(sbl + HC + cl), b1v = *reinterpret_cast<const f32x4*>(sbl + HC + cl + 4);
@@ -485,12 +486,26 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
                         }
                     }
                 }
+                if (EPI == HEPI_F32) {  // fp32 destination, optionally accumulating (see conv_halo.hip): straight from the registers
+                    if (pok && co < a.Cd) {
+                        float* const yo = reinterpret_cast<float*>(a.y) + (int64_t)p * a.dst_ld + a.dst_coff + co;
+                        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                        if (a.accum) {
+                            o0 += *reinterpret_cast<const f32x4*>(yo);
+                            o1 += *reinterpret_cast<const f32x4*>(yo + 4);
+                        }
+                        *reinterpret_cast<f32x4*>(yo) = o0;
+                        *reinterpret_cast<f32x4*>(yo + 4) = o1;
+                    }
+                    continue;
+                }
                 u32x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = hpack2<DT>(v[2 * r], v[2 * r + 1]);
                 *reinterpret_cast<u32x4*>(stg + l31 * RS + cl * 2) = pk;
             }
         }
+        if (EPI == HEPI_F32) continue;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -556,7 +571,10 @@ static VtPlan vt_plan(const cdet_conv_desc* d, bool dgrad) {
     if (Hb != 2 * Hp || Wb != 2 * Wp) return pl;
     if (d->Cs % 8 != 0 || d->src_ld % 8 != 0 || d->src_coff % 8 != 0) return pl;
     if (d->Cd % 8 != 0 || d->dst_ld % 8 != 0 || d->dst_coff % 8 != 0) return pl;
-    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16) || d->out_dtype != d->dtype || d->accumulate) return pl;
+    if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return pl;
+    if (d->out_dtype != d->dtype && d->out_dtype != CDET_F32) return pl;   // 16-bit in == out, or an fp32 destination (HEPI_F32)
+    if (d->accumulate && d->out_dtype != CDET_F32) return pl;
+    if (d->out_dtype == CDET_F32 && (int64_t)d->N * d->Hd * d->Wd * d->dst_ld >= (1ll << 31)) return pl;
     pl.nf = vt_row_block(d->Cd) / 32;
     pl.patch = Hp % PATCH_W == 0 && Wp % PATCH_W == 0;
     if (!pl.patch && HP + Wp + 1 > VT_XR) return pl;  // linear halo: 256 pixels + one row + one pixel
@@ -585,8 +603,11 @@ static void launch_vt(const VtArgs& a, size_t lds, int nblocks, hipStream_t s) {
 }
 
 template <int DT, int NF, int MODE>
-static void dispatch_vt2(const VtArgs& a, bool full, bool patch, size_t lds, int nblocks, hipStream_t s) {
-    if (full) {
+static void dispatch_vt2(const VtArgs& a, int full, bool patch, size_t lds, int nblocks, hipStream_t s) {
+    if (full == HEPI_F32) {
+        if (patch) launch_vt<DT, NF, HEPI_F32, MODE, true>(a, lds, nblocks, s);
+        else launch_vt<DT, NF, HEPI_F32, MODE, false>(a, lds, nblocks, s);
+    } else if (full) {
         if (patch) launch_vt<DT, NF, HEPI_FULL, MODE, true>(a, lds, nblocks, s);
         else launch_vt<DT, NF, HEPI_FULL, MODE, false>(a, lds, nblocks, s);
     } else {
@@ -596,7 +617,7 @@ static void dispatch_vt2(const VtArgs& a, bool full, bool patch, size_t lds, int
 }
 
 template <int DT, int MODE>
-static void dispatch_vt(const VtArgs& a, int nf, bool full, bool patch, size_t lds, int nblocks, hipStream_t s) {
+static void dispatch_vt(const VtArgs& a, int nf, int full, bool patch, size_t lds, int nblocks, hipStream_t s) {
     if (nf == 5) dispatch_vt2<DT, 5, MODE>(a, full, patch, lds, nblocks, s);
     else dispatch_vt2<DT, 3, MODE>(a, full, patch, lds, nblocks, s);
 }
@@ -612,16 +633,16 @@ static void launch_dgrad4(const VtArgs& a, size_t lds, int nblocks, hipStream_t 
 }
 
 template <int DT>
-static void dispatch_dgrad4(const VtArgs& a, int nf, bool full, bool patch, size_t lds, int nblocks, hipStream_t s) {
+static void dispatch_dgrad4(const VtArgs& a, int nf, int full, bool patch, size_t lds, int nblocks, hipStream_t s) {
 #define CDET_D4(NF_, EPI_)                                                   \
     do {                                                                     \
         if (patch) launch_dgrad4<DT, NF_, EPI_, true>(a, lds, nblocks, s);   \
         else launch_dgrad4<DT, NF_, EPI_, false>(a, lds, nblocks, s);        \
     } while (0)
     if (nf == 5) {
-        if (full) CDET_D4(5, HEPI_FULL); else CDET_D4(5, HEPI_RAW);
+        if (full == HEPI_F32) CDET_D4(5, HEPI_F32); else if (full) CDET_D4(5, HEPI_FULL); else CDET_D4(5, HEPI_RAW);
     } else {
-        if (full) CDET_D4(3, HEPI_FULL); else CDET_D4(3, HEPI_RAW);
+        if (full == HEPI_F32) CDET_D4(3, HEPI_F32); else if (full) CDET_D4(3, HEPI_FULL); else CDET_D4(3, HEPI_RAW);
     }
 #undef CDET_D4
 }
@@ -658,6 +679,7 @@ static void vt_fill(VtArgs& a, const cdet_conv_desc* d, const VtPlan& pl, bool d
     a.cp = a.cq = 0;
     a.x_bytes = (unsigned)((int64_t)d->N * d->Hs * d->Ws * d->src_ld * 2);
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * 9 * rb * HROW);
+    a.accum = d->accumulate ? 1 : 0;
 }
 
 extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
@@ -670,7 +692,8 @@ extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, cons
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_s2_tiled: residual ld/coff must be multiples of 8");
     VtArgs a;
     vt_fill(a, d, pl, false, x, w_tiled, scale, bias, residual, y, stats);
-    const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
+    CDET_CHECK_ARG(!(d->out_dtype == CDET_F32 && stats), "cdet_conv2d_s2_tiled: BatchNorm partial sums go with the 16-bit raw output");
+    const int full = d->out_dtype == CDET_F32 ? HEPI_F32 : ((scale || bias || residual || d->act != CDET_ACT_NONE) ? HEPI_FULL : HEPI_RAW);
     const int nblocks = a.n_pblk * a.n_cblk;
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == CDET_BF16) dispatch_vt<CDET_BF16, VT_S2FWD>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
@@ -690,7 +713,7 @@ extern "C" int cdet_conv2d_s2_tiled_dgrad(const cdet_conv_desc* d, const void* d
     hipStream_t s = (hipStream_t)stream;
     VtArgs a;
     vt_fill(a, d, pl, true, dy, w_dgrad_tiled, nullptr, nullptr, residual, dx, nullptr);
-    const bool full = residual != nullptr;
+    const int full = d->out_dtype == CDET_F32 ? HEPI_F32 : (residual != nullptr ? HEPI_FULL : HEPI_RAW);
     const int nblocks = a.n_pblk * 4 * a.n_cblk;  // (pixel tile, class, cout block)
     if (d->dtype == CDET_BF16) dispatch_dgrad4<CDET_BF16>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
     else dispatch_dgrad4<CDET_F16>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);

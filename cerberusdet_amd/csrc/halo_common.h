@@ -13,7 +13,8 @@ constexpr int HZERO = 256;          // LDS bytes reserved in front (zero row)
 constexpr int MAXXP = 7;            // X DMA pieces (16 rows each) per wave per chunk: XH <= 448
 constexpr unsigned HSENT = 0xE0000000u;  // byte offset beyond every buffer: the DMA returns zeros
 constexpr int PATCH_W = 16, PATCH_HPW = PATCH_W + 2;  // patch mode: 16 x 16 pixel tiles, halo pitch 18
-constexpr int HEPI_RAW = 0, HEPI_FULL = 1;           // epilogue: raw 16-bit output (+ BN partial sums) / scale, bias, SiLU, residual
+constexpr int HEPI_RAW = 0, HEPI_FULL = 1, HEPI_F32 = 2;  // epilogue: raw 16-bit output (+ BN partial sums) / scale, bias, SiLU, residual / the same
+                                                      // arithmetic into an fp32 destination, optionally accumulating onto it
 
 template <int DT>
 __device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c) {

@@ -116,14 +116,16 @@ def pack_weight_tiled(w_oihw: torch.Tensor, dtype, fwd=True, dgrad=False):
     return wf, wd
 
 
-def conv2d_tiled_ok(src: View, dst: View, k, s) -> bool:
-    d = conv_desc(src, dst, k, s)
+def conv2d_tiled_ok(src: View, dst: View, k, s, accumulate=False) -> bool:
+    d = conv_desc(src, dst, k, s, accumulate=accumulate)
     return bool(L.load().cdet_conv2d_tiled_ok(C.byref(d)))
 
 
-def conv2d_tiled(src: View, w_tiled, dst: View, k, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None, stats=None):
+def conv2d_tiled(src: View, w_tiled, dst: View, k, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None, stats=None,
+                 accumulate=False):
+    """dst may be fp32 (HEPI_F32 epilogue); accumulate (fp32 dst only): dst += result."""
     lib = L.load()
-    d = conv_desc(src, dst, k, 1, L.CONV_FWD, act, res)
+    d = conv_desc(src, dst, k, 1, L.CONV_FWD, act, res, accumulate)
     L.check(lib.cdet_conv2d_tiled(C.byref(d), ptr(src), ptr(w_tiled), ptr(scale), ptr(bias), ptr(res), ptr(dst), ptr(stats), stream()),
             "cdet_conv2d_tiled")
     return dst
@@ -134,20 +136,21 @@ def conv2d_s2_tiled_ok(src: View, dst: View, mode=L.CONV_FWD) -> bool:
     return bool(L.load().cdet_conv2d_s2_tiled_ok(C.byref(d)))
 
 
-def conv2d_s2_tiled(src: View, w_tiled, dst: View, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None, stats=None):
+def conv2d_s2_tiled(src: View, w_tiled, dst: View, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None, stats=None,
+                    accumulate=False):
     """3x3 stride-2 forward on the tap-resident kernel (csrc/conv_vt.hip); w_tiled = pack_weight_tiled(w)[0]."""
     lib = L.load()
-    d = conv_desc(src, dst, 3, 2, L.CONV_FWD, act, res)
+    d = conv_desc(src, dst, 3, 2, L.CONV_FWD, act, res, accumulate)
     L.check(lib.cdet_conv2d_s2_tiled(C.byref(d), ptr(src), ptr(w_tiled), ptr(scale), ptr(bias), ptr(res), ptr(dst), ptr(stats), stream()),
             "cdet_conv2d_s2_tiled")
     return dst
 
 
-def conv2d_s2_tiled_dgrad(dy: View, w_dgrad_tiled, dx: View, res: Optional[View] = None):
+def conv2d_s2_tiled_dgrad(dy: View, w_dgrad_tiled, dx: View, res: Optional[View] = None, accumulate=False):
     """Data gradient of a 3x3 stride-2 convolution: dy [N,Ho,Wo,Cout] -> dx [N,2Ho,2Wo,Cin] (+ res, the gradient already there);
-    w_dgrad_tiled = pack_weight_tiled(w, fwd=False, dgrad=True)[1]."""
+    w_dgrad_tiled = pack_weight_tiled(w, fwd=False, dgrad=True)[1]. dx may be fp32 (accumulate: dx += result)."""
     lib = L.load()
-    d = conv_desc(dy, dx, 3, 2, L.CONV_DGRAD, L.ACT_NONE, res)
+    d = conv_desc(dy, dx, 3, 2, L.CONV_DGRAD, L.ACT_NONE, res, accumulate)
     L.check(lib.cdet_conv2d_s2_tiled_dgrad(C.byref(d), ptr(dy), ptr(w_dgrad_tiled), None, None, ptr(res), ptr(dx), None, stream()),
             "cdet_conv2d_s2_tiled_dgrad")
     return dx

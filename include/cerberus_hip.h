@@ -108,8 +108,9 @@ int cdet_pack_weights_batched(const cdet_pack_item* items, int32_t n_items, int3
  * `stats` with cdet_conv2d_tiled_stat_blocks(d) pixel blocks of 256 or 128), but the weight operand is the TILED pack below and
  * the pixel tile is staged in LDS once per 32-channel chunk with its halo and reused by all nine taps.
  * Supported (cdet_conv2d_tiled_ok(d) == 1): kh == kw in {1,3}, stride 1, pad kh/2, channels / ld / coff multiples of 8,
- * 16-bit in == out dtype, no fp32 accumulate; 3x3: Ws <= 95 (256 consecutive pixels + linear halo) or Hs, Ws multiples
- * of 16 (16 x 16 pixel patches). The data gradient of such a convolution is a FWD call (d->mode = CDET_CONV_FWD,
+ * 16-bit input; output of the same type, or CDET_F32 (round 4: Detect's biased 1x1 projections, models/yolo.py:82-100, and with
+ * d->accumulate the fp32 fan-in form y += result; no `stats` then); 3x3: Ws <= 95 (256 consecutive pixels + linear halo) or Hs, Ws
+ * multiples of 16 (16 x 16 pixel patches); source / weight buffers below 3 GiB (32-bit buffer addressing). The data gradient of such a convolution is a FWD call (d->mode = CDET_CONV_FWD,
  * source = dY with Cs = Cout, destination = dX with Cd = Cin) on the DGRAD operand written by the packer: autograd's
  * convolution_backward(input) for a stride-1 "same" convolution is the forward convolution with the taps flipped and
  * the channel roles swapped.
@@ -167,8 +168,8 @@ int cdet_conv2d_wgrad_grouped(const cdet_conv_desc* d, const cdet_wgrad_item* it
  * cdet_conv2d_s2_tiled: forward, arguments as cdet_conv2d_tiled (w_tiled = the forward operand of cdet_pack_weights_tiled).
  * cdet_conv2d_s2_tiled_dgrad: data gradient; d is the CDET_CONV_DGRAD descriptor cdet_conv2d takes (source = dY, destination = dX),
  * w_tiled = the DGRAD operand of cdet_pack_weights_tiled, residual = the gradient already in dX's place (fan-in) or NULL; the four
- * parity classes of dX run as four launches. scale / bias / stats must be NULL. _ok: 1 when the geometry is taken (d->mode selects
- * forward or data gradient). */
+ * parity classes of dX run as ONE launch. scale / bias / stats must be NULL. Both take an fp32 destination (and d->accumulate) like
+ * cdet_conv2d_tiled. _ok: 1 when the geometry is taken (d->mode selects forward or data gradient). */
 int cdet_conv2d_s2_tiled_ok(const cdet_conv_desc* d);
 int cdet_conv2d_s2_tiled_stat_blocks(const cdet_conv_desc* d);
 int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,

@@ -2,7 +2,8 @@
 
 The product path stores activations and GEMM operands in bf16, which is a statistical match to the fp32 reference. To check the
 kernels and the weight / BatchNorm handling at the reference's own precision, every convolution here is evaluated as six bf16
-MFMA convolutions accumulated in fp32 (operand splitting: x = x_hi + x_mid + x_lo, likewise w, 8 mantissa bits per term; the six
+MFMA convolutions (round 4: on the tap-resident kernels that carry the product -- conv_halo.hip / conv_vt.hip with their fp32
+accumulate epilogue -- wherever they take the geometry) accumulated in fp32 (operand splitting: x = x_hi + x_mid + x_lo, likewise w, 8 mantissa bits per term; the six
 term pairs above 2^-24 are kept), followed by the folded (or batch-statistics) BatchNorm + SiLU in fp32.
 Plumbing (concat, upsample, max-pool) uses torch ops -- they are exact. The Detect decode runs on the product kernel.
 """
@@ -26,6 +27,12 @@ def _split(t32):
 # operand-term pairs whose product is above 2^-24 relative: (0,0) (0,1) (1,0) (1,1) (0,2) (2,0)
 _PAIRS = [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)]
 
+# which entry point carried each convolution / data gradient (round 4: the tap-resident kernels write and accumulate fp32, so the
+# accuracy chain runs through the kernels that carry the product -- cdet_conv2d_tiled / cdet_conv2d_s2_tiled[_dgrad]; the generic
+# cdet_conv2d only takes the geometries those refuse)
+CALLS = {"tiled": 0, "s2_tiled": 0, "generic": 0, "tiled_dgrad": 0, "s2_tiled_dgrad": 0, "generic_dgrad": 0}
+FORCE_GENERIC = False
+
 
 def conv3(x, w, k, s):
     """x [N,C,H,W] fp32 (cuda), w [O,I,k,k] fp32 -> raw conv [N,O,Ho,Wo] fp32 via 3 bf16 MFMA convs with fp32 accumulation."""
@@ -37,11 +44,27 @@ def conv3(x, w, k, s):
     wp = torch.zeros((Op, Cp, k, k), dtype=torch.float32, device=x.device)
     wp[:O, :Ci] = w
     xs = _split(xn)
-    wpk = [ops.pack_weight(t.float(), torch.bfloat16) for t in _split(wp)]
     Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
     y = ops.new_act(N, Ho, Wo, Op, torch.float32)
+    xv = ops.View(xs[0])
+    path = "generic"
+    if not FORCE_GENERIC:
+        if s == 1 and ops.conv2d_tiled_ok(xv, y, k, 1, accumulate=True):
+            path = "tiled"
+        elif s == 2 and k == 3 and ops.conv2d_s2_tiled_ok(xv, y):
+            path = "s2_tiled"
+    CALLS[path] += 1
+    if path == "generic":
+        wpk = [ops.pack_weight(t.float(), torch.bfloat16) for t in _split(wp)]
+    else:
+        wpk = [ops.pack_weight_tiled(t.float(), torch.bfloat16, fwd=True, dgrad=False)[0] for t in _split(wp)]
     for n_, (i, j) in enumerate(_PAIRS):
-        ops.conv2d(ops.View(xs[i]), wpk[j], y, k, s, accumulate=n_ > 0)
+        if path == "tiled":
+            ops.conv2d_tiled(ops.View(xs[i]), wpk[j], y, k, accumulate=n_ > 0)
+        elif path == "s2_tiled":
+            ops.conv2d_s2_tiled(ops.View(xs[i]), wpk[j], y, accumulate=n_ > 0)
+        else:
+            ops.conv2d(ops.View(xs[i]), wpk[j], y, k, s, accumulate=n_ > 0)
     return y.buf[..., :O].permute(0, 3, 1, 2).contiguous()
 
 
@@ -55,10 +78,28 @@ def dgrad3(dy, w, k, s, x_shape):
     wp = torch.zeros((O, Cp, k, k), dtype=torch.float32, device=dy.device)
     wp[:, :Ci] = w
     ds = _split(dn)
-    wtk = [ops.pack_weight(t.float(), torch.bfloat16, transpose=True, o_pad=Op) for t in _split(wp)]
     dx = ops.new_act(N, H, W, Cp, torch.float32)
+    dv = ops.View(ds[0])
+    path = "generic_dgrad"
+    if not FORCE_GENERIC:
+        if s == 1 and ops.conv2d_tiled_ok(dv, dx, k, 1, accumulate=True):
+            path = "tiled_dgrad"  # the stride-1 data gradient = forward convolution of dY with the DGRAD operand
+        elif s == 2 and k == 3 and ops.conv2d_s2_tiled_ok(dv, dx, L.CONV_DGRAD):
+            path = "s2_tiled_dgrad"
+    CALLS[path] += 1
+    if path == "generic_dgrad":
+        wtk = [ops.pack_weight(t.float(), torch.bfloat16, transpose=True, o_pad=Op) for t in _split(wp)]
+    else:
+        wpp = torch.zeros((Op, Cp, k, k), dtype=torch.float32, device=dy.device)
+        wpp[:O] = wp
+        wtk = [ops.pack_weight_tiled(t.float(), torch.bfloat16, fwd=False, dgrad=True)[1] for t in _split(wpp)]
     for n_, (i, j) in enumerate(_PAIRS):
-        ops.conv2d(ops.View(ds[i]), wtk[j], dx, k, s, mode=L.CONV_DGRAD, accumulate=n_ > 0)
+        if path == "tiled_dgrad":
+            ops.conv2d_tiled(ops.View(ds[i]), wtk[j], dx, k, accumulate=n_ > 0)
+        elif path == "s2_tiled_dgrad":
+            ops.conv2d_s2_tiled_dgrad(ops.View(ds[i]), wtk[j], dx, accumulate=n_ > 0)
+        else:
+            ops.conv2d(ops.View(ds[i]), wtk[j], dx, k, s, mode=L.CONV_DGRAD, accumulate=n_ > 0)
     return dx.buf[..., :Ci].permute(0, 3, 1, 2).contiguous()
 
 

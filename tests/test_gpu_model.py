@@ -133,8 +133,13 @@ def test_eval_boxes_within_1e3_of_reference_at_fp32_accuracy(name):
     arrays, meta = load_golden(name)
     m = _build(meta).eval()
     x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    calls0 = dict(hiprec.CALLS)
     out = hiprec.eval_forward(m, x)
     torch.cuda.synchronize()
+    ran = {k: hiprec.CALLS[k] - calls0[k] for k in calls0}
+    # the chain runs through the kernels that carry the product (conv_halo.hip / conv_vt.hip, fp32 accumulate epilogue); the generic
+    # kernel only takes what those refuse
+    assert ran["tiled"] + ran["s2_tiled"] >= 0.9 * (ran["tiled"] + ran["s2_tiled"] + ran["generic"]) and ran["s2_tiled"] >= 4, ran
     for t in meta["tasks"]:
         y, maps = out[t]
         for i, f in enumerate(maps):
@@ -234,10 +239,16 @@ def test_wide_model_gradients_at_fp32_accuracy_cover_the_pipelined_kernels():
     g, w = oracle_model_from_meta(meta)
     x_cpu = torch.from_numpy(synth.det_image(78, 2, 128))
     t = meta["tasks"][1]
+    calls0 = dict(hiprec.CALLS)
     maps, leaves = hiprec.train_forward(m, x_cpu.to(DEV), t)
     cot = [torch.from_numpy(synth.det_array(78, f"cot/{t}/{i}", f.shape)) for i, f in enumerate(maps)]
     sum((f * c.to(DEV)).sum() for f, c in zip(maps, cot)).backward()
     torch.cuda.synchronize()
+    ran = {k: hiprec.CALLS[k] - calls0[k] for k in calls0}
+    # forward AND data gradients of the chain on the tap-resident kernels (stride 1: conv_halo.hip on the DGRAD operand; stride 2:
+    # the parity-class launch of conv_vt.hip), fp32 accumulate epilogue
+    assert ran["tiled"] >= 50 and ran["s2_tiled"] >= 4 and ran["tiled_dgrad"] >= 50 and ran["s2_tiled_dgrad"] >= 4, ran
+    assert ran["generic"] + ran["generic_dgrad"] <= 0.1 * sum(ran.values()), ran
     wt = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in w.items()}
     of = og.forward(g, wt, x_cpu, t, training=True, bn_updates={})
     sum((f * c).sum() for f, c in zip(of, cot)).backward()
