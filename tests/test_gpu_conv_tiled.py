@@ -203,3 +203,80 @@ def test_pair_kernel_forward_epilogue_stats_and_data_gradient(case, monkeypatch)
     tol = float(x.grad.abs().max())
     _close(dx.nchw(), x.grad, 2 ** -7, 2e-3 * tol)
     _close(out.nchw(), x.grad + prev.nchw().float().cpu(), 2 ** -7, 4e-3 * tol)
+
+
+F32_CASES = [
+    # N, H, W, Cin, Cout, k, stride, dtype
+    (2, 20, 20, 320, 24, 1, 1, torch.bfloat16),    # Detect class projection (nc = 19 / 20 padded to 24) at 20 x 20: half tiles
+    (2, 80, 80, 80, 64, 1, 1, torch.bfloat16),     # Detect box projection at 80 x 80
+    (1, 40, 40, 320, 24, 1, 1, torch.float16),     # fp16 inference form
+    (2, 20, 20, 96, 200, 3, 1, torch.bfloat16),    # 3x3, two cout blocks, linear tiles
+    (1, 32, 48, 80, 80, 3, 1, torch.bfloat16),     # 3x3 patch mode, 96-cout tile, half last chunk
+    (2, 32, 32, 64, 160, 3, 2, torch.bfloat16),    # stride 2 (conv_vt.hip), patch mode
+    (1, 26, 38, 32, 48, 3, 2, torch.float16),      # stride 2, linear tiles
+]
+
+
+@pytest.mark.parametrize("case", F32_CASES)
+def test_tiled_conv_fp32_destination_bias_and_accumulate(case):
+    """HEPI_F32 epilogue (round 4) of conv_halo.hip / conv_vt.hip: an fp32 destination written straight from the accumulators --
+    y = conv * scale + bias into a channel slice of a wider fp32 buffer (Detect's biased 1x1 projections, models/yolo.py:82-100), and the
+    accumulate form y += conv (gradient fan-in; the split-operand accuracy chain of tests/hiprec.py). fp32 in, fp32 out: 1e-5 relative
+    to the tensor scale (accumulation order only)."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, dtype = case
+    g = torch.Generator().manual_seed(41)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype)
+    w = _rt(torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k), dtype)
+    bias = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, s, k // 2)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    src = ops.from_nchw(x.to(DEV), dtype)
+    wf, _ = ops.pack_weight_tiled(w.to(DEV), dtype)
+    yb = torch.full((N, Ho, Wo, Co + 24), 7.0, dtype=torch.float32, device=DEV)
+    dst = ops.View(yb, 8, Co)
+    if s == 1:
+        assert ops.conv2d_tiled_ok(src, dst, k, 1, accumulate=True)
+        run = lambda **kw: ops.conv2d_tiled(src, wf, dst, k, **kw)  # noqa: E731
+    else:
+        assert ops.conv2d_s2_tiled_ok(src, dst)
+        run = lambda **kw: ops.conv2d_s2_tiled(src, wf, dst, **kw)  # noqa: E731
+    run(bias=bias.to(DEV))
+    torch.cuda.synchronize()
+    want = ref + bias.double().view(1, -1, 1, 1)
+    scale_ = float(want.abs().max())
+    assert float((dst.nchw().double().cpu() - want).abs().max()) <= 1e-5 * scale_
+    assert (yb[..., :8] == 7.0).all() and (yb[..., 8 + Co:] == 7.0).all(), "conv wrote outside its channel slice"
+    run(accumulate=True)   # y += conv
+    run(accumulate=True)
+    torch.cuda.synchronize()
+    assert float((dst.nchw().double().cpu() - (want + 2 * ref)).abs().max()) <= 1e-5 * 3 * scale_
+    assert (yb[..., :8] == 7.0).all() and (yb[..., 8 + Co:] == 7.0).all()
+    # a 16-bit destination cannot accumulate: the geometry check refuses it
+    d16 = ops.new_act(N, Ho, Wo, Co, dtype)
+    if s == 1:
+        assert ops.conv2d_tiled_ok(src, d16, k, 1) and not ops.conv2d_tiled_ok(src, d16, k, 1, accumulate=True)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 160, 64, torch.bfloat16), (1, 13, 19, 48, 32, torch.float16)])
+def test_stride2_tiled_dgrad_fp32_destination_accumulates(case):
+    """The four-class stride-2 data gradient of conv_vt.hip into an fp32 dX, overwrite then accumulate."""
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    N, Ho, Wo, Co, Ci, dtype = case
+    H, W = 2 * Ho, 2 * Wo
+    g = torch.Generator().manual_seed(43)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Co * 9), dtype)
+    dy = _rt(torch.randn(N, Co, Ho, Wo, generator=g), dtype)
+    x = torch.zeros(N, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, 2, 1).backward(dy.double())
+    ref = x.grad
+    dyv = ops.from_nchw(dy.to(DEV), dtype)
+    _, wd = ops.pack_weight_tiled(w.to(DEV), dtype, fwd=False, dgrad=True)
+    dx = ops.new_act(N, H, W, Ci, torch.float32)
+    assert ops.conv2d_s2_tiled_ok(dyv, dx, L.CONV_DGRAD)
+    ops.conv2d_s2_tiled_dgrad(dyv, wd, dx)
+    ops.conv2d_s2_tiled_dgrad(dyv, wd, dx, accumulate=True)
+    torch.cuda.synchronize()
+    assert float((dx.nchw().double().cpu() - 2 * ref).abs().max()) <= 1e-5 * 2 * float(ref.abs().max())
