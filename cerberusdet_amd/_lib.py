@@ -102,6 +102,10 @@ _SIGS = {
     "cdet_conv2d_wgrad_grouped_ws_elems": (i64, [C.POINTER(ConvDesc), i32]),
     "cdet_conv2d_wgrad_grouped": (i32, [C.POINTER(ConvDesc), vp, i32, vp, i32, vp]),
     "cdet_stem_conv": (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "cdet_stem_conv1_ok": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32]),
+    "cdet_stem_conv1_pack_elems": (i64, [i32]),
+    "cdet_stem_conv1_pack": (i32, [vp, vp, i32, i32, vp]),
+    "cdet_stem_conv1": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_image_to_nhwc8": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_stem_conv_stat_blocks": (i32, [i32, i32, i32]),
     "cdet_stem_conv_wgrad_ws_elems": (i64, [i32, i32, i32]),

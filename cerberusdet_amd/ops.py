@@ -212,6 +212,21 @@ def stem_conv(img: torch.Tensor, w: torch.Tensor, dst: View, scale=None, bias=No
     return dst
 
 
+def stem_conv1(img: torch.Tensor, w_stem: torch.Tensor, w1: torch.Tensor, dst: View, stem_scale=None, stem_bias=None, scale=None, bias=None,
+               act=L.ACT_SILU):
+    """Eval-form fusion of the first two backbone rows (csrc/stem_conv1.hip): img NCHW, w_stem fp32 [c1,3,3,3], w1 fp32 [c2,c1,3,3]."""
+    lib = L.load()
+    N, c, H, W = img.shape
+    assert c == 3 and img.is_contiguous()
+    c1, c2 = w_stem.shape[0], w1.shape[0]
+    ws = torch.empty(lib.cdet_stem_conv1_pack_elems(c1), dtype=dst.dtype, device=img.device)
+    L.check(lib.cdet_stem_conv1_pack(ptr(w_stem.detach().float().contiguous()), ptr(ws), c1, dt(dst.dtype), stream()), "cdet_stem_conv1_pack")
+    wf, _ = pack_weight_tiled(w1, dst.dtype)
+    L.check(lib.cdet_stem_conv1(ptr(img), dt(img.dtype), ptr(ws), ptr(stem_scale), ptr(stem_bias), ptr(wf), ptr(scale), ptr(bias), ptr(dst), N, H, W,
+                                c1, c2, dt(dst.dtype), dst.ld, dst.coff, act, stream()), "cdet_stem_conv1")
+    return dst
+
+
 def stem_stat_blocks(N, H, W) -> int:
     return L.load().cdet_stem_conv_stat_blocks(N, H, W)
 

@@ -177,6 +177,19 @@ int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_t
 int cdet_conv2d_s2_tiled_dgrad(const cdet_conv_desc* d, const void* dy, const void* w_tiled, const float* scale, const float* bias,
                                const void* residual, void* dx, float* stats, void* stream);
 
+/* Eval-form fusion of the first TWO backbone rows (csrc/stem_conv1.hip, round 4): Conv(3, c1, 3, 2) + Conv(c1, c2, 3, 2), BatchNorm folded
+ * (models/common.py:57-68 as run by models/yolo.py:172-203 in eval mode). The stem's map -- the largest tensor of the network -- is
+ * produced per 16 x 16 output tile inside LDS and never written: same arithmetic and summation order as cdet_stem_conv followed by
+ * cdet_conv2d_s2_tiled. img: NCHW as for cdet_stem_conv; w_stem_packed: cdet_stem_conv1_pack(w_stem fp32 [c1,3,3,3]) (cdet_stem_conv1_pack_elems
+ * 16-bit elements); w1_tiled: the forward operand of cdet_pack_weights_tiled for the second row; y: NHWC [N, H/4, W/4, dst_ld] 16-bit.
+ * cdet_stem_conv1_ok: H, W multiples of 4, c1 <= 96, c2 <= 160, both multiples of 8. */
+int cdet_stem_conv1_ok(int32_t N, int32_t H, int32_t W, int32_t c1, int32_t c2, int32_t img_dtype, int32_t dtype, int32_t dst_ld, int32_t dst_coff);
+int64_t cdet_stem_conv1_pack_elems(int32_t c1);
+int cdet_stem_conv1_pack(const float* w_stem, void* out, int32_t c1, int32_t dtype, void* stream);
+int cdet_stem_conv1(const void* img, int32_t img_dtype, const void* w_stem_packed, const float* stem_scale, const float* stem_bias,
+                    const void* w1_tiled, const float* scale, const float* bias, void* y, int32_t N, int32_t H, int32_t W, int32_t c1,
+                    int32_t c2, int32_t dtype, int32_t dst_ld, int32_t dst_coff, int32_t act, void* stream);
+
 /* Stem convolution (models/common.py:57 for the first backbone row, Cin = 3): reads the image in the
  * reference's NCHW layout (uint8 scaled by 1/255 -- trainers/base_trainer.py:61-63 -- or float), 3x3 stride 2 pad 1,
  * writes NHWC. Direct (non-MFMA) kernel: K = 27, HBM-bound. Same epilogue/stat semantics as cdet_conv2d. */

@@ -309,6 +309,51 @@ def test_stem_conv_and_wgrad(img_dtype):
     _close(dw, w.grad, 4e-3, 4e-3 * float(w.grad.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 80, 160, torch.uint8, torch.bfloat16),      # YOLOv8x rows 0-1: 2.5 chunks, 160-cout tile
+                                  (1, 96, 160, 16, 32, torch.float16, torch.float16),      # YOLOv8n rows 0-1, half image (inference form)
+                                  (2, 72, 104, 48, 96, torch.float32, torch.bfloat16),     # partial tiles (18 x 26 outputs), 1.5 chunks
+                                  (1, 128, 64, 96, 136, torch.bfloat16, torch.bfloat16),   # 3 full chunks, couts not a multiple of 32
+                                  (3, 32, 32, 64, 160, torch.uint8, torch.float16)])
+def test_fused_stem_and_second_row_equal_the_two_kernel_path(case):
+    """csrc/stem_conv1.hip (eval plans: backbone rows 0 and 1 as one kernel, the stem's map kept in LDS) against cdet_stem_conv followed by
+    cdet_conv2d_s2_tiled on the same operands: same arithmetic in the same summation order, so the outputs must carry the SAME BITS --
+    incl. the second row's zero padding around the stem's map, partial tiles and a channel-slice destination. Also pinned against fp32
+    F.conv2d of the rounded operands (one 16-bit rounding of the stem's map, one of the output)."""
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    N, H, W, c1, c2, img_dtype, dtype = case
+    g = torch.Generator().manual_seed(61)
+    img_u8 = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8)
+    img = img_u8 if img_dtype == torch.uint8 else (img_u8.float() / 255).to(img_dtype)
+    w0 = torch.randn(c1, 3, 3, 3, generator=g) / math.sqrt(27)
+    w1 = torch.randn(c2, c1, 3, 3, generator=g) / math.sqrt(9 * c1)
+    s0, b0 = torch.rand(c1, generator=g) + 0.5, torch.randn(c1, generator=g) * 0.3
+    s1, b1 = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g) * 0.3
+    imgd = img.to(DEV).contiguous()
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    # two-kernel path
+    mid = ops.new_act(N, H // 2, W // 2, c1, dtype)
+    ops.stem_conv(imgd, dev(w0), mid, scale=dev(s0), bias=dev(b0), act=L.ACT_SILU)
+    wf, _ = ops.pack_weight_tiled(dev(w1), dtype)
+    two = ops.new_act(N, H // 4, W // 4, c2, dtype)
+    assert ops.conv2d_s2_tiled_ok(mid, two)
+    ops.conv2d_s2_tiled(mid, wf, two, scale=dev(s1), bias=dev(b1), act=L.ACT_SILU)
+    # fused, into a channel slice of a wider buffer
+    yb = torch.full((N, H // 4, W // 4, c2 + 24), 7.0, dtype=dtype, device=DEV)
+    one = ops.View(yb, 16, c2)
+    ops.stem_conv1(imgd, dev(w0), dev(w1), one, stem_scale=dev(s0), stem_bias=dev(b0), scale=dev(s1), bias=dev(b1))
+    torch.cuda.synchronize()
+    assert (yb[..., :16].float() == 7.0).all() and (yb[..., 16 + c2:].float() == 7.0).all(), "wrote outside its channel slice"
+    diff = (one.torch().float() - two.torch().float()).abs()
+    assert torch.equal(one.torch(), two.torch()), f"{int((diff > 0).sum())} of {diff.numel()} outputs differ, max {float(diff.max()):.3g}"
+    # fp32 reference from the rounded operands
+    x = img_u8.float() / 255 if img_dtype == torch.uint8 else img.float()
+    m = _rt(F.silu(F.conv2d(_rt(x, dtype), _rt(w0, dtype), None, 2, 1) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1)), dtype)
+    ref = F.silu(F.conv2d(m, _rt(w1, dtype), None, 2, 1) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    _close(one.nchw(), ref, 2 ** -6, 2e-2)
+
+
 @pytest.mark.parametrize("case", [(2, 36, 44, 80, torch.uint8, torch.bfloat16), (1, 20, 140, 80, torch.float32, torch.bfloat16),
                                   (3, 64, 64, 48, torch.uint8, torch.float16), (1, 18, 130, 64, torch.float16, torch.float16),
                                   (2, 22, 42, 80, torch.uint8, torch.bfloat16)])

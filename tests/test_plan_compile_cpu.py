@@ -54,6 +54,30 @@ def test_every_task_set_compiles_in_train_and_eval_form(cfg_name, tasks):
     assert sum(1 for r in single[(True, tasks[0])].trace if r["kind"] == "copy") <= 2
 
 
+def test_eval_plan_fuses_the_first_two_backbone_rows(monkeypatch):
+    """Eval plans run backbone rows 0 and 1 as one launch (csrc/stem_conv1.hip: the stem's map stays in LDS); training plans and
+    CDET_STEM_FUSE=0 keep the two-kernel form."""
+    from cerberusdet_amd.engine import Plan
+
+    tasks = ["voc", "objects365_animals"]
+    m = _model("v8x_2task.yaml", tasks)
+    dev = torch.device("cpu")
+
+    def names(plan):
+        return [getattr(fn, "__name__", "") for fn, _ in plan.fwd]
+
+    fused = Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev)
+    assert names(fused).count("cdet_stem_conv1") == 1 and "cdet_stem_conv" not in names(fused)
+    assert fused.fwd[0][1] is fused.img_slots[0] and fused.fwd[0][1][9:14] == [2, 64, 64, 80, 160]
+    monkeypatch.setenv("CDET_STEM_FUSE", "0")
+    plain = Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev)
+    assert "cdet_stem_conv1" not in names(plain) and names(plain).count("cdet_stem_conv") == 1
+    assert plain.n_fwd_calls == fused.n_fwd_calls + 1
+    monkeypatch.delenv("CDET_STEM_FUSE")
+    train = Plan(m, [tasks[0]], 2, 64, 64, True, torch.bfloat16, torch.uint8, dev)
+    assert "cdet_stem_conv1" not in names(train)
+
+
 def test_frozen_trunk_plan_compiles_without_backward_for_shared_blocks():
     from cerberusdet_amd.engine import Plan
     from cerberusdet_amd.models import CerberusDet
