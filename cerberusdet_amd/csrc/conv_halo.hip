@@ -725,14 +725,14 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
         abl = e ? atoi(e) : 0;
         if (abl) fprintf(stderr, "[cdet] CDET_HALO_ABLATE=%d: conv results are WRONG by design (timing experiment)\n", abl);
     }
-    if constexpr (DT == CDET_BF16 && NT == 9 && NF == 5 && EPI == HEPI_FULL && NSW == 3 && !PATCH && NG == 2) {
+    if constexpr (DT == CDET_BF16 && NT == 9 && EPI == HEPI_FULL && NSW == 3 && NG == 2 && ((NF == 5 && !PATCH) || (NF == 3 && PATCH))) {
 #define CDET_HABL(N)                                                                                                                                      \
     case N:                                                                                                                                                \
         (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG, N>), dim3(nblocks), dim3(256), lds, s, a);                                       \
         return;
         switch (abl) {
-            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(7) CDET_HABL(8) CDET_HABL(15)
+            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(7) CDET_HABL(8) CDET_HABL(15) CDET_HABL(16) CDET_HABL(24)
             default: break;
         }
 #undef CDET_HABL

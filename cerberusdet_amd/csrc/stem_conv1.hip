@@ -39,7 +39,14 @@ struct Sc1Args {
     int dst_ld, dst_coff, act;
     int tiles_x, tiles_y;
     unsigned w_bytes;
+    int abl;  // -DCDET_PROFILING timing experiments (CDET_SC1_ABLATE): 1 = no SiLU in the stem phase, 2 = no tap steps, 4 = no stem phases, 8 = no patch load
 };
+
+#ifdef CDET_PROFILING
+#define SC1_ABL(bit) (a.abl & (bit))
+#else
+#define SC1_ABL(bit) 0
+#endif
 
 constexpr int SC_PR = 67;                       // image rows (and columns) under a 16 x 16 output tile: 4 * 16 + 3
 constexpr int SC_PITCH = 136;                   // bytes per patch row: entries e = 0 .. 67 <-> image column 4 * ox0 - 3 + e (68 x 2 bytes)
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
         for (int j = 0; j < NWP; ++j) dma_w1(tap_of(s_), s_, j);
 
     // ---- image patch -> LDS (16-bit entries, zeros outside the image) ------------------------------------------------------------------
-    {
+    if (!SC1_ABL(8)) {
         constexpr int ND = (68 + A) / A;               // aligned dwords per patch row: columns 4 * px0 * 4 - 4 ... (entry e = -1 + d * A + j)
         constexpr int NITEM = 3 * SC_PR * ND;
         constexpr int ES = A == 4 ? 1 : (A == 2 ? 2 : 4);
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
 
     // ---- stem plane: the 17 x 17 stem outputs S(2 (py0 + hy - 1) + p, 2 (px0 + hx - 1) + q), channels of `chunk`, into the plane buffer ----
     auto stem_plane = [&](int chunk, int p, int q) __attribute__((always_inline)) {
+        if (SC1_ABL(4)) return;
         // A fragments of the chunk's 32 stem couts (global, L2-resident; drains the ring's DMA as well -- it was issued a step ago)
         u32x4 af[3];
 #pragma unroll
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
                     v[r] = v[r] * s0[r] + b0v[r];
                     v[4 + r] = v[4 + r] * s1[r] + b1v[r];
                 }
-                if (a.act == CDET_ACT_SILU) {
+                if (a.act == CDET_ACT_SILU && !SC1_ABL(1)) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
                 }
@@ -283,9 +291,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
             for (int f = 0; f < NF; ++f) a1[f] = frag_a(ws, 1, f);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!SC1_ABL(2)) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
-        if (!half) {
+        }
+        if (!half && !SC1_ABL(2)) {
 #pragma unroll
             for (int i = 0; i < NM; ++i) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
         }
@@ -482,6 +492,7 @@ extern "C" int cdet_stem_conv1(const void* img, int32_t img_dtype, const void* w
     const int nf = c2 <= 96 ? 3 : 5;
     const int rb = nf * 32;
     a.w_bytes = (unsigned)((int64_t)a.nchunk * 9 * rb * HROW);
+    a.abl = tune_env("CDET_SC1_ABLATE", 0);
     size_t lds = (size_t)HZERO + SC_SB + SC_PATCH_PAD + (size_t)SC_XROWS * HROW + 3 * (size_t)rb * HROW + 1024;
     const size_t epi = (size_t)HZERO + SC_EPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16);
     if (lds < epi) lds = epi;
