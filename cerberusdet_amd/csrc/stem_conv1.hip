@@ -21,6 +21,8 @@
 
 #include "halo_common.h"
 
+#include <type_traits>
+
 namespace cdet {
 
 struct Sc1Args {
@@ -54,12 +56,12 @@ constexpr int SC_PATCH = 3 * SC_PR * SC_PITCH;  // 27336
 constexpr int SC_PATCH_PAD = (SC_PATCH + 255) / 256 * 256;
 constexpr int SC_HPW = PATCH_W + 1;             // plane halo pitch 17 (conv_vt.hip patch mode)
 constexpr int SC_NPOS = SC_HPW * SC_HPW;        // 289 plane positions
-constexpr int SC_XROWS = 320;                   // rows of the plane buffer (10 position fragments of 32)
-constexpr int SC_NFRAG = 10;
+constexpr int SC_XROWS = 290;                   // rows of the plane buffer: 289 positions + a dump row for the lanes of a last, partial fragment
+constexpr int SC_AF = 3 * 64 * 16;                // one chunk's stem A fragments in LDS
 constexpr int SC_SB = 2 * 96 * 4;               // stem scale / bias in LDS
 constexpr int SC_EPI_STAGE_OFF = 6912;
 
-// LDS map: [zero row 256][stem scale/bias 768][patch][plane buffer 320 x 64][weight ring 3 x WTILE][dump 1 KiB]
+// LDS map: [zero row 256][stem scale/bias 768][patch][plane buffer 290 x 64][weight ring 3 x WTILE][dump 1 KiB][stem A fragments 3 KiB]
 template <int DT, int NF, int A>
 __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
     constexpr int NG = 2;
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
     unsigned char* const xbuf = smem + XOFF;
     unsigned char* const wbase = smem + WOFF;
     unsigned char* const wdump = wbase + 3 * WTILE;
+    u32x4* const afl = reinterpret_cast<u32x4*>(wdump + 1024);  // [k16 step][lane]: the current chunk's stem weights
 
     if (t < 16) reinterpret_cast<uint32_t*>(smem)[t] = 0u;  // zero row
     if (t < 96) {
@@ -117,17 +120,21 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
 #pragma unroll
         for (int j = 0; j < NWP; ++j) dma_w1(tap_of(s_), s_, j);
 
-    // ---- image patch -> LDS (16-bit entries, zeros outside the image) ------------------------------------------------------------------
+    // ---- image patch -> LDS (16-bit entries, zeros outside the image). Every thread issues ALL its aligned dword loads before it
+    //      converts the first one (one memory latency per tile instead of one per batch of eight: 10 us -> 4 us per workgroup)
     if (!SC1_ABL(8)) {
-        constexpr int ND = (68 + A) / A;               // aligned dwords per patch row: columns 4 * px0 * 4 - 4 ... (entry e = -1 + d * A + j)
+        constexpr int ND = (68 + A) / A;               // aligned dwords per patch row from column 4 * px0 - 4 on (entry e = -1 + d * A + j)
         constexpr int NITEM = 3 * SC_PR * ND;
+        constexpr int NPT = (NITEM + 255) / 256;       // 15 (uint8) / 28 (16-bit) / 55 (float) dwords per thread
+        constexpr int NB = NPT > 28 ? 28 : NPT;        // per batch (the float image takes two)
         constexpr int ES = A == 4 ? 1 : (A == 2 ? 2 : 4);
         const int iy0 = 4 * py0 - 3, col00 = 4 * px0 - 4;
         uint16_t* const pl = reinterpret_cast<uint16_t*>(patch);
-        for (int base = 0; base < NITEM; base += 256 * 8) {
-            uint32_t v[8];
+        // (a 16-bit image has the compute type -- cdet_stem_conv1_ok -- and its entries are copied bit for bit)
+        for (int base = 0; base < NITEM; base += 256 * NB) {
+            uint32_t v[NB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NB; ++i) {
                 const int idx = base + i * 256 + t;
                 v[i] = 0u;
                 if (idx < NITEM) {
@@ -141,18 +148,18 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NB; ++i) {
                 const int idx = base + i * 256 + t;
                 if (idx < NITEM) {
                     const int row = idx / ND, d = idx - row * ND;
 #pragma unroll
                     for (int e = 0; e < A; ++e) {
                         const int cp = -1 + d * A + e;
-                        float f;
-                        if (A == 4) f = (float)((v[i] >> (8 * e)) & 0xffu) * (1.0f / 255.0f);
-                        else if (A == 2) f = a.img_dtype == CDET_F16 ? f16_bits_to_f32((uint16_t)(v[i] >> (16 * e))) : bf16_bits_to_f32((uint16_t)(v[i] >> (16 * e)));
-                        else f = __uint_as_float(v[i]);
-                        if (cp >= 0 && cp < 68) pl[row * (SC_PITCH / 2) + cp] = Elem<DT>::from_f32(f);
+                        uint16_t bits;
+                        if (A == 2) bits = (uint16_t)(v[i] >> (16 * e));
+                        else if (A == 4) bits = Elem<DT>::from_f32((float)((v[i] >> (8 * e)) & 0xffu) * (1.0f / 255.0f));
+                        else bits = Elem<DT>::from_f32(__uint_as_float(v[i]));
+                        if (cp >= 0 && cp < 68) pl[row * (SC_PITCH / 2) + cp] = bits;
                     }
                 }
             }
@@ -176,75 +183,83 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
 
-    // ---- stem plane: the 17 x 17 stem outputs S(2 (py0 + hy - 1) + p, 2 (px0 + hx - 1) + q), channels of `chunk`, into the plane buffer ----
-    auto stem_plane = [&](int chunk, int p, int q) __attribute__((always_inline)) {
+    // ---- stem plane: the stem outputs S(2 (py0 + hy - 1) + p, 2 (px0 + hx - 1) + q) the plane's taps read -- hy from 1 - p, hx from 1 - q
+    //      (the p = 0 / q = 0 planes have no row / column -1) up to 16 -- channels of `chunk`, into row hy * 17 + hx of the plane buffer.
+    //      P11 289 positions = 10 fragments of 32, P10 / P01 272 = 9, P00 256 = 8: wave w takes fragments w, w + 4, w + 8.
+    //      af: the chunk's three A fragments (loaded once per chunk). half: only the first 16 channels of the chunk exist (c1 % 32 <= 16).
+    auto stem_plane = [&](int chunk, int p, int q, auto HK) __attribute__((always_inline)) {
+        constexpr bool half = decltype(HK)::value;
         if (SC1_ABL(4)) return;
-        // A fragments of the chunk's 32 stem couts (global, L2-resident; drains the ring's DMA as well -- it was issued a step ago)
         u32x4 af[3];
 #pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_) af[s_] = a.ws[(chunk * 3 + s_) * 64 + lane];
-        // per-lane B row offsets: k16 step s, run j reads patch row R(r), r = min(4s + 2h + j, 8), R(r) = (r / 3) * 67 + r % 3
-        int roff[3][2];
-#pragma unroll
-        for (int s_ = 0; s_ < 3; ++s_)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r0 = 4 * s_ + j, r1 = 4 * s_ + 2 + j;
-                const int R0 = ((r0 > 8 ? 8 : r0) / 3) * SC_PR + (r0 > 8 ? 8 : r0) % 3, R1 = ((r1 > 8 ? 8 : r1) / 3) * SC_PR + (r1 > 8 ? 8 : r1) % 3;
-                roff[s_][j] = (h ? R1 : R0) * SC_PITCH;
-            }
+        for (int s_ = 0; s_ < 3; ++s_) af[s_] = afl[s_ * 64 + lane];
+        const int CN = 16 + q, RN = 16 + p;            // columns / rows of the plane that are read
+        const int npos = CN * RN, nfr = (npos + 31) / 32;
         const int poff = (2 * p - 2) * SC_PITCH + (2 * q - 2) * 2;  // plane offset inside the patch (rows, 2-byte entries)
         const float* const sc = ssb + chunk * 32;
         const float* const bi = ssb + 96 + chunk * 32;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 1
-        for (int fr = wave; fr < SC_NFRAG; fr += 4) {
-            const int i = fr * 32 + l31;
-            const int hy = i / SC_HPW, hx = i - hy * SC_HPW;
-            int base = 4 * hy * SC_PITCH + 8 * hx + poff;
-            base = base < 0 ? 0 : base;                               // (row / column -2 of a p = 0 / q = 0 plane: positions no tap reads)
-            base = i < SC_NPOS ? base : 0;
-            f32x16 sa;
+        // opaque copies: every position-dependent value below is invariant across the chunk loop, and hoisted out of it they cost ~50 VGPRs
+        // (spilled to scratch and reloaded inside the phases); recomputing them per phase is a dozen integer instructions per fragment
+        int l31o = l31, ho = h;
+        asm volatile("" : "+v"(l31o), "+v"(ho));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+        for (int rd = 0; rd < 3; ++rd) {
+            const int fr = wave + 4 * rd;              // wave-uniform
+            if (fr < nfr) {
+                const int j = fr * 32 + l31o;
+                const int jy = j / CN, jx = j - jy * CN;
+                const int hy = jy + 1 - p, hx = jx + 1 - q;
+                const bool live = j < npos;
+                const int base = live ? 4 * hy * SC_PITCH + 8 * hx + poff : 0;
+                f32x16 sa;
 #pragma unroll
-            for (int s_ = 0; s_ < 3; ++s_) {
-                const uint32_t* p0 = reinterpret_cast<const uint32_t*>(patch + base + roff[s_][0]);
-                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(patch + base + roff[s_][1]);
-                const u32x4 bf = u32x4{p0[0], p0[1], p1[0], p1[1]};
-                // (the builtin, not the asm wrapper: the compiler then places the wait states between the MFMAs and the VALU epilogue below)
-                if (DT == CDET_BF16) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s_]), __builtin_bit_cast(bf16x8, bf), sa, 0, 0, 0);
-                else sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[s_]), __builtin_bit_cast(f16x8, bf), sa, 0, 0, 0);
-            }
-            const int Y = 2 * (py0 + hy - 1) + p, X = 2 * (px0 + hx - 1) + q;
-            const bool inside = i < SC_NPOS && (unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws;
+                for (int r = 0; r < 16; ++r) sa[r] = 0.f;
 #pragma unroll
-            for (int qq = 0; qq < 4; qq += 2) {
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float lo = sa[4 * qq + r], hi = sa[4 * qq + 4 + r];
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-                    const unsigned s0 = sw[0], s1 = sw[1];
-                    v[r] = __uint_as_float(s0);
-                    v[4 + r] = __uint_as_float(s1);
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    // k16 step s, run jr reads patch row R(r), r = min(4s + 2h + jr, 8), R(r) = (r / 3) * 67 + r % 3
+                    const int r0 = 4 * s_, r1 = 4 * s_ + 2;
+                    const int ra0 = r0 > 8 ? 8 : r0, ra1 = r1 > 8 ? 8 : r1, rb0 = r0 + 1 > 8 ? 8 : r0 + 1, rb1 = r1 + 1 > 8 ? 8 : r1 + 1;
+                    const int o0 = (ho ? (ra1 / 3) * SC_PR + ra1 % 3 : (ra0 / 3) * SC_PR + ra0 % 3) * SC_PITCH;
+                    const int o1 = (ho ? (rb1 / 3) * SC_PR + rb1 % 3 : (rb0 / 3) * SC_PR + rb0 % 3) * SC_PITCH;
+                    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(patch + base + o0);
+                    const uint32_t* p1 = reinterpret_cast<const uint32_t*>(patch + base + o1);
+                    const u32x4 bf = u32x4{p0[0], p0[1], p1[0], p1[1]};
+                    // (the builtin, not the asm wrapper: the compiler then places the wait states between the MFMAs and the VALU epilogue below)
+                    if (DT == CDET_BF16) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s_]), __builtin_bit_cast(bf16x8, bf), sa, 0, 0, 0);
+                    else sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[s_]), __builtin_bit_cast(f16x8, bf), sa, 0, 0, 0);
                 }
-                const int cl = 8 * (qq + h);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + cl), s1 = *reinterpret_cast<const f32x4*>(sc + cl + 4);
-                const f32x4 b0v = *reinterpret_cast<const f32x4*>(bi + cl), b1v = *reinterpret_cast<const f32x4*>(bi + cl + 4);
+                const int Y = 2 * (py0 + hy - 1) + p, X = 2 * (px0 + hx - 1) + q;
+                const bool inside = live && (unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws;
+                const int i = live ? hy * SC_HPW + hx : SC_NPOS;  // plane-buffer row (dead lanes of a partial fragment: the dump row)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = v[r] * s0[r] + b0v[r];
-                    v[4 + r] = v[4 + r] * s1[r] + b1v[r];
+                for (int qq = 0; qq < 4; qq += 2) {
+                    if (half && qq == 2) continue;     // channels 16 .. 31 of the last chunk do not exist: the tap steps never read them
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float lo = sa[4 * qq + r], hi = sa[4 * qq + 4 + r];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                        const unsigned s0 = sw[0], s1 = sw[1];
+                        v[r] = __uint_as_float(s0);
+                        v[4 + r] = __uint_as_float(s1);
+                    }
+                    const int cl = 8 * (qq + ho);
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + cl), s1 = *reinterpret_cast<const f32x4*>(sc + cl + 4);
+                    const f32x4 b0v = *reinterpret_cast<const f32x4*>(bi + cl), b1v = *reinterpret_cast<const f32x4*>(bi + cl + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = v[r] * s0[r] + b0v[r];
+                        v[4 + r] = v[4 + r] * s1[r] + b1v[r];
+                    }
+                    if (a.act == CDET_ACT_SILU && !SC1_ABL(1)) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+                    }
+                    u32x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = inside ? hpack2<DT>(v[2 * r], v[2 * r + 1]) : 0u;
+                    *reinterpret_cast<u32x4*>(xbuf + i * HROW + (((qq + ho) ^ ((i >> 2) & 3)) << 4)) = pk;
                 }
-                if (a.act == CDET_ACT_SILU && !SC1_ABL(1)) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-                }
-                u32x4 pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk[r] = inside ? hpack2<DT>(v[2 * r], v[2 * r + 1]) : 0u;
-                if (i < SC_XROWS) *reinterpret_cast<u32x4*>(xbuf + i * HROW + (((qq + h) ^ ((i >> 2) & 3)) << 4)) = pk;
             }
         }
     };
@@ -271,75 +286,96 @@ __global__ __launch_bounds__(256, 2) void stem_conv1_kernel(const Sc1Args a) {
         return *reinterpret_cast<const u32x4*>(ws_ + ((aoff0 ^ (s_ << 5)) + f * 32 * HROW));
     };
 
-    // One tap step: st = chunk * 9 + u (ring stage u % 3). Tile st has landed and is visible when the step starts (the barrier of the
-    // previous step or of the stem phase); tile st + 3 is issued into the stage freed by this step's mid barrier.
-    auto run_step = [&](int chunk, int u, bool half) __attribute__((always_inline)) {
-        const int stage = u % 3;
+    // One tap step: st = chunk * 9 + u (ring stage u % 3), two-phase as in conv_vt.hip. Tile st has landed and is visible when the step
+    // starts (the mid-step barrier of the previous step / the barrier behind the stem phase).
+    //   phase A: MFMAs of k16 #0 with the fragment reads of k16 #1 in their shadow; counted wait (tile st + 1, issued two steps ago, has
+    //            landed) + barrier: nobody reads stage u % 3 or -- at a plane's last step -- the plane buffer any more;
+    //   phase B: DMA of tile st + 3 into the freed stage, MFMAs of k16 #1, and inside a plane the k16 #0 fragments of step st + 1.
+    // first / last: the step opens / closes its parity plane (the plane buffer is rewritten between planes, so the fragment
+    // prefetch stops at the boundary and the first step reads its own).
+    u32x4 a0[NF], b0[NG], a1[NF], b1[NG];
+    int bo_cur[NG], bo_nxt[NG];
+    auto run_step = [&](int chunk, int u, auto HK, bool first, bool last) __attribute__((always_inline)) {
+        constexpr bool half = decltype(HK)::value;
+        const int stage = u % 3, stn = (u + 1) % 3;
         const unsigned char* ws = wbase + stage * WTILE;
+        const unsigned char* wsn = wbase + stn * WTILE;
         constexpr int KY[9] = {0, 0, 2, 2, 0, 2, 1, 1, 1}, KX[9] = {0, 2, 0, 2, 1, 1, 0, 2, 1};
-        int bo[NG];
-        b_offsets(KY[u], KX[u], bo);
-        u32x4 a0[NF], b0[NG], a1[NF], b1[NG];
+        if (first) {
+            b_offsets(KY[u], KX[u], bo_cur);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) b0[g] = frag_b(bo, 0, g);
+            for (int g = 0; g < NG; ++g) b0[g] = frag_b(bo_cur, 0, g);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) a0[f] = frag_a(ws, 0, f);
-        if (!half) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) b1[g] = frag_b(bo, 1, g);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) a1[f] = frag_a(ws, 1, f);
+            for (int f = 0; f < NF; ++f) a0[f] = frag_a(ws, 0, f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!SC1_ABL(2)) {
 #pragma unroll
-        for (int i = 0; i < NM; ++i) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
+        for (int i = 0; i < NM; ++i) {
+            if (!SC1_ABL(2)) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
+            if (!half) {
+                if (i < NG) b1[i] = frag_b(bo_cur, 1, i);
+                else if (i < NG + NF) a1[i - NG] = frag_a(ws, 1, i - NG);
+            }
+            if (i == NM - 1 && !last) b_offsets(KY[(u + 1) % 9], KX[(u + 1) % 9], bo_nxt);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (!half && !SC1_ABL(2)) {
-#pragma unroll
-            for (int i = 0; i < NM; ++i) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // every wave is done with this stage and with the plane rows of this tap: tile st + 1 (issued two steps ago) must have landed
         wait_vm_lgkm0<NWP>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         {
             const int u3 = (u + 3) % 9, c3 = chunk + (u + 3) / 9;
 #pragma unroll
-            for (int j = 0; j < NWP; ++j) dma_w1(c3 * 9 + tap_of(u3), stage, j);
+            for (int i = 0; i < NM; ++i) {
+                if (!half && !SC1_ABL(2)) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+                if (i < NWP) dma_w1(c3 * 9 + tap_of(u3), stage, i);
+                if (!last) {
+                    if (i >= 1 && i - 1 < NG) b0[i - 1] = frag_b(bo_nxt, 0, i - 1);
+                    else if (i >= 1 && i - 1 < NG + NF) a0[i - 1 - NG] = frag_a(wsn, 0, i - 1 - NG);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!last) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) bo_cur[g] = bo_nxt[g];
         }
     };
 
-    __syncthreads();  // patch, zero row, scale / bias visible
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        const bool half = a.halfk && chunk == a.nchunk - 1;
+    // one 32-channel chunk of the stem's output: its A fragments into LDS, then per parity plane the stem phase and the plane's tap steps
+    auto run_chunk = [&](int chunk, auto HK) __attribute__((always_inline)) {
+        if (t < 192) afl[t] = a.ws[chunk * 192 + t];  // (the previous chunk's last read of this area lies four barriers back)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         // P11: taps (0,0) (0,2) (2,0) (2,2)
-        stem_plane(chunk, 1, 1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stem_plane(chunk, 1, 1, HK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        run_step(chunk, 0, half);
-        run_step(chunk, 1, half);
-        run_step(chunk, 2, half);
-        run_step(chunk, 3, half);
+        run_step(chunk, 0, HK, true, false);
+        run_step(chunk, 1, HK, false, false);
+        run_step(chunk, 2, HK, false, false);
+        run_step(chunk, 3, HK, false, true);
         // P10: taps (0,1) (2,1)
-        stem_plane(chunk, 1, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stem_plane(chunk, 1, 0, HK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        run_step(chunk, 4, half);
-        run_step(chunk, 5, half);
+        run_step(chunk, 4, HK, true, false);
+        run_step(chunk, 5, HK, false, true);
         // P01: taps (1,0) (1,2)
-        stem_plane(chunk, 0, 1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stem_plane(chunk, 0, 1, HK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        run_step(chunk, 6, half);
-        run_step(chunk, 7, half);
+        run_step(chunk, 6, HK, true, false);
+        run_step(chunk, 7, HK, false, true);
         // P00: tap (1,1)
-        stem_plane(chunk, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stem_plane(chunk, 0, 0, HK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        run_step(chunk, 8, half);
-    }
+        run_step(chunk, 8, HK, true, true);
+    };
+    // (the barrier inside run_chunk also publishes the patch, the zero row and the scale / bias table)
+    const int nfull = a.halfk ? a.nchunk - 1 : a.nchunk;
+    for (int chunk = 0; chunk < nfull; ++chunk) run_chunk(chunk, std::false_type{});
+    if (a.halfk) run_chunk(nfull, std::true_type{});  // the last chunk holds at most 16 channels: its second k16 half does not exist
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -453,7 +489,7 @@ extern "C" int cdet_stem_conv1_ok(int32_t N, int32_t H, int32_t W, int32_t c1, i
     if (N <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 4 != 0) return 0;
     if (c1 % 8 != 0 || c1 < 8 || c1 > 96 || c2 % 8 != 0 || c2 < 8 || c2 > 160) return 0;
     if (!(dtype == CDET_BF16 || dtype == CDET_F16)) return 0;
-    if (!(img_dtype == CDET_U8 || img_dtype == CDET_F32 || img_dtype == CDET_F16 || img_dtype == CDET_BF16)) return 0;
+    if (!(img_dtype == CDET_U8 || img_dtype == CDET_F32 || img_dtype == dtype)) return 0;  // a 16-bit image must have the compute type
     if (dst_ld % 8 != 0 || dst_coff % 8 != 0) return 0;
     if ((int64_t)N * (H / 4) * (W / 4) * dst_ld >= (1ll << 31)) return 0;
     return 1;
@@ -475,7 +511,7 @@ extern "C" int cdet_stem_conv1(const void* img, int32_t img_dtype, const void* w
     CDET_CHECK_ARG(img && w_stem_packed && w1_tiled && y, "cdet_stem_conv1: null pointer");
     CDET_CHECK_ARG(cdet_stem_conv1_ok(N, H, W, c1, c2, img_dtype, dtype, dst_ld, dst_coff),
                    "cdet_stem_conv1: unsupported geometry (H, W multiples of 4; stem couts <= 96, second-row couts <= 160, both multiples of 8; "
-                   "16-bit activations)");
+                   "16-bit activations; image uint8, float or of the activation type)");
     const int per = img_dtype == CDET_U8 ? 4 : (img_dtype == CDET_F32 ? 1 : 2);
     CDET_CHECK_ARG(W % per == 0, "cdet_stem_conv1: image rows must be whole dwords");
     Sc1Args a;
@@ -493,7 +529,7 @@ extern "C" int cdet_stem_conv1(const void* img, int32_t img_dtype, const void* w
     const int rb = nf * 32;
     a.w_bytes = (unsigned)((int64_t)a.nchunk * 9 * rb * HROW);
     a.abl = tune_env("CDET_SC1_ABLATE", 0);
-    size_t lds = (size_t)HZERO + SC_SB + SC_PATCH_PAD + (size_t)SC_XROWS * HROW + 3 * (size_t)rb * HROW + 1024;
+    size_t lds = (size_t)HZERO + SC_SB + SC_PATCH_PAD + (size_t)SC_XROWS * HROW + 3 * (size_t)rb * HROW + 1024 + SC_AF;
     const size_t epi = (size_t)HZERO + SC_EPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16);
     if (lds < epi) lds = epi;
     const int nblocks = N * a.tiles_x * a.tiles_y;
