@@ -72,6 +72,10 @@ class WgradItem(C.Structure):
     _fields_ = [("x", vp), ("dy", vp), ("dw", vp), ("src_ld", i32), ("src_coff", i32)]
 
 
+class CatSrc(C.Structure):
+    _fields_ = [("x", vp), ("ld", i32), ("coff", i32), ("C", i32), ("upsample", i32)]
+
+
 class ParamSlot(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("mom", vp), ("ema", vp), ("n", i64), ("group", i32), ("weight_decay", f32),
                 ("inv_div", f32), ("first_step", i32)]
@@ -89,6 +93,8 @@ _SIGS = {
     "cdet_conv2d_tiled_ok": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_tiled_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_tiled": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_conv2d_tiled_cat_ok": (i32, [C.POINTER(ConvDesc), C.POINTER(CatSrc), i32]),
+    "cdet_conv2d_tiled_cat": (i32, [C.POINTER(ConvDesc), C.POINTER(CatSrc), i32, vp, vp, vp, vp, vp, vp]),
     "cdet_conv2d_s2_tiled_ok": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_s2_tiled_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d_s2_tiled": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -50,6 +50,7 @@ struct HaloArgs {
     int Hd, Wd, cp, cq;  // OMAP: tile pixel (n, y, x) is written to pixel (2y + cp, 2x + cq) of an Hd x Wd destination
     int halfk;  // 3x3 only: the last 32-channel chunk holds at most 16 channels (Cs = 80): its second k16 half is all zeros and is skipped
     int accum;  // HEPI_F32 only: y (fp32) += result
+    CatSrcs cat;  // CAT instantiations (1x1 only): the source is a virtual Concat of up to three buffers (halo_common.h)
 };
 
 constexpr int HEPI_STAGE_OFF = 6912;  // epilogue LDS map (after HZERO): statistics scratch [4][2][HC] fp32, scale/bias [2][HC] fp32, then the store staging
@@ -72,8 +73,9 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // of 256 consecutive pixels (halo 256 + 2W + 2 rows) -- half the halo on the 80-wide maps, and the only form that fits for 160-wide.
 // ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no epilogue
 // stores, 16 = no K loop
-template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false>
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false, bool CAT = false>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
+    static_assert(!CAT || (NT == 1 && !PATCH && !OMAP), "a virtual-Concat source is a 1x1 convolution's");
     constexpr int HPB = 128 * NG;         // pixels per block: a wave owns NG 32-pixel fragments (NG = 1: half tiles for layers whose
                                           // 256-pixel tiles would leave most CUs idle, e.g. the 20 x 20 maps at batch 32)
     static_assert(NG == 2 || !PATCH, "the 16 x 16 patch form is a 256-pixel tile");
@@ -150,6 +152,21 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         const unsigned off = ((unsigned)g * (unsigned)a.src_ld + (unsigned)a.src_coff) * 2u + ((unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4);
         xvoff[i] = ok ? off : HSENT;
     }
+    // CAT: the same pieces inside segments 1 and 2 (segment 0 lives in xvoff)
+    constexpr int NXC = CAT ? 2 * NG : 1;
+    unsigned xv1[NXC], xv2[NXC];
+    if (CAT) {
+#pragma unroll
+        for (int i = 0; i < NXC; ++i) {
+            const int hrow = 16 * (4 * i + wave) + (lane >> 2);
+            const int g = p0 + hrow;
+            const bool ok = g < a.M;
+            const unsigned slot = (unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4;
+            xvoff[i] = ok ? cat_pixel_off(a.cat, 0, g) + slot : HSENT;
+            xv1[i] = (ok && a.cat.n > 1) ? cat_pixel_off(a.cat, 1, g) + slot : HSENT;
+            xv2[i] = (ok && a.cat.n > 2) ? cat_pixel_off(a.cat, 2, g) + slot : HSENT;
+        }
+    }
     const bool partial = (a.Cs & 31) != 0;                   // wave-uniform
     const int xls = (lane & 3) ^ ((lane >> 4) & 3);          // logical 16-byte slot this lane fetches (the same for every piece)
     // ---- W DMA: a plain linear copy of the packed tile; wave w copies bytes [w*WQ, (w+1)*WQ) -----------------------------------
@@ -166,8 +183,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         else if (j == NWP - 1 && lane < 32) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);  // the 512-byte tail of the wave's share
     };
     auto dma_x = [&](int i, int chunk, int xb) {  // piece i of this wave, channels of `chunk` -> pixel buffer xb
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, chunk < a.nchunk ? (int)a.x_bytes : 0, 0x00020000);
         unsigned char* dst = xbase + xb * XHB + (4 * i + wave) * 1024;
+        if constexpr (CAT) {  // the chunk's segment (wave-uniform): its buffer, its pixel offsets, the chunk's position inside it
+            const int sg = chunk >= a.cat.c0[2] ? 2 : (chunk >= a.cat.c0[1] ? 1 : 0);
+            const uint16_t* xp = sg == 2 ? a.cat.x[2] : (sg == 1 ? a.cat.x[1] : a.cat.x[0]);
+            const unsigned xb_ = sg == 2 ? a.cat.bytes[2] : (sg == 1 ? a.cat.bytes[1] : a.cat.bytes[0]);
+            const int cf = sg == 2 ? a.cat.c0[2] : (sg == 1 ? a.cat.c0[1] : 0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, chunk < a.nchunk ? (int)xb_ : 0, 0x00020000);
+            unsigned v = sg == 2 ? xv2[i < NXC ? i : 0] : (sg == 1 ? xv1[i < NXC ? i : 0] : xvoff[i]);
+            if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
+            dma16<CDET_HALO_X_AUX>(rs, v, (unsigned)(chunk - cf) * 64u, dst);
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, chunk < a.nchunk ? (int)a.x_bytes : 0, 0x00020000);
         unsigned v = xvoff[i] + (unsigned)chunk * 64u;
         // last partial chunk (Cs % 32 != 0, the 80-channel layers): the lanes whose 8-channel slot lies beyond Cs fetch zeros -- what
         // sits there in memory is a neighbouring channel slice (possibly never written), and 0-weight x NaN would still be NaN
@@ -741,6 +769,28 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
     hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG>), dim3(nblocks), dim3(256), lds, s, a);
 }
 
+template <int DT, int NF, int NG>
+static void launch_halo_cat(const HaloArgs& a, size_t lds, int nblocks, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, 1, NF, HEPI_FULL, 3, false, NG, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<DT, 1, NF, HEPI_FULL, 3, false, NG, 0, false, true>), dim3(nblocks), dim3(256), lds, s, a);
+}
+
+template <int DT>
+static void dispatch_halo_cat(const HaloArgs& a, const HaloPlan& pl, int nblocks, hipStream_t s) {
+    if (pl.nf == 5) {
+        if (pl.ng == 1) launch_halo_cat<DT, 5, 1>(a, pl.lds, nblocks, s);
+        else launch_halo_cat<DT, 5, 2>(a, pl.lds, nblocks, s);
+    } else {
+        if (pl.ng == 1) launch_halo_cat<DT, 3, 1>(a, pl.lds, nblocks, s);
+        else launch_halo_cat<DT, 3, 2>(a, pl.lds, nblocks, s);
+    }
+}
+
 template <int DT, int NF, int EPI>
 static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nblocks, hipStream_t s) {
     if (pl.ng == 1) {
@@ -774,7 +824,33 @@ namespace cdet {
 // csrc/conv_pair.hip: 1x1 layers with an even number of 160-cout blocks -- two blocks share the staged pixel tile
 bool pair_plan_ok(const cdet_conv_desc* d);
 int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
-                float* stats, hipStream_t s);
+                float* stats, hipStream_t s, const CatSrcs* cat = nullptr);
+
+// host-side check + fill of a virtual-Concat source list against the convolution's descriptor
+static int cat_fill(const cdet_conv_desc* d, const cdet_cat_src* srcs, int n, CatSrcs* c) {
+    if (!srcs || n < 1 || n > 3) return 0;
+    if (!(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->Hs == d->Hd && d->Ws == d->Wd)) return 0;
+    int ctot = 0;
+    for (int i = 0; i < 3; ++i) {
+        c->x[i] = nullptr; c->bytes[i] = 0; c->ld[i] = 0; c->coff[i] = 0; c->up[i] = 0;
+        c->c0[i] = 0x7fffffff;
+    }
+    for (int i = 0; i < n; ++i) {
+        const cdet_cat_src& sc = srcs[i];
+        if (!sc.x || sc.C <= 0 || sc.C % 8 != 0 || sc.ld % 8 != 0 || sc.coff % 8 != 0 || sc.coff + sc.C > sc.ld) return 0;
+        if (i + 1 < n && sc.C % 32 != 0) return 0;       // segments start on 32-channel chunks
+        if (sc.upsample && (d->Hs % 2 != 0 || d->Ws % 2 != 0)) return 0;
+        const int64_t px = sc.upsample ? (int64_t)d->N * (d->Hs / 2) * (d->Ws / 2) : (int64_t)d->N * d->Hs * d->Ws;
+        const int64_t bytes = px * sc.ld * 2;
+        if (bytes >= 0xC0000000ll) return 0;
+        c->x[i] = (const uint16_t*)sc.x; c->bytes[i] = (unsigned)bytes; c->ld[i] = sc.ld; c->coff[i] = sc.coff; c->up[i] = sc.upsample ? 1 : 0;
+        c->c0[i] = ctot / 32;
+        ctot += sc.C;
+    }
+    if (ctot != d->Cs) return 0;
+    c->n = n; c->H = d->Hs; c->W = d->Ws;
+    return 1;
+}
 }  // namespace cdet
 
 using namespace cdet;
@@ -822,8 +898,36 @@ extern "C" int cdet_pack_weight_tiled(const float* w_oihw, void* w_fwd, void* w_
     return 0;
 }
 
+static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
+                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat);
+
+extern "C" int cdet_conv2d_tiled_cat_ok(const cdet_conv_desc* d, const cdet_cat_src* srcs, int32_t n_src) {
+    if (!d) return 0;
+    CatSrcs c;
+    cdet_conv_desc dd = *d;  // (the descriptor's own source fields are not used: any aligned values pass the geometry check)
+    dd.src_ld = (d->Cs + 7) / 8 * 8; dd.src_coff = 0;
+    return cat_fill(d, srcs, n_src, &c) && halo_plan(&dd).ok && d->out_dtype == d->dtype ? 1 : 0;
+}
+
+extern "C" int cdet_conv2d_tiled_cat(const cdet_conv_desc* d, const cdet_cat_src* srcs, int32_t n_src, const void* w_tiled, const float* scale,
+                                     const float* bias, const void* residual, void* y, void* stream) {
+    CDET_CHECK_ARG(d && srcs && w_tiled && y, "cdet_conv2d_tiled_cat: null pointer");
+    CatSrcs c;
+    CDET_CHECK_ARG(cat_fill(d, srcs, n_src, &c), "cdet_conv2d_tiled_cat: bad source list (1x1 stride 1; 1-3 segments, channels / ld / coff multiples of 8, all "
+                                                 "but the last a multiple of 32 channels, sum = Cs; upsampled segments need even H, W; buffers < 3 GiB)");
+    CDET_CHECK_ARG(d->out_dtype == d->dtype, "cdet_conv2d_tiled_cat: 16-bit in == out");
+    cdet_conv_desc dd = *d;
+    dd.src_ld = (d->Cs + 7) / 8 * 8; dd.src_coff = 0;
+    return conv2d_tiled_impl(&dd, srcs[0].x, w_tiled, scale, bias, residual, y, nullptr, stream, &c);
+}
+
 extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                                  const void* residual, void* y, float* stats, void* stream) {
+    return conv2d_tiled_impl(d, x, w_tiled, scale, bias, residual, y, stats, stream, nullptr);
+}
+
+static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
+                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat) {
     CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_tiled: null pointer");
     const HaloPlan pl = halo_plan(d);
     CDET_CHECK_ARG(pl.ok, "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs/Cd/ld/coff %% 8 == 0, 16-bit in, out = the same "
@@ -833,7 +937,7 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_tiled: the data gradient is a FWD call on the DGRAD operand of cdet_pack_weights_tiled");
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_tiled: residual ld/coff must be multiples of 8");
     if (!f32out && pl.nf == 5 && pl.ng == 2 && pair_plan_ok(d)) {
-        const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream);
+        const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream, cat);
         CDET_LAUNCH_CHECK();
         return rc;
     }
@@ -861,6 +965,14 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
     const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
     const int nblocks = a.n_pblk * a.n_cblk;
     hipStream_t s = (hipStream_t)stream;
+    if (cat) {
+        a.cat = *cat;
+        if (d->dtype == CDET_BF16) dispatch_halo_cat<CDET_BF16>(a, pl, nblocks, s);
+        else dispatch_halo_cat<CDET_F16>(a, pl, nblocks, s);
+        CDET_LAUNCH_CHECK();
+        return 0;
+    }
+    a.cat.n = 0;
     if (d->dtype == CDET_BF16) dispatch_halo<CDET_BF16>(a, d->kh, full, f32out, pl, nblocks, s);
     else dispatch_halo<CDET_F16>(a, d->kh, full, f32out, pl, nblocks, s);
     CDET_LAUNCH_CHECK();

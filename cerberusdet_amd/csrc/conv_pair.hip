@@ -28,12 +28,13 @@ struct PairArgs {
     int src_ld, src_coff, dst_ld, dst_coff, res_ld, res_coff;
     int nchunk, Cs, n_pblk, n_pair, act;
     unsigned x_bytes, w_bytes;
+    CatSrcs cat;  // CAT instantiations: the source is a virtual Concat of up to three buffers (halo_common.h)
 };
 
 constexpr int PR_XB = HP * HROW;          // one pixel buffer: 256 rows of 64 B
 constexpr int PR_STAGE_OFF = 13312;       // epilogue LDS map: statistics scratch [8][2][160] fp32 (10 KiB), scale / bias [2][320] fp32, staging
 
-template <int DT, int EPI>
+template <int DT, int EPI, bool CAT = false>
 __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
     constexpr int NF = 5, NG = 2, HC = 160;
     constexpr int WTILE = HC * HROW;      // one cout block's tile: 10 KiB
@@ -73,12 +74,36 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
         const unsigned off = ((unsigned)g * (unsigned)a.src_ld + (unsigned)a.src_coff) * 2u + ((unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4);
         xvoff[i] = g < a.M ? off : HSENT;
     }
+    unsigned xv1[NXP], xv2[NXP];  // CAT: the same pieces inside segments 1 and 2 (segment 0 lives in xvoff)
+    if (CAT) {
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int hrow = 16 * (8 * i + wave) + (lane >> 2);
+            const int g = p0 + hrow;
+            const bool ok = g < a.M;
+            const unsigned slot = (unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4;
+            xvoff[i] = ok ? cat_pixel_off(a.cat, 0, g) + slot : HSENT;
+            xv1[i] = (ok && a.cat.n > 1) ? cat_pixel_off(a.cat, 1, g) + slot : HSENT;
+            xv2[i] = (ok && a.cat.n > 2) ? cat_pixel_off(a.cat, 2, g) + slot : HSENT;
+        }
+    }
     const bool partial = (a.Cs & 31) != 0;
     const int xls = (lane & 3) ^ ((lane >> 4) & 3);
 
     auto dma_x = [&](int i, int chunk, int xb) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, chunk < a.nchunk ? (int)a.x_bytes : 0, 0x00020000);
         unsigned char* dst = xbase + xb * PR_XB + (8 * i + wave) * 1024;
+        if constexpr (CAT) {  // the chunk's segment (wave-uniform): its buffer, its pixel offsets, the chunk's position inside it
+            const int sg = chunk >= a.cat.c0[2] ? 2 : (chunk >= a.cat.c0[1] ? 1 : 0);
+            const uint16_t* xp = sg == 2 ? a.cat.x[2] : (sg == 1 ? a.cat.x[1] : a.cat.x[0]);
+            const unsigned xb_ = sg == 2 ? a.cat.bytes[2] : (sg == 1 ? a.cat.bytes[1] : a.cat.bytes[0]);
+            const int cf = sg == 2 ? a.cat.c0[2] : (sg == 1 ? a.cat.c0[1] : 0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, chunk < a.nchunk ? (int)xb_ : 0, 0x00020000);
+            unsigned v = sg == 2 ? xv2[i] : (sg == 1 ? xv1[i] : xvoff[i]);
+            if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
+            dma16<CDET_HALO_X_AUX>(rs, v, (unsigned)(chunk - cf) * 64u, dst);
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, chunk < a.nchunk ? (int)a.x_bytes : 0, 0x00020000);
         unsigned v = xvoff[i];
         if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
         dma16<CDET_HALO_X_AUX>(rs, v, (unsigned)chunk * 64u, dst);
@@ -302,14 +327,14 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
     }
 }
 
-template <int DT, int EPI>
+template <int DT, int EPI, bool CAT = false>
 static void launch_pair(const PairArgs& a, size_t lds, int nblocks, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_pair_kernel<DT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_pair_kernel<DT, EPI, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((conv_pair_kernel<DT, EPI>), dim3(nblocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<DT, EPI, CAT>), dim3(nblocks), dim3(512), lds, s, a);
 }
 
 // 1x1, stride 1, 16-bit in == out, an even number (>= 2) of 160-cout blocks, enough pixel tiles to give every CU a workgroup
@@ -329,7 +354,7 @@ bool pair_plan_ok(const cdet_conv_desc* d) {
 }
 
 int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
-                float* stats, hipStream_t s) {
+                float* stats, hipStream_t s, const CatSrcs* cat) {
     PairArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_tiled; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
     a.y = y; a.stats = stats;
@@ -350,6 +375,13 @@ int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, con
     const size_t lds = loop > epi ? loop : epi;
     const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
     const int nblocks = a.n_pblk * a.n_pair;
+    if (cat) {
+        a.cat = *cat;
+        if (d->dtype == CDET_BF16) launch_pair<CDET_BF16, HEPI_FULL, true>(a, lds, nblocks, s);
+        else launch_pair<CDET_F16, HEPI_FULL, true>(a, lds, nblocks, s);
+        return 0;
+    }
+    a.cat.n = 0;
     if (d->dtype == CDET_BF16) {
         if (full) launch_pair<CDET_BF16, HEPI_FULL>(a, lds, nblocks, s);
         else launch_pair<CDET_BF16, HEPI_RAW>(a, lds, nblocks, s);

@@ -16,6 +16,29 @@ constexpr int PATCH_W = 16, PATCH_HPW = PATCH_W + 2;  // patch mode: 16 x 16 pix
 constexpr int HEPI_RAW = 0, HEPI_FULL = 1, HEPI_F32 = 2;  // epilogue: raw 16-bit output (+ BN partial sums) / scale, bias, SiLU, residual / the same
                                                       // arithmetic into an fp32 destination, optionally accumulating onto it
 
+// Virtual Concat (+ nearest 2x Upsample) as the source of a 1x1 convolution (models/common.py:288-295 in front of every neck C2f's cv1): up to three
+// channel segments, each a slice of its own NHWC buffer, visited in order by the K loop; segment s covers K chunks [c0[s], c0[s + 1]). `up`: the
+// segment is read through a nearest-neighbour 2x upsample (source pixel (y / 2, x / 2) of an H/2 x W/2 map) -- neither the upsampled map nor the
+// concatenated buffer is ever written. All but the last segment hold a multiple of 32 channels.
+struct CatSrcs {
+    const uint16_t* x[3];
+    unsigned bytes[3];
+    int ld[3], coff[3], c0[3], up[3];
+    int n, H, W;  // pixel geometry of the convolution (for the upsampled segments)
+};
+
+// byte offset (before the chunk offset and the 16-byte slot) of pixel g of the N x H x W pixel space inside segment s
+__device__ __forceinline__ unsigned cat_pixel_off(const CatSrcs& c, int s, int g) {
+    int gs = g;
+    if (c.up[s]) {
+        const int hw = c.H * c.W;
+        const int n = g / hw, r = g - n * hw;
+        const int y = r / c.W, x = r - y * c.W;
+        gs = (n * (c.H >> 1) + (y >> 1)) * (c.W >> 1) + (x >> 1);
+    }
+    return ((unsigned)gs * (unsigned)c.ld[s] + (unsigned)c.coff[s]) * 2u;
+}
+
 template <int DT>
 __device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c) {
     if (DT == CDET_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));

@@ -131,6 +131,36 @@ def conv2d_tiled(src: View, w_tiled, dst: View, k, scale=None, bias=None, act=L.
     return dst
 
 
+def cat_srcs(parts):
+    """parts: [(View, upsample: bool)] -> (ctypes array of cdet_cat_src, total channels)."""
+    arr = (L.CatSrc * len(parts))()
+    for i, (v, up) in enumerate(parts):
+        arr[i].x, arr[i].ld, arr[i].coff, arr[i].C, arr[i].upsample = v.buf.data_ptr(), v.ld, v.coff, v.C, int(bool(up))
+    return arr, sum(v.C for v, _ in parts)
+
+
+def cat_desc(parts, dst: View, act=L.ACT_NONE, res: Optional[View] = None) -> L.ConvDesc:
+    """Descriptor of a 1x1 convolution over the virtual Concat of `parts` (an upsampled part is half the destination's size)."""
+    d = L.ConvDesc()
+    d.N, d.Hs, d.Ws, d.Cs = dst.N, dst.H, dst.W, sum(v.C for v, _ in parts)
+    d.Hd, d.Wd, d.Cd = dst.H, dst.W, dst.C
+    d.kh = d.kw = 1
+    d.stride, d.pad, d.mode = 1, 0, L.CONV_FWD
+    d.dtype, d.out_dtype, d.act = dt(parts[0][0].dtype), dt(dst.dtype), act
+    d.src_ld, d.src_coff, d.dst_ld, d.dst_coff = d.Cs, 0, dst.ld, dst.coff
+    d.res_ld, d.res_coff = (res.ld, res.coff) if res is not None else (0, 0)
+    return d
+
+
+def conv2d_tiled_cat(parts, w_tiled, dst: View, scale=None, bias=None, act=L.ACT_NONE, res: Optional[View] = None):
+    """1x1 convolution over a virtual Concat (+ nearest 2x Upsample) of up to three NHWC views (csrc/conv_halo.hip / conv_pair.hip, CAT forms)."""
+    lib = L.load()
+    arr, _ = cat_srcs(parts)
+    d = cat_desc(parts, dst, act, res)
+    L.check(lib.cdet_conv2d_tiled_cat(C.byref(d), arr, len(parts), ptr(w_tiled), ptr(scale), ptr(bias), ptr(res), ptr(dst), stream()), "cdet_conv2d_tiled_cat")
+    return dst
+
+
 def conv2d_s2_tiled_ok(src: View, dst: View, mode=L.CONV_FWD) -> bool:
     d = conv_desc(src, dst, 3, 2, mode)
     return bool(L.load().cdet_conv2d_s2_tiled_ok(C.byref(d)))

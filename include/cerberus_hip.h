@@ -119,6 +119,20 @@ int cdet_conv2d_tiled_ok(const cdet_conv_desc* d);
 int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d);
 int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                       const void* residual, void* y, float* stats, void* stream);
+/* Round 4 -- the same 1x1 convolution over a VIRTUAL Concat (+ nearest 2x Upsample): models/common.py:288-295 (Concat) and nn.Upsample in front of
+ * every neck C2f's cv1 (models/yolo.py:172-203 walks them as separate modules and materialises both). Here the K loop visits up to three channel
+ * segments, each a slice of its own NHWC buffer (`upsample`: read through (y / 2, x / 2) of an H/2 x W/2 map): neither the upsampled map nor the
+ * concatenated tensor is written. d describes the convolution (Cs = total channels; its src_ld / src_coff are ignored); all but the last segment hold
+ * a multiple of 32 channels; w_tiled = the ordinary forward operand over the concatenated channels. Same arithmetic and summation order as
+ * cdet_conv2d_tiled on the materialised tensor. */
+typedef struct {
+    const void* x;             /* NHWC buffer of the segment (N x H x W, or N x H/2 x W/2 when upsample != 0) */
+    int32_t ld, coff, C;       /* row pitch, first channel, channels                                           */
+    int32_t upsample;
+} cdet_cat_src;
+int cdet_conv2d_tiled_cat_ok(const cdet_conv_desc* d, const cdet_cat_src* srcs, int32_t n_src);
+int cdet_conv2d_tiled_cat(const cdet_conv_desc* d, const cdet_cat_src* srcs, int32_t n_src, const void* w_tiled, const float* scale, const float* bias,
+                          const void* residual, void* y, void* stream);
 /* Tiled operand: [ceil(rows/RB)][ceil(red/32)][kh*kw][RB][32] elements of the activation dtype, RB = 160 (96 when
  * rows <= 96), 16-byte slots XOR-swizzled (the LDS image of one (row block, chunk, tap) tile is a linear copy).
  * rows = O, red = I for the forward operand; rows = I, red = O, taps flipped, for the DGRAD operand. Rows beyond `rows`

@@ -280,3 +280,49 @@ def test_stride2_tiled_dgrad_fp32_destination_accumulates(case):
     ops.conv2d_s2_tiled_dgrad(dyv, wd, dx, accumulate=True)
     torch.cuda.synchronize()
     assert float((dx.nchw().double().cpu() - 2 * ref).abs().max()) <= 1e-5 * 2 * float(ref.abs().max())
+
+
+CAT_CASES = [
+    # N, H, W, parts [(C, upsampled)], Cout, dtype, pair kernel
+    (2, 16, 16, [(64, True), (96, False)], 160, torch.bfloat16, False),               # neck top-down: [Upsample(x), backbone tap]
+    (1, 20, 24, [(32, False), (64, False), (40, False)], 80, torch.float16, False),    # three parts, last one not a multiple of 32; 96-cout tile
+    (3, 8, 8, [(128, True), (64, False)], 320, torch.bfloat16, False),                 # half tiles (few pixels), two cout blocks
+    (2, 16, 16, [(640, True), (640, False)], 320, torch.bfloat16, True),               # conv_pair.hip CAT form (YOLOv8x 40 x 40 neck shape)
+    (1, 16, 16, [(320, False), (640, False)], 640, torch.float16, True),               # bottom-up: [Conv s2 output, top-down tap], pair form
+]
+
+
+@pytest.mark.parametrize("case", CAT_CASES)
+def test_conv_over_virtual_concat_equals_the_materialised_one(case, monkeypatch):
+    """cdet_conv2d_tiled_cat: the 1x1 convolution behind a Concat (+ Upsample) reading its inputs from their own buffers (slices of wider
+    buffers, NaN around them) must give the SAME BITS as cdet_conv2d_tiled on the materialised tensor -- same K order, same kernel body."""
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    N, H, W, parts, Co, dtype, pair = case
+    monkeypatch.setenv("CDET_CONV_PAIR", "2" if pair else "0")
+    g = torch.Generator().manual_seed(71)
+    views, mats = [], []
+    for Cp, up in parts:
+        h, w_ = (H // 2, W // 2) if up else (H, W)
+        buf = torch.full((N, h, w_, Cp + 24), float("nan"), dtype=dtype, device=DEV)
+        t = _rt(torch.randn(N, h, w_, Cp, generator=g), dtype)
+        buf[..., 8:8 + Cp] = t.to(dtype).to(DEV)
+        views.append((ops.View(buf, 8, Cp), up))
+        mats.append(t.repeat_interleave(2, 1).repeat_interleave(2, 2) if up else t)
+    x = torch.cat(mats, 3)
+    Ci = x.shape[3]
+    w = _rt(torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci), dtype)
+    scale, bias = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    wf, _ = ops.pack_weight_tiled(w.to(DEV), dtype)
+    src = ops.View(x.to(dtype).to(DEV).contiguous())
+    want = ops.new_act(N, H, W, Co, dtype)
+    ops.conv2d_tiled(src, wf, want, 1, scale=scale.to(DEV), bias=bias.to(DEV), act=L.ACT_SILU)
+    yb = torch.full((N, H, W, Co + 16), 7.0, dtype=dtype, device=DEV)
+    got = ops.View(yb, 8, Co)
+    ops.conv2d_tiled_cat(views, wf, got, scale=scale.to(DEV), bias=bias.to(DEV), act=L.ACT_SILU)
+    torch.cuda.synchronize()
+    assert torch.equal(got.torch(), want.torch()), f"{int((got.torch() != want.torch()).sum())} of {want.torch().numel()} outputs differ"
+    assert (yb[..., :8].float() == 7.0).all() and (yb[..., 8 + Co:].float() == 7.0).all()
+    ref = F.silu(F.conv2d(x.permute(0, 3, 1, 2), w) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    _close(got.nchw(), ref, 2 ** -7, 2e-2)

@@ -78,6 +78,29 @@ def test_eval_plan_fuses_the_first_two_backbone_rows(monkeypatch):
     assert "cdet_stem_conv1" not in names(train)
 
 
+def test_eval_plan_keeps_concat_and_upsample_virtual(monkeypatch):
+    """Eval plans never build the neck's Concat / Upsample tensors: the C2f cv1 behind each Concat reads its inputs itself
+    (cdet_conv2d_tiled_cat). CDET_VCAT=0 is the round-3 form with upsample / copy launches."""
+    from cerberusdet_amd.engine import Plan
+
+    tasks = ["voc", "objects365_animals"]
+    m = _model("v8x_2task.yaml", tasks)
+    dev = torch.device("cpu")
+
+    def names(plan):
+        return [getattr(fn, "__name__", "") for fn, _ in plan.fwd]
+
+    v = names(Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev))
+    assert v.count("cdet_conv2d_tiled_cat") == 8 and "cdet_upsample2" not in v and "cdet_copy_channels" not in v  # 4 neck Concats per task
+    monkeypatch.setenv("CDET_VCAT", "0")
+    r3 = names(Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev))
+    assert "cdet_conv2d_tiled_cat" not in r3 and r3.count("cdet_upsample2") == 4 and r3.count("cdet_copy_channels") >= 2
+    assert len(r3) == len(v) + r3.count("cdet_upsample2") + r3.count("cdet_copy_channels")
+    monkeypatch.delenv("CDET_VCAT")
+    tr = names(Plan(m, [tasks[0]], 2, 64, 64, True, torch.bfloat16, torch.uint8, dev))
+    assert "cdet_conv2d_tiled_cat" not in tr
+
+
 def test_frozen_trunk_plan_compiles_without_backward_for_shared_blocks():
     from cerberusdet_amd.engine import Plan
     from cerberusdet_amd.models import CerberusDet
