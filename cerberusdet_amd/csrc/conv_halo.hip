@@ -162,10 +162,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             const int g = p0 + hrow;
             const bool ok = g < a.M;
             const unsigned slot = (unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4;
-            xvoff[i] = ok ? cat_pixel_off(a.cat, 0, g) + slot : HSENT;
-            xv1[i] = (ok && a.cat.n > 1) ? cat_pixel_off(a.cat, 1, g) + slot : HSENT;
-            xv2[i] = (ok && a.cat.n > 2) ? cat_pixel_off(a.cat, 2, g) + slot : HSENT;
+            xvoff[i] = ok ? cat_pixel_off(a.cat.up0, a.cat.ld0, a.cat.co0, a.cat.H, a.cat.W, g) + slot : HSENT;
+            xv1[i] = (ok && a.cat.n > 1) ? cat_pixel_off(a.cat.up1, a.cat.ld1, a.cat.co1, a.cat.H, a.cat.W, g) + slot : HSENT;
+            xv2[i] = (ok && a.cat.n > 2) ? cat_pixel_off(a.cat.up2, a.cat.ld2, a.cat.co2, a.cat.H, a.cat.W, g) + slot : HSENT;
         }
+    }
+    // CAT: the segment table as uniform VGPR values (see dma_x). Scalars, not arrays: a select over array elements became a
+    // dynamically indexed private-memory array (scratch loads inside the K loop)
+    unsigned cl0 = 0u, cl1 = 0u, cl2 = 0u, ch0 = 0u, ch1 = 0u, ch2 = 0u;
+    int cat_c1 = 0x7fffffff, cat_c2 = 0x7fffffff;
+    if (CAT) {
+        cl0 = (unsigned)(uint64_t)a.cat.x0; ch0 = (unsigned)((uint64_t)a.cat.x0 >> 32);
+        cl1 = (unsigned)(uint64_t)a.cat.x1; ch1 = (unsigned)((uint64_t)a.cat.x1 >> 32);
+        cl2 = (unsigned)(uint64_t)a.cat.x2; ch2 = (unsigned)((uint64_t)a.cat.x2 >> 32);
+        asm volatile("" : "+v"(cl0), "+v"(cl1), "+v"(cl2), "+v"(ch0), "+v"(ch1), "+v"(ch2));
+        cat_c1 = a.cat.c1;
+        cat_c2 = a.cat.c2;
     }
     const bool partial = (a.Cs & 31) != 0;                   // wave-uniform
     const int xls = (lane & 3) ^ ((lane >> 4) & 3);          // logical 16-byte slot this lane fetches (the same for every piece)
@@ -182,15 +194,28 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         if (j < NWP - 1) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);
         else if (j == NWP - 1 && lane < 32) dma16(rs, wvoff + (unsigned)j * 1024u, soff, dst);  // the 512-byte tail of the wave's share
     };
-    auto dma_x = [&](int i, int chunk, int xb) {  // piece i of this wave, channels of `chunk` -> pixel buffer xb
+    // (the segment table is captured BY VALUE: through by-reference captures the selects below became selects of addresses inside a
+    //  closure object kept in private memory)
+    auto dma_x = [&, xvoff, xv1, xv2, cl0, cl1, cl2, ch0, ch1, ch2, cat_c1, cat_c2](int i, int chunk, int xb) {  // piece i of this wave, channels of `chunk` -> pixel buffer xb
         unsigned char* dst = xbase + xb * XHB + (4 * i + wave) * 1024;
-        if constexpr (CAT) {  // the chunk's segment (wave-uniform): its buffer, its pixel offsets, the chunk's position inside it
-            const int sg = chunk >= a.cat.c0[2] ? 2 : (chunk >= a.cat.c0[1] ? 1 : 0);
-            const uint16_t* xp = sg == 2 ? a.cat.x[2] : (sg == 1 ? a.cat.x[1] : a.cat.x[0]);
-            const unsigned xb_ = sg == 2 ? a.cat.bytes[2] : (sg == 1 ? a.cat.bytes[1] : a.cat.bytes[0]);
-            const int cf = sg == 2 ? a.cat.c0[2] : (sg == 1 ? a.cat.c0[1] : 0);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, chunk < a.nchunk ? (int)xb_ : 0, 0x00020000);
-            unsigned v = sg == 2 ? xv2[i < NXC ? i : 0] : (sg == 1 ? xv1[i < NXC ? i : 0] : xvoff[i]);
+        if constexpr (CAT) {  // the chunk's segment (wave-uniform): its buffer, its pixel offsets, the chunk's position inside it.
+            // The segment table lives in VGPRs (uniform values, selected by v_cndmask and read back with v_readfirstlane): as scalars the
+            // three pointers / extents / boundaries stayed live through the whole K loop, the kernel ran out of SGPRs, and the spill
+            // code's scratch loads drained the DMA queue every step (3x slower than the plain form)
+            const bool sg2 = chunk >= cat_c2, sg1 = chunk >= cat_c1;
+            // every candidate is read into a register and made opaque BEFORE the select: a select of loads from the (by-value) closure is
+            // rewritten by the optimiser into one load at a selected address, the closure then stays in private memory, and with it the
+            // kernel arguments it refers to -- their scratch loads share the DMA's counter (the first CAT build ran 3x slower)
+            unsigned l0 = cl0, l1 = cl1, l2 = cl2, h0 = ch0, h1 = ch1, h2 = ch2;
+            unsigned t0 = xvoff[i], t1 = xv1[i < NXC ? i : 0], t2 = xv2[i < NXC ? i : 0];
+            asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(t0), "+v"(t1), "+v"(t2));
+            const unsigned plo = sg2 ? l2 : (sg1 ? l1 : l0);
+            const unsigned phi = sg2 ? h2 : (sg1 ? h1 : h0);
+            // (readfirstlane returns int: without the unsigned cast a low word with its top bit set sign-extends into the high word)
+            const uint64_t pa = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(plo) | ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(phi) << 32);
+            const int cf = sg2 ? cat_c2 : (sg1 ? cat_c1 : 0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, chunk < a.nchunk ? (int)0xC0000000u : 0, 0x00020000);  // (every real offset lies inside its buffer -- host check; the extent only has to exclude the HSENT sentinel)
+            unsigned v = sg2 ? t2 : (sg1 ? t1 : t0);
             if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
             dma16<CDET_HALO_X_AUX>(rs, v, (unsigned)(chunk - cf) * 64u, dst);
             return;
@@ -831,10 +856,9 @@ static int cat_fill(const cdet_conv_desc* d, const cdet_cat_src* srcs, int n, Ca
     if (!srcs || n < 1 || n > 3) return 0;
     if (!(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->Hs == d->Hd && d->Ws == d->Wd)) return 0;
     int ctot = 0;
-    for (int i = 0; i < 3; ++i) {
-        c->x[i] = nullptr; c->bytes[i] = 0; c->ld[i] = 0; c->coff[i] = 0; c->up[i] = 0;
-        c->c0[i] = 0x7fffffff;
-    }
+    const uint16_t* xs[3] = {nullptr, nullptr, nullptr};
+    unsigned by[3] = {0u, 0u, 0u};
+    int ld[3] = {0, 0, 0}, co[3] = {0, 0, 0}, up[3] = {0, 0, 0}, c0[3] = {0, 0x7fffffff, 0x7fffffff};
     for (int i = 0; i < n; ++i) {
         const cdet_cat_src& sc = srcs[i];
         if (!sc.x || sc.C <= 0 || sc.C % 8 != 0 || sc.ld % 8 != 0 || sc.coff % 8 != 0 || sc.coff + sc.C > sc.ld) return 0;
@@ -843,10 +867,16 @@ static int cat_fill(const cdet_conv_desc* d, const cdet_cat_src* srcs, int n, Ca
         const int64_t px = sc.upsample ? (int64_t)d->N * (d->Hs / 2) * (d->Ws / 2) : (int64_t)d->N * d->Hs * d->Ws;
         const int64_t bytes = px * sc.ld * 2;
         if (bytes >= 0xC0000000ll) return 0;
-        c->x[i] = (const uint16_t*)sc.x; c->bytes[i] = (unsigned)bytes; c->ld[i] = sc.ld; c->coff[i] = sc.coff; c->up[i] = sc.upsample ? 1 : 0;
-        c->c0[i] = ctot / 32;
+        xs[i] = (const uint16_t*)sc.x; by[i] = (unsigned)bytes; ld[i] = sc.ld; co[i] = sc.coff; up[i] = sc.upsample ? 1 : 0;
+        c0[i] = ctot / 32;
         ctot += sc.C;
     }
+    c->x0 = xs[0]; c->x1 = xs[1]; c->x2 = xs[2];
+    c->b0 = by[0]; c->b1 = by[1]; c->b2 = by[2];
+    c->ld0 = ld[0]; c->ld1 = ld[1]; c->ld2 = ld[2];
+    c->co0 = co[0]; c->co1 = co[1]; c->co2 = co[2];
+    c->up0 = up[0]; c->up1 = up[1]; c->up2 = up[2];
+    c->c1 = c0[1]; c->c2 = c0[2];
     if (ctot != d->Cs) return 0;
     c->n = n; c->H = d->Hs; c->W = d->Ws;
     return 1;

@@ -82,23 +82,48 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
             const int g = p0 + hrow;
             const bool ok = g < a.M;
             const unsigned slot = (unsigned)((lane & 3) ^ ((hrow >> 2) & 3)) << 4;
-            xvoff[i] = ok ? cat_pixel_off(a.cat, 0, g) + slot : HSENT;
-            xv1[i] = (ok && a.cat.n > 1) ? cat_pixel_off(a.cat, 1, g) + slot : HSENT;
-            xv2[i] = (ok && a.cat.n > 2) ? cat_pixel_off(a.cat, 2, g) + slot : HSENT;
+            xvoff[i] = ok ? cat_pixel_off(a.cat.up0, a.cat.ld0, a.cat.co0, a.cat.H, a.cat.W, g) + slot : HSENT;
+            xv1[i] = (ok && a.cat.n > 1) ? cat_pixel_off(a.cat.up1, a.cat.ld1, a.cat.co1, a.cat.H, a.cat.W, g) + slot : HSENT;
+            xv2[i] = (ok && a.cat.n > 2) ? cat_pixel_off(a.cat.up2, a.cat.ld2, a.cat.co2, a.cat.H, a.cat.W, g) + slot : HSENT;
         }
+    }
+    // CAT: the segment table as uniform VGPR values (see dma_x). Scalars, not arrays: a select over array elements became a
+    // dynamically indexed private-memory array (scratch loads inside the K loop)
+    unsigned cl0 = 0u, cl1 = 0u, cl2 = 0u, ch0 = 0u, ch1 = 0u, ch2 = 0u;
+    int cat_c1 = 0x7fffffff, cat_c2 = 0x7fffffff;
+    if (CAT) {
+        cl0 = (unsigned)(uint64_t)a.cat.x0; ch0 = (unsigned)((uint64_t)a.cat.x0 >> 32);
+        cl1 = (unsigned)(uint64_t)a.cat.x1; ch1 = (unsigned)((uint64_t)a.cat.x1 >> 32);
+        cl2 = (unsigned)(uint64_t)a.cat.x2; ch2 = (unsigned)((uint64_t)a.cat.x2 >> 32);
+        asm volatile("" : "+v"(cl0), "+v"(cl1), "+v"(cl2), "+v"(ch0), "+v"(ch1), "+v"(ch2));
+        cat_c1 = a.cat.c1;
+        cat_c2 = a.cat.c2;
     }
     const bool partial = (a.Cs & 31) != 0;
     const int xls = (lane & 3) ^ ((lane >> 4) & 3);
 
-    auto dma_x = [&](int i, int chunk, int xb) {
+    // (the segment table is captured BY VALUE: through by-reference captures the selects below became selects of addresses inside a
+    //  closure object kept in private memory)
+    auto dma_x = [&, xvoff, xv1, xv2, cl0, cl1, cl2, ch0, ch1, ch2, cat_c1, cat_c2](int i, int chunk, int xb) {
         unsigned char* dst = xbase + xb * PR_XB + (8 * i + wave) * 1024;
-        if constexpr (CAT) {  // the chunk's segment (wave-uniform): its buffer, its pixel offsets, the chunk's position inside it
-            const int sg = chunk >= a.cat.c0[2] ? 2 : (chunk >= a.cat.c0[1] ? 1 : 0);
-            const uint16_t* xp = sg == 2 ? a.cat.x[2] : (sg == 1 ? a.cat.x[1] : a.cat.x[0]);
-            const unsigned xb_ = sg == 2 ? a.cat.bytes[2] : (sg == 1 ? a.cat.bytes[1] : a.cat.bytes[0]);
-            const int cf = sg == 2 ? a.cat.c0[2] : (sg == 1 ? a.cat.c0[1] : 0);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, chunk < a.nchunk ? (int)xb_ : 0, 0x00020000);
-            unsigned v = sg == 2 ? xv2[i] : (sg == 1 ? xv1[i] : xvoff[i]);
+        if constexpr (CAT) {  // the chunk's segment (wave-uniform): its buffer, its pixel offsets, the chunk's position inside it.
+            // The segment table lives in VGPRs (uniform values, selected by v_cndmask and read back with v_readfirstlane): as scalars the
+            // three pointers / extents / boundaries stayed live through the whole K loop, the kernel ran out of SGPRs, and the spill
+            // code's scratch loads drained the DMA queue every step (3x slower than the plain form)
+            const bool sg2 = chunk >= cat_c2, sg1 = chunk >= cat_c1;
+            // every candidate is read into a register and made opaque BEFORE the select: a select of loads from the (by-value) closure is
+            // rewritten by the optimiser into one load at a selected address, the closure then stays in private memory, and with it the
+            // kernel arguments it refers to -- their scratch loads share the DMA's counter (the first CAT build ran 3x slower)
+            unsigned l0 = cl0, l1 = cl1, l2 = cl2, h0 = ch0, h1 = ch1, h2 = ch2;
+            unsigned t0 = xvoff[i], t1 = xv1[i], t2 = xv2[i];
+            asm volatile("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(t0), "+v"(t1), "+v"(t2));
+            const unsigned plo = sg2 ? l2 : (sg1 ? l1 : l0);
+            const unsigned phi = sg2 ? h2 : (sg1 ? h1 : h0);
+            // (readfirstlane returns int: without the unsigned cast a low word with its top bit set sign-extends into the high word)
+            const uint64_t pa = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(plo) | ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(phi) << 32);
+            const int cf = sg2 ? cat_c2 : (sg1 ? cat_c1 : 0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pa, 0, chunk < a.nchunk ? (int)0xC0000000u : 0, 0x00020000);  // (every real offset lies inside its buffer -- host check; the extent only has to exclude the HSENT sentinel)
+            unsigned v = sg2 ? t2 : (sg1 ? t1 : t0);
             if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
             dma16<CDET_HALO_X_AUX>(rs, v, (unsigned)(chunk - cf) * 64u, dst);
             return;

@@ -20,23 +20,25 @@ constexpr int HEPI_RAW = 0, HEPI_FULL = 1, HEPI_F32 = 2;  // epilogue: raw 16-bi
 // channel segments, each a slice of its own NHWC buffer, visited in order by the K loop; segment s covers K chunks [c0[s], c0[s + 1]). `up`: the
 // segment is read through a nearest-neighbour 2x upsample (source pixel (y / 2, x / 2) of an H/2 x W/2 map) -- neither the upsampled map nor the
 // concatenated buffer is ever written. All but the last segment hold a multiple of 32 channels.
-struct CatSrcs {
-    const uint16_t* x[3];
-    unsigned bytes[3];
-    int ld[3], coff[3], c0[3], up[3];
-    int n, H, W;  // pixel geometry of the convolution (for the upsampled segments)
+struct CatSrcs {  // (scalar fields on purpose: arrays inside a by-value kernel argument made hipcc keep a private-memory copy of the whole argument)
+    const uint16_t *x0, *x1, *x2;
+    unsigned b0, b1, b2;        // buffer extents (bytes)
+    int ld0, ld1, ld2, co0, co1, co2, up0, up1, up2;
+    int c1, c2;                 // first K chunk of segments 1 and 2 (0x7fffffff: absent)
+    int n, H, W;                // segments; pixel geometry of the convolution (for the upsampled segments)
 };
 
-// byte offset (before the chunk offset and the 16-byte slot) of pixel g of the N x H x W pixel space inside segment s
-__device__ __forceinline__ unsigned cat_pixel_off(const CatSrcs& c, int s, int g) {
+// byte offset (before the chunk offset and the 16-byte slot) of pixel g of the N x H x W pixel space inside a segment (scalars, not the struct:
+// a reference to the by-value kernel argument makes the compiler keep a private-memory copy of it, and its loads share the DMA's counter)
+__device__ __forceinline__ unsigned cat_pixel_off(int up, int ld, int coff, int H, int W, int g) {
     int gs = g;
-    if (c.up[s]) {
-        const int hw = c.H * c.W;
+    if (up) {
+        const int hw = H * W;
         const int n = g / hw, r = g - n * hw;
-        const int y = r / c.W, x = r - y * c.W;
-        gs = (n * (c.H >> 1) + (y >> 1)) * (c.W >> 1) + (x >> 1);
+        const int y = r / W, x = r - y * W;
+        gs = (n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
     }
-    return ((unsigned)gs * (unsigned)c.ld[s] + (unsigned)c.coff[s]) * 2u;
+    return ((unsigned)gs * (unsigned)ld + (unsigned)coff) * 2u;
 }
 
 template <int DT>
