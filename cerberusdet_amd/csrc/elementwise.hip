@@ -6,6 +6,8 @@
 
 #include "common.h"
 
+#include <type_traits>
+
 namespace cdet {
 
 struct Vec8 {
@@ -370,6 +372,236 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const uint16_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: lean forms of the three BatchNorm + SiLU tensor passes. The kernels above run at the same time per ELEMENT whether they move
+// 4 or 6 bytes per element (profiles/r03_pmc_traffic.json: reduce 4.0, forward 4.8, apply 5.2 TB/s) -- they are bound by their VALU
+// stream (13 - 15 instruction slots per element: 64-bit address arithmetic per row and tensor, three-op normalisation, unpaired fp32
+// ops around the two transcendentals), not by HBM. Here:
+//   * tensors are addressed through buffer descriptors: one 32-bit byte offset per tensor and thread, advanced by ONE add per row, and
+//     rows beyond M read zeros / drop their stores (no tail loop);
+//   * all arithmetic on pairs (v_pk_fma / v_pk_mul / v_pk_add_f32), the per-channel affine maps folded on the host side of the loop:
+//     a = x k1 + k0 (one fma instead of sub, mul, fma); the backward sums as S1 = sum da and S2' = sum da x (xhat never formed in the
+//     loop: sum da xhat = invstd (S2' - mean S1)); dz = da K + x A + B;
+//   => 3.5 / 6.5 / 7 paired-instruction slots per element + the two transcendentals.
+// Used when every tensor of the call is below 2 GiB (32-bit offsets with room for the row-ahead unroll); CDET_BN_V2=0 (profiling
+// builds) selects the kernels above for A/B timing.
+// ------------------------------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+template <int DT>
+__device__ __forceinline__ f2v unpack2(uint32_t w) {
+    if (DT == CDET_BF16) return f2v{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    const f16x2_e h = __builtin_bit_cast(f16x2_e, w);
+    return f2v{(float)h[0], (float)h[1]};
+}
+__device__ __forceinline__ f2v sigmoid_from(f2v a) {  // 1 / (1 + exp(-a)), the same instruction sequence as the scalar form above
+    const f2v t = a * -1.4426950408889634f;
+    const f2v e = f2v{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const f2v d = e + 1.0f;
+    return f2v{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bn_rsrc(const void* p, int64_t M, int ld) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)(M * ld * 2), 0x00020000);
+}
+struct Pair4 {
+    f2v v[4];
+};
+__device__ __forceinline__ Pair4 loadf8p(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    Pair4 o;
+    o.v[0] = f2v{a[0], a[1]}; o.v[1] = f2v{a[2], a[3]}; o.v[2] = f2v{b[0], b[1]}; o.v[3] = f2v{b[2], b[3]};
+    return o;
+}
+
+constexpr int BN2_U = 4;  // rows in flight per thread
+
+template <int DT>
+__global__ __launch_bounds__(256) void bn_silu_fwd2_kernel(const uint16_t* __restrict__ z, int z_ld, int z_coff,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const uint16_t* __restrict__ res, int res_ld, int res_coff,
+                                                           uint16_t* __restrict__ y, int y_ld, int y_coff, int64_t M, int CV, int rev) {
+    const ColMap cm = col_map(CV);
+    if (!cm.active) return;
+    const int c = cm.cv * 8;
+    const Pair4 mu = loadf8p(mean + c), is = loadf8p(invstd + c), ga = loadf8p(gamma + c), be = loadf8p(beta + c);
+    f2v sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = ga.v[i] * is.v[i];
+        sh[i] = be.v[i] - mu.v[i] * sc[i];
+    }
+    const __amdgpu_buffer_rsrc_t rz = bn_rsrc(z, M, z_ld), rr = bn_rsrc(res ? res : z, res ? M : 0, res_ld), ry = bn_rsrc(y, M, y_ld);
+    const int step = (int)gridDim.x * cm.rows_per_pass;
+    const int r0 = (int)blockIdx.x * cm.rows_per_pass + cm.rl;
+    const int row = rev ? (int)M - 1 - r0 : r0, dir = rev ? -1 : 1;
+    unsigned oz = (unsigned)((row * z_ld + z_coff + c) * 2), orr = (unsigned)((row * res_ld + res_coff + c) * 2), oy = (unsigned)((row * y_ld + y_coff + c) * 2);
+    const unsigned iz = (unsigned)(dir * step * z_ld * 2), ir = (unsigned)(dir * step * res_ld * 2), iy = (unsigned)(dir * step * y_ld * 2);
+    auto rows = [&](auto UC) __attribute__((always_inline)) {  // UC rows in flight, all inside [0, M)
+        constexpr int U = decltype(UC)::value;
+        u4v zr[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zr[u] = __builtin_amdgcn_raw_buffer_load_b128(rz, (int)(oz + u * iz), 0, 0);
+            if (res) rv[u] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(orr + u * ir), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u4v o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f2v a = unpack2<DT>(zr[u][i]) * sc[i] + sh[i];
+                f2v v = a * sigmoid_from(a);
+                if (res) v += unpack2<DT>(rv[u][i]);
+                o[i] = pack2e<DT>(v.x, v.y);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry, (int)(oy + u * iy), 0, 0);
+        }
+        oz += U * iz; orr += U * ir; oy += U * iy;
+    };
+    int r = r0;
+    for (; r + (BN2_U - 1) * step < M; r += BN2_U * step) rows(std::integral_constant<int, BN2_U>{});
+    for (; r < M; r += step) rows(std::integral_constant<int, 1>{});
+}
+
+// da = dy * silu'(a), a = x k1 + k0; silu'(a) = s (1 + a (1 - s))
+__device__ __forceinline__ f2v dact_of(f2v g, f2v x, f2v k1, f2v k0) {
+    const f2v a = x * k1 + k0;
+    const f2v s = sigmoid_from(a);
+    const f2v w = a * (1.0f - s) + 1.0f;
+    return g * (s * w);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void bn_silu_bwd_reduce2_kernel(const uint16_t* __restrict__ dy, int dy_ld, int dy_coff,
+                                                                  const uint16_t* __restrict__ z, int z_ld, int z_coff,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* __restrict__ part, int64_t M, int C, int CV) {
+    extern __shared__ float shm[];  // [rows_per_pass][2][C]
+    const ColMap cm = col_map(CV);
+    const int c = cm.cv * 8;
+    if (cm.active) {
+        const Pair4 mu = loadf8p(mean + c), is = loadf8p(invstd + c), ga = loadf8p(gamma + c), be = loadf8p(beta + c);
+        f2v k1[4], k0[4], s1[4], s2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            k1[i] = ga.v[i] * is.v[i];
+            k0[i] = be.v[i] - mu.v[i] * k1[i];
+            s1[i] = s2[i] = f2v{0.f, 0.f};
+        }
+        const __amdgpu_buffer_rsrc_t rg = bn_rsrc(dy, M, dy_ld), rz = bn_rsrc(z, M, z_ld);
+        const int step = (int)gridDim.x * cm.rows_per_pass;
+        const int r0 = (int)blockIdx.x * cm.rows_per_pass + cm.rl;
+        unsigned og = (unsigned)((r0 * dy_ld + dy_coff + c) * 2), oz = (unsigned)((r0 * z_ld + z_coff + c) * 2);
+        const unsigned ig = (unsigned)(step * dy_ld * 2), iz = (unsigned)(step * z_ld * 2);
+        auto rows = [&](auto UC) __attribute__((always_inline)) {
+            constexpr int U = decltype(UC)::value;
+            u4v gr[U], zr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                gr[u] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(og + u * ig), 0, 0);
+                zr[u] = __builtin_amdgcn_raw_buffer_load_b128(rz, (int)(oz + u * iz), 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f2v x = unpack2<DT>(zr[u][i]);
+                    const f2v da = dact_of(unpack2<DT>(gr[u][i]), x, k1[i], k0[i]);
+                    s1[i] += da;
+                    s2[i] = da * x + s2[i];
+                }
+            og += U * ig; oz += U * iz;
+        };
+        int r = r0;
+        for (; r + (BN2_U - 1) * step < M; r += BN2_U * step) rows(std::integral_constant<int, BN2_U>{});
+        for (; r < M; r += step) rows(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // sum da xhat = invstd (sum da x - mean sum da)
+            const f2v q = is.v[i] * (s2[i] - mu.v[i] * s1[i]);
+            shm[(cm.rl * 2 + 0) * C + c + 2 * i] = s1[i].x;
+            shm[(cm.rl * 2 + 0) * C + c + 2 * i + 1] = s1[i].y;
+            shm[(cm.rl * 2 + 1) * C + c + 2 * i] = q.x;
+            shm[(cm.rl * 2 + 1) * C + c + 2 * i + 1] = q.y;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < cm.rows_per_pass; ++r) acc += shm[r * 2 * C + j];
+        part[(int64_t)blockIdx.x * 2 * C + j] = acc;
+    }
+}
+
+template <int DT, bool ALSO>
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply2_kernel(const uint16_t* __restrict__ dy, int dy_ld, int dy_coff,
+                                                                 const uint16_t* __restrict__ z, int z_ld, int z_coff,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ sums, float inv_count,
+                                                                 uint16_t* __restrict__ dz, int dz_ld, int dz_coff, int64_t M, int C, int CV, int rev,
+                                                                 uint16_t* __restrict__ also, int also_ld, int also_coff) {
+    const ColMap cm = col_map(CV);
+    if (!cm.active) return;
+    const int c = cm.cv * 8;
+    const Pair4 mu = loadf8p(mean + c), is = loadf8p(invstd + c), ga = loadf8p(gamma + c), be = loadf8p(beta + c);
+    const Pair4 m1 = loadf8p(sums + c), m2 = loadf8p(sums + C + c);
+    // dz = gamma invstd (da - m1 - xhat m2), xhat = (x - mean) invstd   ->   dz = da K + x A + B
+    f2v k1[4], k0[4], K[4], A[4], B[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k1[i] = ga.v[i] * is.v[i];
+        k0[i] = be.v[i] - mu.v[i] * k1[i];
+        K[i] = k1[i];
+        const f2v km2 = k1[i] * (m2.v[i] * inv_count) * is.v[i];
+        A[i] = -km2;
+        B[i] = km2 * mu.v[i] - k1[i] * (m1.v[i] * inv_count);
+    }
+    const __amdgpu_buffer_rsrc_t rg = bn_rsrc(dy, M, dy_ld), rz = bn_rsrc(z, M, z_ld), ro = bn_rsrc(dz, M, dz_ld),
+                                 ra = bn_rsrc(ALSO ? also : dz, ALSO ? M : 0, also_ld);
+    const int step = (int)gridDim.x * cm.rows_per_pass;
+    const int r0 = (int)blockIdx.x * cm.rows_per_pass + cm.rl;
+    const int row = rev ? (int)M - 1 - r0 : r0, dir = rev ? -1 : 1;
+    unsigned og = (unsigned)((row * dy_ld + dy_coff + c) * 2), oz = (unsigned)((row * z_ld + z_coff + c) * 2),
+             oo = (unsigned)((row * dz_ld + dz_coff + c) * 2), oa = (unsigned)((row * also_ld + also_coff + c) * 2);
+    const unsigned ig = (unsigned)(dir * step * dy_ld * 2), iz = (unsigned)(dir * step * z_ld * 2), io = (unsigned)(dir * step * dz_ld * 2),
+                   ia = (unsigned)(dir * step * also_ld * 2);
+    auto rows = [&](auto UC) __attribute__((always_inline)) {
+        constexpr int U = decltype(UC)::value;
+        u4v gr[U], zr[U], ar[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            gr[u] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(og + u * ig), 0, 0);
+            zr[u] = __builtin_amdgcn_raw_buffer_load_b128(rz, (int)(oz + u * iz), 0, 0);
+            if (ALSO) ar[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(oa + u * ia), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u4v o, s_;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f2v g = unpack2<DT>(gr[u][i]), x = unpack2<DT>(zr[u][i]);
+                const f2v da = dact_of(g, x, k1[i], k0[i]);
+                const f2v v = da * K[i] + (x * A[i] + B[i]);
+                o[i] = pack2e<DT>(v.x, v.y);
+                if (ALSO) {
+                    const f2v w = unpack2<DT>(ar[u][i]) + g;
+                    s_[i] = pack2e<DT>(w.x, w.y);
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(o, ro, (int)(oo + u * io), 0, 0);
+            if (ALSO) __builtin_amdgcn_raw_buffer_store_b128(s_, ra, (int)(oa + u * ia), 0, 0);
+        }
+        og += U * ig; oz += U * iz; oo += U * io; oa += U * ia;
+    };
+    int r = r0;
+    for (; r + (BN2_U - 1) * step < M; r += BN2_U * step) rows(std::integral_constant<int, BN2_U>{});
+    for (; r < M; r += step) rows(std::integral_constant<int, 1>{});
+}
+
+// ------------------------------------------------------------------------------------------------
 // channel-slice copy / add, upsample, SPPF pools
 // ------------------------------------------------------------------------------------------------
 template <int DT>
@@ -682,6 +914,14 @@ static int bn_rev() {
     return v;
 }
 
+static int bn_v2() {
+    static int v = -1;
+    if (v < 0) v = tune_env("CDET_BN_V2", 1);
+    return v;
+}
+// every tensor of the call below 2 GiB: the lean kernels address with 32-bit byte offsets
+static inline bool bn_small(int64_t M, int ld) { return M * (int64_t)ld * 2 < (1ll << 31) - 65536; }
+
 static inline int grid_for(int64_t work_items, int per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -722,6 +962,13 @@ extern "C" int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, con
     CDET_CHECK_ARG(C / 8 <= 256, "cdet_bn_silu_fwd: C too large");
     const int CV = C / 8, rpp = 256 / CV;
     const int grid = grid_for(M, rpp * 8);
+    if (bn_v2() && bn_small(M, z_ld) && bn_small(M, y_ld) && (!residual || bn_small(M, res_ld))) {
+        DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_fwd2_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)z, z_ld,
+                                             z_coff, mean, invstd, gamma, beta, (const uint16_t*)residual, res_ld, res_coff, (uint16_t*)y, y_ld,
+                                             y_coff, M, CV, bn_rev() & 1));
+        CDET_LAUNCH_CHECK();
+        return 0;
+    }
     DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_fwd_kernel<DT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)z, z_ld,
                                          z_coff, mean, invstd, gamma, beta, (const uint16_t*)residual, res_ld, res_coff, (uint16_t*)y, y_ld,
                                          y_coff, M, CV, bn_rev() & 1));
@@ -747,6 +994,13 @@ extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy
     const int CV = C / 8, rpp = 256 / CV;
     const size_t shm = (size_t)rpp * 2 * C * sizeof(float);
     CDET_CHECK_ARG(shm <= 64 * 1024, "cdet_bn_silu_bwd_reduce: LDS budget exceeded");
+    if (bn_v2() && bn_small(M, dy_ld) && bn_small(M, z_ld)) {
+        DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_reduce2_kernel<DT>), dim3(cdet_bn_bwd_blocks(M)), dim3(256), shm, (hipStream_t)stream,
+                                             (const uint16_t*)dy, dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, part,
+                                             M, C, CV));
+        CDET_LAUNCH_CHECK();
+        return 0;
+    }
     DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_reduce_kernel<DT>), dim3(cdet_bn_bwd_blocks(M)), dim3(256), shm, (hipStream_t)stream,
                                          (const uint16_t*)dy, dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, part,
                                          M, C, CV));
@@ -771,6 +1025,19 @@ static int bn_silu_bwd_apply_impl(const char* fn, const void* dy, int32_t dy_ld,
     const int64_t cnt = count > 0 ? count : M;
     const int CV = C / 8, rpp = 256 / CV;
     const int grid = grid_for(M, rpp * 8);
+    if (bn_v2() && bn_small(M, dy_ld) && bn_small(M, z_ld) && bn_small(M, dz_ld) && (!also || bn_small(M, also_ld))) {
+        if (also) {
+            DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply2_kernel<DT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy,
+                                                 dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
+                                                 (uint16_t*)dz, dz_ld, dz_coff, M, C, CV, (bn_rev() >> 1) & 1, (uint16_t*)also, also_ld, also_coff));
+        } else {
+            DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply2_kernel<DT, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy,
+                                                 dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
+                                                 (uint16_t*)dz, dz_ld, dz_coff, M, C, CV, (bn_rev() >> 1) & 1, (uint16_t*)nullptr, 0, 0));
+        }
+        CDET_LAUNCH_CHECK();
+        return 0;
+    }
     if (also) {
         DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<DT, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy,
                                              dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, sums, 1.0f / (float)cnt,
