@@ -1,0 +1,126 @@
+// SyncBatchNorm statistics exchange by peer writes (gfx950, one node): the small all-reduce between a BatchNorm layer's statistics kernel and its
+// normalisation kernel (reference train.py:140-143 turns every BatchNorm into SyncBatchNorm: 2 x 97 tiny collectives per task pass).
+//
+// As RCCL calls these are ~350 host-enqueued collectives per iteration, each a kernel launch + a ring/tree protocol for 0.3 - 15 KB, on the dependent
+// chain of every layer. Here every rank owns ONE exchange buffer that all its peers map through HIP IPC (hipIpcGetMemHandle / OpenMemHandle, exchanged
+// once at start-up). One single-workgroup kernel per exchange:
+//   1. writes the rank's vector into its row of the slot in EVERY rank's buffer (its own included) -- peer stores over xGMI --, fences at system
+//      scope and publishes a per-(slot, rank) flag = the exchange's epoch in every buffer;
+//   2. spins (bounded) until all `world` flags of the slot in its OWN buffer carry the epoch, then sums the `world` rows in rank order -- the same
+//      order on every rank, so all ranks hold bit-identical sums (RCCL's ring order is not specified; for two ranks a + b is the same either way).
+// Slots are double-buffered by epoch parity: a rank can only reach epoch e + 2 of a slot after every peer has finished reading epoch e (it needs their
+// e + 1 flags first). A spin that exceeds its budget raises an error word instead of hanging the GPU.
+#include "common.h"
+
+namespace cdet {
+
+constexpr unsigned long long PEER_SPIN_CLOCKS = 4000000000ull;  // ~2 s at 2 GHz: a missing peer is an error, not a hang
+
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(float* __restrict__ vec, int n, const uint64_t* __restrict__ peers, int world, int rank,
+                                                             long long data_off, long long flag_off, unsigned epoch, unsigned* __restrict__ err) {
+    const int t = threadIdx.x;
+    const int par = (int)(epoch & 1u);
+    const long long row = ((long long)par * world + rank) * n;
+    // 1. my vector into my row of the slot on every rank
+    for (int p = 0; p < world; ++p) {
+        float* dst = reinterpret_cast<float*>(peers[p]) + data_off + row;
+        for (int i = t; i < n; i += 256) __hip_atomic_store(dst + i, vec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t < world) {
+        unsigned* f = reinterpret_cast<unsigned*>(peers[t]) + flag_off + par * world + rank;
+        __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 2. all rows of the slot in MY buffer
+    if (t < world) {
+        const unsigned* f = reinterpret_cast<const unsigned*>(peers[rank]) + flag_off + par * world + t;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+            if (__builtin_readcyclecounter() - t0 > PEER_SPIN_CLOCKS) {
+                __hip_atomic_store(err, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    const float* src = reinterpret_cast<const float*>(peers[rank]) + data_off + (long long)par * world * n;
+    for (int i = t; i < n; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < world; ++r) s += __hip_atomic_load(src + (long long)r * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        vec[i] = s;
+    }
+}
+
+}  // namespace cdet
+
+using namespace cdet;
+
+extern "C" int cdet_peer_alloc(int64_t bytes, void** out) {
+    CDET_CHECK_ARG(out && bytes > 0, "cdet_peer_alloc: bad arguments");
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&p, (size_t)bytes);
+    }
+    if (e != hipSuccess) {
+        set_error("cdet_peer_alloc: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    e = hipMemset(p, 0, (size_t)bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        set_error("cdet_peer_alloc: memset: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int cdet_peer_free(void* p) {
+    if (p) (void)hipFree(p);
+    return 0;
+}
+
+extern "C" int cdet_peer_export(void* p, void* handle64) {
+    CDET_CHECK_ARG(p && handle64, "cdet_peer_export: null pointer");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
+    hipError_t e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle64), p);
+    if (e != hipSuccess) {
+        set_error("cdet_peer_export: hipIpcGetMemHandle: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+extern "C" int cdet_peer_import(const void* handle64, void** out) {
+    CDET_CHECK_ARG(handle64 && out, "cdet_peer_import: null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+        set_error("cdet_peer_import: hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int cdet_peer_close(void* p) {
+    if (p) (void)hipIpcCloseMemHandle(p);
+    return 0;
+}
+
+extern "C" int cdet_peer_allreduce(float* vec, int32_t n, const void* peer_table, int32_t world, int32_t rank, int64_t data_off, int64_t flag_off,
+                                   uint32_t epoch, void* err, void* stream) {
+    CDET_CHECK_ARG(vec && peer_table && err && n > 0, "cdet_peer_allreduce: bad arguments");
+    CDET_CHECK_ARG(world >= 1 && world <= 64 && rank >= 0 && rank < world && epoch != 0, "cdet_peer_allreduce: bad world / rank / epoch");
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vec, n, (const uint64_t*)peer_table, world, rank,
+                       (long long)data_off, (long long)flag_off, epoch, (unsigned*)err);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}

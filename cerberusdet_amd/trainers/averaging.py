@@ -106,6 +106,16 @@ class Averaging:
         self.task_streams = bool(task_streams) and torch.device(device).type == "cuda"
         self.rank, self.world_size = rank, world_size
         model.sync_bn = bool(sync_bn)  # SyncBatchNorm: per-layer statistics all-reduced over the ranks (reference train.py:140-143)
+        # round 4: those small all-reduces as peer-write kernels over HIP IPC (peer_exchange.py) when every rank can map every other
+        # rank's exchange buffer (one node); otherwise -- or with CDET_SYNCBN_PEER=0 -- the process group (RCCL) carries them
+        model._peer_xchg = None
+        if sync_bn and world_size > 1 and torch.device(device).type == "cuda":
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                from ..peer_exchange import try_setup
+
+                model._peer_xchg = try_setup(device, max(rank, 0), world_size)
         self.epochs, self.nb = epochs, nb
         self.nw = max(round(get_hyperparameter(hyp, "warmup_epochs") * nb), 1000)  # averaging.py:58
         self.lr0, self.lrf = get_hyperparameter(hyp, "lr0"), get_hyperparameter(hyp, "lrf")
@@ -344,6 +354,9 @@ class Averaging:
             if n:
                 self._gt_dropped.zero_()
                 raise RuntimeError(f"{n} label(s) exceeded n_max in train_step(): pass a larger n_max (or None to size it per batch)")
+        px = getattr(self.model, "_peer_xchg", None)
+        if px is not None:
+            px.check()  # a SyncBatchNorm exchange that timed out waiting for a peer
 
     # ---------------------------------------------------------------------------------------------------- resume
     def state_dict(self):

@@ -444,6 +444,25 @@ int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* o
 int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm,
                       const float* lrs, int32_t n_groups, float momentum, float ema_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * SyncBatchNorm statistics exchange by peer writes (csrc/peer_exchange.hip, round 4; reference train.py:140-143 converts every BatchNorm to
+ * SyncBatchNorm, i.e. one small all-reduce per layer and direction). One exchange buffer per rank, mapped by all peers of the node through HIP IPC:
+ *   cdet_peer_alloc / _free          device buffer for the exchange (uncached where the runtime offers it), zeroed
+ *   cdet_peer_export / _import       64-byte IPC handle of a buffer / map a peer's buffer (cdet_peer_close unmaps)
+ *   cdet_peer_allreduce              vec[0..n) <- sum over ranks, in rank order (bit-identical on every rank): one single-workgroup kernel that writes
+ *                                    the rank's row into every peer's slot, publishes an epoch flag, waits (bounded; *err != 0 on time-out) for all
+ *                                    ranks' flags in its own buffer and sums. peer_table: device array of `world` buffer addresses (own included);
+ *                                    the slot = 2 x world x n floats at data_off (floats) + 2 x world flags at flag_off (32-bit words); epoch > 0
+ *                                    grows by one per use of the slot.
+ * ---------------------------------------------------------------------------------------------- */
+int cdet_peer_alloc(int64_t bytes, void** out);
+int cdet_peer_free(void* p);
+int cdet_peer_export(void* p, void* handle64);
+int cdet_peer_import(const void* handle64, void** out);
+int cdet_peer_close(void* p);
+int cdet_peer_allreduce(float* vec, int32_t n, const void* peer_table, int32_t world, int32_t rank, int64_t data_off, int64_t flag_off, uint32_t epoch,
+                        void* err, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

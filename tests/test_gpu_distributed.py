@@ -251,6 +251,86 @@ def test_two_ranks_train_step_task_streams_equal_sequential_under_syncbn():
         assert np.array_equal(res[0][True][1][k], res[1][True][1][k]), k
 
 
+def _worker_peer(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cerberusdet_amd.peer_exchange import PeerExchange
+        from cerberusdet_amd.trainers import Averaging
+
+        # (a) the primitive: many epochs of several slots, lengths from 2 to 5000 floats, against the process group's all-reduce
+        px = PeerExchange(torch.device(DEV), rank, world)
+        g = torch.Generator().manual_seed(100 + rank)
+        vecs = [torch.randn(n, generator=g).to(DEV) for n in (2, 160, 640, 5000)]
+        calls = [px.make_call(v) for v in vecs]
+        st = torch.cuda.current_stream().cuda_stream
+        prim_ok = True
+        for it in range(25):
+            for v, c in zip(vecs, calls):
+                v.copy_(torch.randn(v.shape, generator=g).to(DEV))
+                want = v.clone()
+                dist.all_reduce(want)
+                c(st)
+                torch.cuda.synchronize()
+                prim_ok = prim_ok and bool(torch.equal(v, want))
+        px.check()
+        px.close()
+        # (b) two iterations of train_step under SyncBatchNorm: peer-write exchange vs the process-group form
+        synth, meta, mmeta = _setup()
+        half = BS // world
+        batches = _batches(synth, meta, rank * half, (rank + 1) * half)
+        out = {}
+        for peer in ("0", "1"):
+            os.environ["CDET_SYNCBN_PEER"] = peer
+            m = _model(synth, meta, mmeta)
+            tr = Averaging(torch.device(DEV), m, meta["hyp"], meta["tasks"], epochs=100, nb=1000, use_ema=False, rank=rank, world_size=world,
+                           sync_bn=True)
+            assert (m._peer_xchg is not None) == (peer == "1")
+            items = None
+            for it in range(2):
+                items = tr.train_step(batches, n_max=8, ni=2000 + it)
+            torch.cuda.synchronize()
+            tr.check_targets()
+            n_x = m._peer_xchg.n_calls if m._peer_xchg is not None else 0
+            out[peer] = ({t: v.cpu().numpy() for t, v in items.items()}, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, n_x)
+        q.put((rank, prim_ok, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_peer_write_syncbn_exchange_bit_identical_to_the_process_group_form():
+    """Round 4 (SURVEY section 5 plan item v, reference train.py:140-143): the SyncBatchNorm statistics travel as peer writes into IPC-mapped exchange
+    buffers (csrc/peer_exchange.hip) instead of ~350 collectives per iteration. Two ranks sharing the GPU: the primitive equals the group's all-reduce
+    bit for bit over 100 exchanges; two training iterations with the exchange give the same loss items, weights and running statistics -- bit for
+    bit -- as with the process-group all-reduces, on both ranks, and both ranks end with identical weights."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1500) + 21
+    procs = [ctx.Process(target=_worker_peer, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (ok, out) for r, ok, out in (q.get(timeout=600) for _ in procs)}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok, out = res[rank]
+        assert ok, f"rank {rank}: peer-write all-reduce differs from the process group's"
+        (it_g, sd_g, n_g), (it_p, sd_p, n_p) = out["0"], out["1"]
+        assert n_g == 0 and n_p > 20  # every SyncBatchNorm collective of the compiled plans went through the exchange
+        for t in it_g:
+            assert np.array_equal(it_g[t], it_p[t]), (rank, t)
+        for k in sd_g:
+            assert np.array_equal(sd_g[k], sd_p[k]), (rank, k)
+    for k in res[0][1]["1"][1]:
+        assert np.array_equal(res[0][1]["1"][1][k], res[1][1]["1"][1][k]), k
+
+
 def test_dry_comm_every_virtual_rank_enqueues_the_same_collective_sequence():
     """bench.py --dry-comm: collectives recorded instead of executed, three virtual ranks with their own shards, 2- and 3-task plans,
     SyncBatchNorm + gradient reduction + task streams, all-tasks / one-task iterations (--skip-batches): identical (bytes, stream)
