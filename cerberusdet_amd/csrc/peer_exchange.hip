@@ -10,6 +10,8 @@
 //      order on every rank, so all ranks hold bit-identical sums (RCCL's ring order is not specified; for two ranks a + b is the same either way).
 // Slots are double-buffered by epoch parity: a rank can only reach epoch e + 2 of a slot after every peer has finished reading epoch e (it needs their
 // e + 1 flags first). A spin that exceeds its budget raises an error word instead of hanging the GPU.
+#include <string.h>
+
 #include "common.h"
 
 namespace cdet {

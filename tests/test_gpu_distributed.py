@@ -314,7 +314,7 @@ def test_two_ranks_peer_write_syncbn_exchange_bit_identical_to_the_process_group
     procs = [ctx.Process(target=_worker_peer, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = {r: (ok, out) for r, ok, out in (q.get(timeout=600) for _ in procs)}
+    res = {r: (ok, out) for r, ok, out in (q.get(timeout=240) for _ in procs)}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
