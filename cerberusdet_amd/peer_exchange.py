@@ -24,7 +24,9 @@ from . import _lib as L
 class PeerExchange:
     def __init__(self, device, rank: int, world: int, group=None, capacity_bytes: int = 64 << 20):
         self.lib = L.load()
-        self.device, self.rank, self.world, self.group = torch.device(device), rank, world, group
+        dev = torch.device(device)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.rank, self.world, self.group = rank, world, group
         self.capacity = capacity_bytes
         self.n_calls = 0       # exchanges compiled into launch lists (collectives per iteration = those on the executed plans)
         self._bump = 256       # bytes handed out (the first 256 stay zero)
@@ -54,7 +56,7 @@ class PeerExchange:
     # ---------------------------------------------------------------------------------------------------------------------------------
     def make_call(self, t: torch.Tensor):
         """Launch-list entry (callable taking the raw stream) that SUM-all-reduces the fp32 vector `t` in place over the ranks."""
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.device.type == "cuda" and t.device.index == self.device.index
         n = t.numel()
         data_bytes, flag_bytes = 2 * self.world * n * 4, 2 * self.world * 4
         data_off = (self._bump + 255) // 256 * 256

@@ -297,6 +297,10 @@ def _worker_peer(rank, world, port, q):
             n_x = m._peer_xchg.n_calls if m._peer_xchg is not None else 0
             out[peer] = ({t: v.cpu().numpy() for t, v in items.items()}, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, n_x)
         q.put((rank, prim_ok, out))
+    except Exception:  # noqa: BLE001 -- report instead of letting the parent wait for its queue time-out
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()))
     finally:
         dist.destroy_process_group()
 
@@ -317,9 +321,9 @@ def test_two_ranks_peer_write_syncbn_exchange_bit_identical_to_the_process_group
     res = {r: (ok, out) for r, ok, out in (q.get(timeout=240) for _ in procs)}
     for p in procs:
         p.join(60)
-        assert p.exitcode == 0
     for rank in (0, 1):
         ok, out = res[rank]
+        assert not isinstance(out, str), out
         assert ok, f"rank {rank}: peer-write all-reduce differs from the process group's"
         (it_g, sd_g, n_g), (it_p, sd_p, n_p) = out["0"], out["1"]
         assert n_g == 0 and n_p > 20  # every SyncBatchNorm collective of the compiled plans went through the exchange
