@@ -10,20 +10,24 @@
 //      order on every rank, so all ranks hold bit-identical sums (RCCL's ring order is not specified; for two ranks a + b is the same either way).
 // Slots are double-buffered by epoch parity: a rank can only reach epoch e + 2 of a slot after every peer has finished reading epoch e (it needs their
 // e + 1 flags first). A spin that exceeds its budget raises an error word instead of hanging the GPU.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
 
 namespace cdet {
 
-constexpr unsigned long long PEER_SPIN_CLOCKS = 4000000000ull;  // ~2 s at 2 GHz: a missing peer is an error, not a hang
-
+// phase: 0 = the whole exchange; 1 = write + publish only, 2 = wait + sum only (the two halves as separate launches with a host-side barrier
+// between them: for ranks that SHARE one GPU, whose kernels the driver time-slices instead of running them side by side -- a spinning kernel
+// would wait for a peer that cannot run; tests/test_gpu_distributed.py). spin: clock budget of the wait (a missing peer is an error, not a hang).
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(float* __restrict__ vec, int n, const uint64_t* __restrict__ peers, int world, int rank,
-                                                             long long data_off, long long flag_off, unsigned epoch, unsigned* __restrict__ err) {
+                                                             long long data_off, long long flag_off, unsigned epoch, unsigned* __restrict__ err,
+                                                             int phase, unsigned long long spin) {
     const int t = threadIdx.x;
     const int par = (int)(epoch & 1u);
     const long long row = ((long long)par * world + rank) * n;
     // 1. my vector into my row of the slot on every rank
+    if (phase != 2) {
     for (int p = 0; p < world; ++p) {
         float* dst = reinterpret_cast<float*>(peers[p]) + data_off + row;
         for (int i = t; i < n; i += 256) __hip_atomic_store(dst + i, vec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -34,12 +38,14 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(float* __restrict__
         unsigned* f = reinterpret_cast<unsigned*>(peers[t]) + flag_off + par * world + rank;
         __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    }
+    if (phase == 1) return;
     // 2. all rows of the slot in MY buffer
     if (t < world) {
         const unsigned* f = reinterpret_cast<const unsigned*>(peers[rank]) + flag_off + par * world + t;
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (__builtin_readcyclecounter() - t0 > PEER_SPIN_CLOCKS) {
+            if (__builtin_readcyclecounter() - t0 > spin) {
                 __hip_atomic_store(err, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -118,11 +124,17 @@ extern "C" int cdet_peer_close(void* p) {
 }
 
 extern "C" int cdet_peer_allreduce(float* vec, int32_t n, const void* peer_table, int32_t world, int32_t rank, int64_t data_off, int64_t flag_off,
-                                   uint32_t epoch, void* err, void* stream) {
+                                   uint32_t epoch, void* err, int32_t phase, void* stream) {
     CDET_CHECK_ARG(vec && peer_table && err && n > 0, "cdet_peer_allreduce: bad arguments");
     CDET_CHECK_ARG(world >= 1 && world <= 64 && rank >= 0 && rank < world && epoch != 0, "cdet_peer_allreduce: bad world / rank / epoch");
+    CDET_CHECK_ARG(phase >= 0 && phase <= 2, "cdet_peer_allreduce: phase must be 0 (whole exchange), 1 (publish) or 2 (collect)");
+    static unsigned long long spin = 0;
+    if (!spin) {
+        const char* e = getenv("CDET_PEER_SPIN_MS");  // wait budget per exchange (default 10 s)
+        spin = (unsigned long long)(e ? atoll(e) : 10000) * 2000000ull;  // ~2 GHz shader clock
+    }
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vec, n, (const uint64_t*)peer_table, world, rank,
-                       (long long)data_off, (long long)flag_off, epoch, (unsigned*)err);
+                       (long long)data_off, (long long)flag_off, epoch, (unsigned*)err, phase, spin);
     CDET_LAUNCH_CHECK();
     return 0;
 }

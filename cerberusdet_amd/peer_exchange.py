@@ -28,6 +28,9 @@ class PeerExchange:
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.rank, self.world, self.group = rank, world, group
         self.capacity = capacity_bytes
+        # CDET_PEER_XCHG_HOSTSYNC=1: the two halves of an exchange as separate launches around a host barrier -- for ranks that share one GPU
+        # (the driver time-slices the kernels of different processes; an in-kernel wait for a peer that cannot run would only time out)
+        self.hostsync = os.environ.get("CDET_PEER_XCHG_HOSTSYNC", "0") == "1"
         self.n_calls = 0       # exchanges compiled into launch lists (collectives per iteration = those on the executed plans)
         self._bump = 256       # bytes handed out (the first 256 stay zero)
         self._mine = C.c_void_p()
@@ -69,9 +72,17 @@ class PeerExchange:
         lib, ptr, tab, err, world, rank = self.lib, t.data_ptr(), self.table.data_ptr(), self.err.data_ptr(), self.world, self.rank
         d_off, f_off = data_off // 4, flag_off // 4
 
+        hostsync, group = self.hostsync, self.group
+
         def call(st, t=t):  # (keeps `t` alive)
             state["epoch"] += 1
-            rc = lib.cdet_peer_allreduce(ptr, n, tab, world, rank, d_off, f_off, state["epoch"], err, st)
+            if hostsync:  # ranks sharing ONE GPU (tests): publish, host barrier, collect -- a spinning kernel would wait for a time-sliced peer
+                rc = lib.cdet_peer_allreduce(ptr, n, tab, world, rank, d_off, f_off, state["epoch"], err, 1, st)
+                torch.cuda.synchronize()
+                dist.barrier(group=group)
+                rc = rc or lib.cdet_peer_allreduce(ptr, n, tab, world, rank, d_off, f_off, state["epoch"], err, 2, st)
+            else:
+                rc = lib.cdet_peer_allreduce(ptr, n, tab, world, rank, d_off, f_off, state["epoch"], err, 0, st)
             if rc:
                 L.check(rc, "cdet_peer_allreduce")
 

@@ -453,7 +453,8 @@ int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const f
  *                                    the rank's row into every peer's slot, publishes an epoch flag, waits (bounded; *err != 0 on time-out) for all
  *                                    ranks' flags in its own buffer and sums. peer_table: device array of `world` buffer addresses (own included);
  *                                    the slot = 2 x world x n floats at data_off (floats) + 2 x world flags at flag_off (32-bit words); epoch > 0
- *                                    grows by one per use of the slot.
+ *                                    grows by one per use of the slot. phase 0 = the whole exchange; 1 / 2 = its publish / collect halves as separate
+ *                                    launches (ranks sharing one GPU are time-sliced, not concurrent: they need a host barrier between the halves).
  * ---------------------------------------------------------------------------------------------- */
 int cdet_peer_alloc(int64_t bytes, void** out);
 int cdet_peer_free(void* p);
@@ -461,7 +462,7 @@ int cdet_peer_export(void* p, void* handle64);
 int cdet_peer_import(const void* handle64, void** out);
 int cdet_peer_close(void* p);
 int cdet_peer_allreduce(float* vec, int32_t n, const void* peer_table, int32_t world, int32_t rank, int64_t data_off, int64_t flag_off, uint32_t epoch,
-                        void* err, void* stream);
+                        void* err, int32_t phase, void* stream);
 
 #ifdef __cplusplus
 }

@@ -255,6 +255,9 @@ def _worker_peer(rank, world, port, q):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    # both ranks share cuda:0 here, and the driver time-slices the kernels of different processes: the exchange runs as its two halves around a
+    # host barrier (the one-kernel form with its in-kernel wait is covered by test_peer_exchange_kernel_virtual_ranks_on_streams)
+    os.environ["CDET_PEER_XCHG_HOSTSYNC"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -305,9 +308,58 @@ def _worker_peer(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_peer_exchange_kernel_virtual_ranks_on_streams():
+    """csrc/peer_exchange.hip, the one-kernel form (write my row into every rank's slot, publish the epoch, WAIT in the kernel for all ranks' flags,
+    sum in rank order): three virtual ranks = three exchange buffers and three HIP streams of one process, whose kernels do run side by side.
+    60 epochs over three slots (parity double-buffering, epochs far beyond 2), against the rank-ordered fp32 sum, bit for bit; no time-out flag."""
+    import ctypes as C
+
+    from cerberusdet_amd import _lib as L
+
+    lib = L.load()
+    W, sizes = 3, (2, 640, 3001)
+    cap = 4 << 20
+    bufs = []
+    for _ in range(W):
+        p = C.c_void_p()
+        L.check(lib.cdet_peer_alloc(cap, C.byref(p)), "cdet_peer_alloc")
+        bufs.append(p)
+    table = torch.tensor([b.value for b in bufs], dtype=torch.int64, device=DEV)
+    errs = torch.zeros(W, dtype=torch.int32, device=DEV)
+    streams = [torch.cuda.Stream() for _ in range(W)]
+    offs, bump = [], 256
+    for n in sizes:
+        d = (bump + 255) // 256 * 256
+        f = d + 2 * W * n * 4
+        bump = f + 2 * W * 4
+        offs.append((d // 4, f // 4))
+    g = torch.Generator().manual_seed(9)
+    try:
+        for epoch in range(1, 61):
+            for (d_off, f_off), n in zip(offs, sizes):
+                vecs = [torch.randn(n, generator=g).to(DEV) for _ in range(W)]
+                want = vecs[0].clone()
+                for r in range(1, W):
+                    want = want + vecs[r]           # rank order
+                torch.cuda.synchronize()
+                order = [(epoch + r) % W for r in range(W)]  # the enqueue order of the virtual ranks changes every epoch
+                for r in order:
+                    with torch.cuda.stream(streams[r]):
+                        L.check(lib.cdet_peer_allreduce(vecs[r].data_ptr(), n, table.data_ptr(), W, r, d_off, f_off, epoch, errs[r:].data_ptr(), 0,
+                                                        streams[r].cuda_stream), "cdet_peer_allreduce")
+                torch.cuda.synchronize()
+                for r in range(W):
+                    assert torch.equal(vecs[r], want), (epoch, n, r)
+        assert int(errs.abs().sum()) == 0
+    finally:
+        for b in bufs:
+            lib.cdet_peer_free(b)
+
+
 def test_two_ranks_peer_write_syncbn_exchange_bit_identical_to_the_process_group_form():
     """Round 4 (SURVEY section 5 plan item v, reference train.py:140-143): the SyncBatchNorm statistics travel as peer writes into IPC-mapped exchange
-    buffers (csrc/peer_exchange.hip) instead of ~350 collectives per iteration. Two ranks sharing the GPU: the primitive equals the group's all-reduce
+    buffers (csrc/peer_exchange.hip) instead of ~350 collectives per iteration. Two PROCESSES sharing the GPU (HIP IPC handles exchanged over gloo; the
+    exchange as publish / host barrier / collect because the shared GPU time-slices the two processes): the primitive equals the group's all-reduce
     bit for bit over 100 exchanges; two training iterations with the exchange give the same loss items, weights and running statistics -- bit for
     bit -- as with the process-group all-reduces, on both ranks, and both ranks end with identical weights."""
     import torch.multiprocessing as mp
