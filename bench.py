@@ -420,6 +420,8 @@ def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29513")
     os.environ["CDET_REDUCE_ALWAYS"] = "1"
+    os.environ["CDET_SYNCBN_PEER"] = "0"  # record the process-group form: every SyncBatchNorm exchange shows up as a collective (the peer-write form,
+    #                                       peer_exchange.py, replaces exactly the non-gradient ones: `collectives_with_peer_exchange` below)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)  # a real (1-rank) group: the plans compile their SyncBN form
     real = dist.all_reduce
     log, streams = [], {}
@@ -430,7 +432,7 @@ def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
 
     def recorder(t, op=None, group=None, async_op=False):
         sid = streams.setdefault(torch.cuda.current_stream().cuda_stream, len(streams))
-        log.append((t.numel() * t.element_size(), sid))
+        log.append((t.numel() * t.element_size(), sid, bool(async_op)))  # async_op: a gradient bucket (trainers/averaging.GradReducer)
         return _Done() if async_op else None
 
     out = {"mode": "dry-comm", "virtual_ranks": virtual_ranks, "batch": batch, "imgsz": imgsz, "plans": {}}
@@ -460,8 +462,11 @@ def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
             same = all(s_ == seqs[0] for s_ in seqs[1:])
             ok = ok and same
             out["plans"][cfg_name] = {"identical_on_all_ranks": same,
-                                      "steps": [{"active_tasks": a, "collectives": len(st), "bytes": sum(b for b, _ in st),
-                                                 "streams_used": len({s_ for _, s_ in st})} for a, st in zip(patterns, seqs[0])]}
+                                      "steps": [{"active_tasks": a, "collectives": len(st), "bytes": sum(b for b, _, _ in st),
+                                                 "streams_used": len({s_ for _, s_, _ in st}),
+                                                 "syncbn_exchanges": sum(1 for _, _, g_ in st if not g_),
+                                                 "collectives_with_peer_exchange": sum(1 for _, _, g_ in st if g_)}
+                                                for a, st in zip(patterns, seqs[0])]}
     finally:
         dist.all_reduce = real
         dist.destroy_process_group()
