@@ -482,14 +482,22 @@ class CerberusDet(nn.Module):
             frozen = tuple(i for i, b in enumerate(self.blocks)
                            if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters()))
         key = (tuple(tasks), tuple(shape), img_dtype, training, self.compute_dtype, bool(getattr(self, "sync_bn", False)), frozen)
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
             dev = next(super().parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
             N, c, H, W = shape
+            if not training:
+                # every plan owns its activation buffers (a YOLOv8x eval plan at batch 32 @640: ~6 GB): rectangular validation batches
+                # (one frame shape per aspect-ratio bucket, data.rect_batch_shapes) or odd last batches would otherwise pile up one
+                # resident plan per shape. Least recently used eval plans beyond CDET_MAX_EVAL_PLANS (default 6) are dropped.
+                cap = int(os.environ.get("CDET_MAX_EVAL_PLANS", "6"))
+                evals = [k for k in self._plans if k[3] is False]
+                for k in evals[:max(len(evals) - cap + 1, 0)]:
+                    del self._plans[k]
             plan = Plan(self, tasks, N, H, W, training, self.compute_dtype, img_dtype, dev, frozen=frozen)
-            self._plans[key] = plan
+        self._plans[key] = plan  # (re-inserted last: dict order = recency)
         return plan
 
     def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False, zero_copy=False):

@@ -86,6 +86,23 @@ def test_eval_stream_lanes_bit_identical_to_single_stream(name, monkeypatch):
             assert torch.equal(a, b)
 
 
+def test_eval_plan_cache_is_bounded(monkeypatch):
+    """Every eval plan owns its buffers; rectangular validation batches bring one frame shape per bucket. The model keeps the most recently
+    used CDET_MAX_EVAL_PLANS eval plans (training plans are never dropped) and re-compiles an evicted shape on demand with the same result."""
+    arrays, meta = load_golden("model_tiny2")
+    m = _build(meta).eval()
+    monkeypatch.setenv("CDET_MAX_EVAL_PLANS", "3")
+    x0 = torch.from_numpy(synth.det_image(meta["seed"], 1, 64)).to(DEV)
+    with torch.no_grad():
+        first = m(x0)[meta["tasks"][0]][0].clone()
+        for hw in ((64, 96), (96, 64), (96, 96), (128, 64), (64, 128)):
+            m(torch.zeros(1, 3, *hw, dtype=torch.uint8, device=DEV))
+            assert sum(1 for k in m._plans if k[3] is False) <= 3
+        assert not any(k[1] == tuple(x0.shape) for k in m._plans)      # the first shape was evicted ...
+        again = m(x0)[meta["tasks"][0]][0]
+    assert torch.equal(first, again)                                     # ... and compiles again to the same result
+
+
 def test_default_forward_returns_fresh_tensors_without_a_copy():
     """Reference contract (cerberus.py:804-882): every call returns new tensors. The eval plan gets there by pointing the projection /
     decode launches at a newly allocated output set (engine.Plan.fresh_outputs), train mode by one flat copy: results of an earlier call
