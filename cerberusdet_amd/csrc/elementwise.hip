@@ -712,6 +712,61 @@ __global__ __launch_bounds__(256) void pool5_kernel(uint16_t* __restrict__ buf, 
     }
 }
 
+// Round 4: the three chained 5x5 pools of an SPPF (models/common.py:230-245: y1 = m(x), y2 = m(y1), y3 = m(y2)) as ONE launch when the map fits
+// LDS (20 x 20 at 640 px): a workgroup owns one image x 32 channels, keeps the plane in LDS and runs each stage separably (row maximum, then
+// column maximum -- the same window maximum, exact for 16-bit values), writing every stage's slice as it goes. Same bits as three pool5
+// launches; two launches and two round trips through L2 less on the serial trunk.
+template <int DT>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(uint16_t* __restrict__ buf, int ld, int coff, int C, int H, int W, int CV) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp[];
+    constexpr int G = 4;                                   // 8-channel vectors per workgroup
+    const int groups = (CV + G - 1) / G;
+    const int n = blockIdx.x / groups, g0 = (blockIdx.x % groups) * G;
+    const int ng = CV - g0 < G ? CV - g0 : G;
+    const int HW = H * W;
+    u32x4* const A = reinterpret_cast<u32x4*>(sp);         // [HW][G]
+    u32x4* const B = A + HW * G;
+    uint16_t* const base = buf + (int64_t)n * HW * ld;
+    for (int e = threadIdx.x; e < HW * ng; e += 256) {
+        const int p = e / ng, g = e - p * ng;
+        A[p * G + g] = *reinterpret_cast<const u32x4*>(base + (int64_t)p * ld + coff + (g0 + g) * 8);
+    }
+    __syncthreads();
+    auto vmax = [](const u32x4& a, const u32x4& b) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float al = Elem<DT>::to_f32((uint16_t)(a[i] & 0xffff)), ah = Elem<DT>::to_f32((uint16_t)(a[i] >> 16));
+            const float bl = Elem<DT>::to_f32((uint16_t)(b[i] & 0xffff)), bh = Elem<DT>::to_f32((uint16_t)(b[i] >> 16));
+            o[i] = (uint32_t)Elem<DT>::from_f32(fmaxf(al, bl)) | ((uint32_t)Elem<DT>::from_f32(fmaxf(ah, bh)) << 16);
+        }
+        return o;
+    };
+    for (int stage = 0; stage < 3; ++stage) {
+        for (int e = threadIdx.x; e < HW * ng; e += 256) {  // rows: B = max over x - 2 .. x + 2 of A
+            const int p = e / ng, g = e - p * ng;
+            const int x = p % W;
+            u32x4 m = A[p * G + g];
+#pragma unroll
+            for (int k = -2; k <= 2; ++k)
+                if (k != 0 && (unsigned)(x + k) < (unsigned)W) m = vmax(m, A[(p + k) * G + g]);
+            B[p * G + g] = m;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < HW * ng; e += 256) {  // columns: A = max over y - 2 .. y + 2 of B, and out
+            const int p = e / ng, g = e - p * ng;
+            const int y = p / W;
+            u32x4 m = B[p * G + g];
+#pragma unroll
+            for (int k = -2; k <= 2; ++k)
+                if (k != 0 && (unsigned)(y + k) < (unsigned)H) m = vmax(m, B[(p + k * W) * G + g]);
+            *reinterpret_cast<u32x4*>(base + (int64_t)p * ld + coff + (stage + 1) * C + (g0 + g) * 8) = m;
+            if (stage < 2) A[p * G + g] = m;                // (nobody reads A in this pass)
+        }
+        __syncthreads();
+    }
+}
+
 // backward of one pool stage: din[q] += sum over windows p containing q of dout[p] * [argmax_p == q], argmax_p = first
 // maximum of window p in (ky, kx) scan order, recomputed from the saved forward input slice. One block owns a T x T pixel
 // tile of one image for one 8-channel vector (T = 20 when the whole map fits one tile -- the 20x20 level of a 640 input: four
@@ -1114,6 +1169,13 @@ extern "C" int cdet_upsample2_bwd(const void* ddst, int32_t ddst_ld, int32_t dds
 extern "C" int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
     if (int e = check16("cdet_sppf_pool", dtype, C, ld, coff, 0, 0)) return e;
     const int CV = C / 8;
+    if ((int64_t)H * W * 4 * 16 * 2 <= 60 * 1024 && tune_env("CDET_SPPF_FUSED", 1)) {  // the plane of 32 channels twice in LDS: one launch for the chain
+        const size_t lds = (size_t)H * W * 4 * 16 * 2;
+        DISPATCH16(dtype, hipLaunchKernelGGL((sppf_pool3_kernel<DT>), dim3(N * div_up(CV, 4)), dim3(256), lds, (hipStream_t)stream, (uint16_t*)buf, ld, coff,
+                                             C, H, W, CV));
+        CDET_LAUNCH_CHECK();
+        return 0;
+    }
     for (int i = 0; i < 3; ++i) {
         DISPATCH16(dtype, hipLaunchKernelGGL((pool5_kernel<DT>), dim3(grid_for((int64_t)N * H * W * CV, 256)), dim3(256), 0, (hipStream_t)stream,
                                              (uint16_t*)buf, ld, coff + i * C, coff + (i + 1) * C, N, H, W, CV));

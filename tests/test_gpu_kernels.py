@@ -441,15 +441,17 @@ def test_upsample_copy_pool():
     _close(dx.nchw(), x.grad, 2 ** -7, 1e-2)
 
 
-@pytest.mark.parametrize("hw", [(9, 11), (20, 20), (19, 17), (8, 8), (40, 40)])
+@pytest.mark.parametrize("hw", [(9, 11, 24), (20, 20, 24), (20, 20, 72), (19, 17, 24), (8, 8, 40), (40, 40, 24)])
 def test_sppf_pool_chain_forward_backward(hw):
     """reference SPPF (models/common.py:230-245): three chained 5x5 max pools, their autograd routing to the first maximum.
-    (20, 20) and (19, 17) take the one-tile form of the backward kernel, the others the 16x16 tiles."""
+    (20, 20) and (19, 17) take the one-tile form of the backward kernel, the others the 16x16 tiles. Round 4: maps up to 20 x 20 run the
+    forward chain as ONE launch (sppf_pool3_kernel: plane in LDS, separable maxima; channel groups of 32 with a partial last group), the
+    40 x 40 case three pool5 launches -- both must equal torch bit for bit."""
     ops = _ops()
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(5)
-    N, C2 = 2, 24
-    Hm, Wm = hw
+    N = 2
+    Hm, Wm, C2 = hw
     xs = _rt(torch.randn(N, C2, Hm, Wm, generator=g), dtype).requires_grad_(True)
     y1 = F.max_pool2d(xs, 5, 1, 2)
     y2 = F.max_pool2d(y1, 5, 1, 2)
