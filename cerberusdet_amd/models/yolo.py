@@ -66,45 +66,72 @@ def initialize_weights(model):
             m.momentum = BN_MOMENTUM
 
 
+# ---- YAML rows -> modules, table-driven -------------------------------------------------------------------------------------------
+# The reference builds every row through one if/elif chain on the eval()'d class (yolo.py:283-339). Here each module type names a
+# handler that turns (input widths, `from` index, YAML args, repeat count) into (constructor args, output width, repeats); the row
+# schema, the width-scaling rule (incl. its class-count quirk) and the resulting module tree / state-dict keys are the reference's.
+_LITERALS = {"None": None, "True": True, "False": False}
+
+
+def _resolve(name):
+    if not isinstance(name, str):
+        return name
+    if name == "Detect":
+        return Detect
+    try:
+        return MODULES[name]
+    except KeyError:
+        raise NotImplementedError(f"module '{name}' is not part of the CerberusDet hot path (Conv, C2f, SPPF, Concat, nn.Upsample, Detect)") from None
+
+
+def _row_conv(m, ch, f, args, n, nc, gw, max_channels):
+    c2 = args[0]
+    if c2 not in nc:  # reference quirk (yolo.py:311): a width that equals a class count is left unscaled
+        c2 = make_divisible(min(c2, max_channels) * gw, 8)
+    out = [ch[f], c2] + list(args[1:])
+    if m is C2f:  # the repeat count becomes the block's own depth argument
+        out.insert(2, n)
+        n = 1
+    return out, c2, n
+
+
+def _row_concat(m, ch, f, args, n, nc, gw, max_channels):
+    return list(args), sum(ch[x] for x in f), n
+
+
+def _row_detect(m, ch, f, args, n, nc, gw, max_channels):
+    out = list(args)
+    if not out:
+        out.append(nc.pop(0))       # one class count per Detect row, in task order
+    elif isinstance(out[0], list):
+        out[0] = out[0][0]
+    out.append([ch[x] for x in f])
+    return out, None, n
+
+
+def _row_same_width(m, ch, f, args, n, nc, gw, max_channels):
+    return list(args), ch[f], n
+
+
+_ROW_HANDLERS = {Conv: _row_conv, SPPF: _row_conv, C2f: _row_conv, Concat: _row_concat}
+
+
 def get_next_layer_from_cfg(gd, ch, gw, nc, m, n, f, args, max_channels):
-    """One YAML row -> module instance (reference yolo.py:283-339). `nc` is the list of per-task class counts;
-    a Detect row pops the first entry. Returns (args, nc, n, c2, module)."""
-    args = list(args)
-    for j, a in enumerate(args):
-        if isinstance(a, str):
-            if a == "None":
-                args[j] = None
-            elif a in ("True", "False"):
-                args[j] = a == "True"
-    if isinstance(m, str):
-        if m == "Detect":
-            m = Detect
-        elif m in MODULES:
-            m = MODULES[m]
-        else:
-            raise NotImplementedError(f"module '{m}' is not part of the CerberusDet hot path (Conv, C2f, SPPF, Concat, nn.Upsample, Detect)")
-    c2 = None
-    n = n_ = max(round(n * gd), 1) if n > 1 else n
-    if m in (Conv, SPPF, C2f):
-        c1, c2 = ch[f], args[0]
-        if all(c2 != nc_ for nc_ in nc):  # reference quirk (yolo.py:311): widths that equal a class count are not scaled
-            c2 = make_divisible(min(c2, max_channels) * gw, 8)
-        args = [c1, c2, *args[1:]]
-        if m is C2f:
-            args.insert(2, n)
-            n = 1
-    elif m is Concat:
-        c2 = sum(ch[x] for x in f)
-    elif m is Detect:
-        if len(args) == 0:
-            args.append(nc.pop(0))
-        elif isinstance(args[0], list):
-            args[0] = args[0][0]
-        args.append([ch[x] for x in f])
-    else:
-        c2 = ch[f]
-    module = nn.Sequential(*[m(*args) for _ in range(n)]) if n > 1 else m(*args)
-    return args, nc, n_, c2, module
+    """One YAML row -> module instance (reference yolo.py:283-339). `nc` is the list of per-task class counts; a Detect row pops
+    the first entry. Returns (args, nc, n, c2, module)."""
+    m = _resolve(m)
+    args = [_LITERALS.get(a, a) if isinstance(a, str) else a for a in args]
+    depth = max(round(n * gd), 1) if n > 1 else n
+    handler = _row_detect if m is Detect else _ROW_HANDLERS.get(m, _row_same_width)
+    args, c2, reps = handler(m, ch, f, args, depth, nc, gw, max_channels)
+    module = m(*args) if reps <= 1 else nn.Sequential(*(m(*args) for _ in range(reps)))
+    return args, nc, depth, c2, module
+
+
+def _sources(f, i, limit=None):
+    """Absolute indices of the layers row i reads besides its predecessor (the reference's `save` list entries)."""
+    refs = [f] if isinstance(f, int) else list(f)
+    return [x % i for x in refs if x != -1 and (limit is None or x < limit)]
 
 
 def parse_model(yaml_config, ch, without_head=False, verbose=False):
@@ -112,27 +139,20 @@ def parse_model(yaml_config, ch, without_head=False, verbose=False):
     gd, gw = yaml_config["depth_multiple"], yaml_config["width_multiple"]
     max_channels = yaml_config.get("max_channels", 1024)
     nc = yaml_config["nc"]
-    rows = list(yaml_config["backbone"])
-    if not without_head:
-        rows += list(yaml_config.get("neck") or []) + list(yaml_config["head"])
-    layers, save = [], []
+    tail = list(yaml_config.get("neck") or []) + list(yaml_config["head"])
+    rows = list(yaml_config["backbone"]) + ([] if without_head else tail)
+    layers, save, widths = [], [], list(ch)
     for i, (f, n, m, args) in enumerate(rows):
-        args, _, n_, c2, m_ = get_next_layer_from_cfg(gd, ch, gw, nc, m, n, f, args, max_channels)
-        m_.i, m_.f, m_.type = i, f, (m if isinstance(m, str) else m.__name__)
-        m_.np = sum(x.numel() for x in m_.parameters())
-        layers.append(m_)
-        if i == 0:
-            ch = []
-        ch.append(c2)
-        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
-    if without_head:
-        i = len(layers)
-        for h_layer in list(yaml_config["neck"]) + list(yaml_config["head"]):
-            f = h_layer[0]
-            f = [f] if isinstance(f, int) else f
-            save.extend(x % i for x in f if x != -1 and x < len(layers))
-            i += 1
-    return nn.Sequential(*layers), sorted(set(save)), ch
+        _, _, _, c2, layer = get_next_layer_from_cfg(gd, widths, gw, nc, m, n, f, args, max_channels)
+        layer.i, layer.f, layer.type = i, f, (m if isinstance(m, str) else m.__name__)
+        layer.np = sum(x.numel() for x in layer.parameters())
+        layers.append(layer)
+        widths = [c2] if i == 0 else widths + [c2]   # (the input width is dropped once row 0 has consumed it)
+        save += _sources(f, i)
+    if without_head:  # rows of neck / head that tap the backbone decide which of its outputs are kept
+        for k, row in enumerate(tail):
+            save += _sources(row[0], len(layers) + k, limit=len(layers))
+    return nn.Sequential(*layers), sorted(set(save)), widths
 
 
 class Model(_NoEager):
