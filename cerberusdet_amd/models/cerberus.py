@@ -389,7 +389,7 @@ class CerberusDet(nn.Module):
         return super().state_dict(*a, **k)
 
     _RUNTIME_ATTRS = ("_plan_slots", "_pack_key", "_wp", "_wpt", "_scale", "_bias", "_bias_pad", "_w8", "_gw8", "_stem8", "_wp_zeroed",
-                      "_wt_f", "_wt_d")
+                      "_wt_f", "_wt_d", "_ws1", "_merged_first")
 
     def _grad_buffer(self, p):
         g = self._pgrad.get(id(p))
@@ -413,6 +413,7 @@ class CerberusDet(nn.Module):
             if st:
                 saved[m] = st
         plans, pgrad, anchor = self._plans, self._pgrad, self.__dict__.pop("_anchor", None)
+        peer = self.__dict__.pop("_peer_xchg", None)  # (IPC-mapped exchange buffers belong to the trainer's model, not to its EMA copy)
         self._plans, self._pgrad = {}, {}
         try:
             new = self.__class__.__new__(self.__class__)
@@ -421,6 +422,8 @@ class CerberusDet(nn.Module):
                 new.__dict__[k] = deepcopy(v, memo)
         finally:
             self._plans, self._pgrad = plans, pgrad
+            if peer is not None:
+                self._peer_xchg = peer
             if anchor is not None:
                 object.__setattr__(self, "_anchor", anchor)
             for m, st in saved.items():

@@ -108,6 +108,18 @@ def try_setup(device, rank: int, world: int, group=None):
     """PeerExchange on every rank, or None on every rank (RCCL form) when any rank cannot set it up / CDET_SYNCBN_PEER=0."""
     if world <= 1 or os.environ.get("CDET_SYNCBN_PEER", "1") == "0":
         return None
+    # Ranks that SHARE a GPU (tests; never a production layout) are time-sliced by the driver, not run side by side: the in-kernel wait of
+    # the one-kernel exchange would only time out. Unless the split form is asked for explicitly (CDET_PEER_XCHG_HOSTSYNC=1), such a group
+    # keeps the process-group exchange.
+    import socket
+
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ident = (socket.gethostname(), str(getattr(torch.cuda.get_device_properties(idx), "uuid", idx)), idx)
+    idents = [None] * world
+    dist.all_gather_object(idents, ident, group=group)
+    if len(set(idents)) < world and os.environ.get("CDET_PEER_XCHG_HOSTSYNC", "0") != "1":
+        return None
     px, ok = None, 1
     try:
         px = PeerExchange(device, rank, world, group, capacity_bytes=int(os.environ.get("CDET_PEER_XCHG_MB", "64")) << 20)

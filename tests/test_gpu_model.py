@@ -86,6 +86,39 @@ def test_eval_stream_lanes_bit_identical_to_single_stream(name, monkeypatch):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
+def test_eval_plan_variants_carry_the_same_bits(name, monkeypatch):
+    """Round-4 forms of the eval plan against the round-3 forms they replace, switch by switch: merged first convolutions of a Detect level
+    (CDET_HEAD_MERGE), virtual Concat / Upsample (CDET_VCAT), fused first two backbone rows (CDET_STEM_FUSE), early head chains
+    (CDET_EARLY_HEADS), projections on the tap-resident kernel (CDET_PROJ_TILED is NOT in this list: fp32 sums in another order) -- each
+    one reorders launches or removes copies, none may change a bit of `y` or of the head maps."""
+    arrays, meta = load_golden(name)
+    m = _build(meta).eval()
+    x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
+    switches = ("CDET_HEAD_MERGE", "CDET_VCAT", "CDET_STEM_FUSE", "CDET_EARLY_HEADS")
+
+    def run():
+        m._plans.clear()
+        with torch.no_grad():
+            o = m(x)
+        torch.cuda.synchronize()
+        return [o[t][0].clone() for t in meta["tasks"]] + [f.clone() for t in meta["tasks"] for f in o[t][1]]
+
+    base = run()
+    plan = m.get_plan(meta["tasks"], x.shape, x.dtype)
+    names = [getattr(fn, "__name__", "") for fn, _ in plan.fwd]
+    assert "cdet_stem_conv1" in names and "cdet_conv2d_tiled_cat" in names and "cdet_upsample2" not in names
+    for sw in switches:
+        monkeypatch.setenv(sw, "0")
+        got = run()
+        monkeypatch.delenv(sw)
+        assert len(got) == len(base) and all(torch.equal(a, b) for a, b in zip(got, base)), sw
+    for sw in switches:
+        monkeypatch.setenv(sw, "0")
+    got = run()  # the round-3 plan
+    assert all(torch.equal(a, b) for a, b in zip(got, base))
+
+
 def test_eval_plan_cache_is_bounded(monkeypatch):
     """Every eval plan owns its buffers; rectangular validation batches bring one frame shape per bucket. The model keeps the most recently
     used CDET_MAX_EVAL_PLANS eval plans (training plans are never dropped) and re-compiles an evicted shape on demand with the same result."""

@@ -91,6 +91,10 @@ def test_eval_plan_keeps_concat_and_upsample_virtual(monkeypatch):
         return [getattr(fn, "__name__", "") for fn, _ in plan.fwd]
 
     v = names(Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev))
+    monkeypatch.setenv("CDET_HEAD_MERGE", "0")
+    unmerged = names(Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev))
+    monkeypatch.delenv("CDET_HEAD_MERGE")
+    assert len(unmerged) == len(v) + 2 * 3  # one launch less per Detect level: cv2[l][0] and cv3[l][0] read the same input
     assert v.count("cdet_conv2d_tiled_cat") == 8 and "cdet_upsample2" not in v and "cdet_copy_channels" not in v  # 4 neck Concats per task
     monkeypatch.setenv("CDET_VCAT", "0")
     r3 = names(Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev))
@@ -132,3 +136,23 @@ def test_gemm_form_reference_equals_torch_conv2d_and_its_autograd(case):
     # integer operands: exact, whatever the order
     xi, wi = torch.randint(-2, 3, x.shape).float(), torch.randint(-1, 2, w.shape).float()
     assert torch.equal(R.conv_fwd(xi, wi, s), F.conv2d(xi.permute(0, 3, 1, 2), wi, None, s, k // 2).permute(0, 2, 3, 1))
+
+
+def test_model_with_compiled_plans_deep_copies_without_runtime_state():
+    """ModelEMA / branch cloning deep-copy the model while launch lists (ctypes descriptors), packed operands, merged head convolutions
+    and the trainer's IPC exchange hang off its modules: none of that may travel (or break the copy)."""
+    import copy
+
+    from cerberusdet_amd.engine import Plan
+
+    tasks = ["voc", "objects365_animals"]
+    m = _model("v8n_2task.yaml", tasks)
+    dev = torch.device("cpu")
+    Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev)
+    Plan(m, [tasks[0]], 2, 64, 64, True, torch.bfloat16, torch.uint8, dev)
+    m._peer_xchg = object()
+    c = copy.deepcopy(m)
+    assert not hasattr(c, "_peer_xchg") and m._peer_xchg is not None
+    assert not any(a in mod.__dict__ for mod in c.modules() for a in type(m)._RUNTIME_ATTRS)
+    assert any("_plan_slots" in mod.__dict__ for mod in m.modules())  # the original keeps its runtime state
+    assert c.state_dict().keys() == m.state_dict().keys()
