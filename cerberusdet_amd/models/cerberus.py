@@ -389,7 +389,7 @@ class CerberusDet(nn.Module):
         return super().state_dict(*a, **k)
 
     _RUNTIME_ATTRS = ("_plan_slots", "_pack_key", "_wp", "_wpt", "_scale", "_bias", "_bias_pad", "_w8", "_gw8", "_stem8", "_wp_zeroed",
-                      "_wt_f", "_wt_d", "_ws1", "_merged_first")
+                      "_wt_f", "_wt_d", "_ws1")
 
     def _grad_buffer(self, p):
         g = self._pgrad.get(id(p))

@@ -88,14 +88,14 @@ def test_eval_stream_lanes_bit_identical_to_single_stream(name, monkeypatch):
 
 @pytest.mark.parametrize("name", ["model_tiny2", "model_tiny3"])
 def test_eval_plan_variants_carry_the_same_bits(name, monkeypatch):
-    """Round-4 forms of the eval plan against the round-3 forms they replace, switch by switch: merged first convolutions of a Detect level
-    (CDET_HEAD_MERGE), virtual Concat / Upsample (CDET_VCAT), fused first two backbone rows (CDET_STEM_FUSE), early head chains
+    """Round-4 forms of the eval plan against the round-3 forms they replace, switch by switch: virtual Concat / Upsample (CDET_VCAT), fused
+    first two backbone rows (CDET_STEM_FUSE), early head chains
     (CDET_EARLY_HEADS), projections on the tap-resident kernel (CDET_PROJ_TILED is NOT in this list: fp32 sums in another order) -- each
     one reorders launches or removes copies, none may change a bit of `y` or of the head maps."""
     arrays, meta = load_golden(name)
     m = _build(meta).eval()
     x = torch.from_numpy(synth.det_image(meta["seed"], meta["bs"], meta["imgsz"])).to(DEV)
-    switches = ("CDET_HEAD_MERGE", "CDET_VCAT", "CDET_STEM_FUSE", "CDET_EARLY_HEADS")
+    switches = ("CDET_VCAT", "CDET_STEM_FUSE", "CDET_EARLY_HEADS")
 
     def run():
         m._plans.clear()
