@@ -233,6 +233,7 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
         float* stl = reinterpret_cast<float*>(smem + HZERO);  // [8 waves][2][HC]
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
+            float s16[16], q16[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float s_ = 0.f, q_ = 0.f;
@@ -242,14 +243,10 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
                     s_ += v0;
                     q_ += v0 * v0;
                 }
-                const float sv = half_sum32(s_);
-                const float qv = half_sum32(q_);
-                if (l31 == 0) {
-                    const int cl = f * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    stl[(wave * 2 + 0) * HC + cl] = sv;
-                    stl[(wave * 2 + 1) * HC + cl] = qv;
-                }
+                s16[r] = s_;
+                q16[r] = q_;
             }
+            tile_stats32(s16, q16, stl + (wave * 2 + 0) * HC + f * 32, stl + (wave * 2 + 1) * HC + f * 32, lane);
         }
         __syncthreads();
         if (t < 2 * HC) {

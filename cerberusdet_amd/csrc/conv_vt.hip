@@ -396,6 +396,7 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
         float* stl = reinterpret_cast<float*>(smem + HZERO);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
+            float s16[16], q16[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float s_ = 0.f, q_ = 0.f;
@@ -405,14 +406,10 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
                     s_ += v0;
                     q_ += v0 * v0;
                 }
-                const float sv = half_sum32(s_);
-                const float qv = half_sum32(q_);
-                if (l31 == 0) {
-                    const int cl = f * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    stl[(wave * 2 + 0) * HC + cl] = sv;
-                    stl[(wave * 2 + 1) * HC + cl] = qv;
-                }
+                s16[r] = s_;
+                q16[r] = q_;
             }
+            tile_stats32(s16, q16, stl + (wave * 2 + 0) * HC + f * 32, stl + (wave * 2 + 1) * HC + f * 32, lane);
         }
         __syncthreads();
         if (t < HC && c0 + t < a.Cd) {

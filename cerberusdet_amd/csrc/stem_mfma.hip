@@ -52,15 +52,36 @@ __device__ __forceinline__ void smfma32(const u32x4& a, const u32x4& b, sf32x16&
     else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float shalf_sum32(float v) {
+// BatchNorm partial sums of one 32 x 32 accumulator tile over its 32 pixels (same scheme as halo_common.h tile_stats32: v_permlane16_swap pairs
+// registers r / r + 8, four DPP levels inside the 16-lane rows, lanes 0 / 16 / 32 / 48 store the totals)
+__device__ __forceinline__ float srow_sum16(float v) {
 #define CDET_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
     CDET_DPP_ADD(0xB1);
     CDET_DPP_ADD(0x4E);
     CDET_DPP_ADD(0x141);
     CDET_DPP_ADD(0x140);
 #undef CDET_DPP_ADD
-    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
     return v;
+}
+
+__device__ __forceinline__ void stile_stats32(const float (&s)[16], const float (&q)[16], float* ds, float* dq, int lane) {
+    float ts[8], tq[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[r]), __float_as_uint(s[r + 8]), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(q[r]), __float_as_uint(q[r + 8]), false, false);
+        const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        ts[r] = srow_sum16(__uint_as_float(a0) + __uint_as_float(a1));
+        tq[r] = srow_sum16(__uint_as_float(b0) + __uint_as_float(b1));
+    }
+    if ((lane & 15) == 0) {
+        const int base = 4 * (lane >> 5) + 16 * ((lane >> 4) & 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            ds[base + 8 * (r >> 2) + (r & 3)] = ts[r];
+            dq[base + 8 * (r >> 2) + (r & 3)] = tq[r];
+        }
+    }
 }
 
 // A: image elements per aligned dword load (4 = uint8, 2 = half / bfloat16, 1 = float)
@@ -218,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs a) {
     if (a.stats != nullptr) {
 #pragma unroll
         for (int f = 0; f < ST_NF; ++f) {
+            float s16[16], q16[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float s_ = 0.f, q_ = 0.f;
@@ -227,13 +249,10 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const StemArgs a) {
                     s_ += v0;
                     q_ += v0 * v0;
                 }
-                const float sv = shalf_sum32(s_), qv = shalf_sum32(q_);
-                if (l31 == 0) {
-                    const int cl = f * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    red[(wave * 2 + 0) * ST_HC + cl] = sv;
-                    red[(wave * 2 + 1) * ST_HC + cl] = qv;
-                }
+                s16[r] = s_;
+                q16[r] = q_;
             }
+            stile_stats32(s16, q16, red + (wave * 2 + 0) * ST_HC + f * 32, red + (wave * 2 + 1) * ST_HC + f * 32, lane);
         }
         __syncthreads();
         if (t < a.Cout) {

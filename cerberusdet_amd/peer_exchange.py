@@ -126,6 +126,22 @@ def try_setup(device, rank: int, world: int, group=None):
     except Exception as e:  # noqa: BLE001 -- any failure means "use RCCL", decided collectively below
         print(f"[cerberusdet_amd] peer exchange unavailable on rank {rank} ({e}); SyncBatchNorm statistics go over the process group", flush=True)
         ok = 0
+    if px is not None:
+        # known-answer exchange before anything depends on it: rank r contributes r + 1, every rank must read world (world + 1) / 2.
+        # A mapping that opens but does not carry peer stores (or flags that never become visible) shows up HERE, as a fall-back to the
+        # process group, instead of as timed-out exchanges inside the first training iteration.
+        try:
+            probe = torch.full((64,), float(rank + 1), dtype=torch.float32, device=px.device)
+            with torch.cuda.device(px.device):
+                px.make_call(probe)(torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+            px.n_calls -= 1  # (not an exchange of any plan)
+            if int(px.err.item()) != 0 or not bool((probe == world * (world + 1) / 2).all()):
+                raise RuntimeError(f"known-answer exchange failed (error word {int(px.err.item())}, got {float(probe[0])})")
+        except Exception as e:  # noqa: BLE001
+            print(f"[cerberusdet_amd] peer exchange self-test failed on rank {rank} ({e}); SyncBatchNorm statistics go over the process group", flush=True)
+            px.err.zero_()
+            ok = 0
     flags = [None] * world
     dist.all_gather_object(flags, ok, group=group)
     if not all(flags):

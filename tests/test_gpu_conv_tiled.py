@@ -326,3 +326,4 @@ def test_conv_over_virtual_concat_equals_the_materialised_one(case, monkeypatch)
     assert (yb[..., :8].float() == 7.0).all() and (yb[..., 8 + Co:].float() == 7.0).all()
     ref = F.silu(F.conv2d(x.permute(0, 3, 1, 2), w) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
     _close(got.nchw(), ref, 2 ** -7, 2e-2)
+

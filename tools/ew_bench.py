@@ -60,6 +60,10 @@ def main():
         P = ops.ptr
         dtc = ops.dt(torch.bfloat16)
         t_f = timeit(lambda: ops.bn_silu_fwd(z, mean, invstd, gamma, beta, y), a.reps)
+        wide = ops.new_act(N, H, W, 5 * Cn, torch.bfloat16, dev)   # the same pass writing a channel slice of a concat buffer (pitch 5 C)
+        ys = ops.View(wide.buf, Cn, Cn)
+        t_fs = timeit(lambda: ops.bn_silu_fwd(z, mean, invstd, gamma, beta, ys), a.reps)
+        del wide, ys
         t_r = timeit(lambda: lib.cdet_bn_silu_bwd_reduce(P(dy), dy.ld, 0, P(z), z.ld, 0, P(mean), P(invstd), P(gamma), P(beta), P(part), M, Cn, dtc,
                                                          st), a.reps)
         t_a = timeit(lambda: lib.cdet_bn_silu_bwd_apply(P(dy), dy.ld, 0, P(z), z.ld, 0, P(mean), P(invstd), P(gamma), P(beta), P(part), 0, None, None,
@@ -68,7 +72,7 @@ def main():
         t_s = timeit(lambda: lib.cdet_bn_bwd_sums(P(part), nb, Cn, P(part) + nb * 2 * Cn * 4, P(dg), P(db), 1, st), a.reps)
         by = M * Cn * 2
         print(f"{f'{N}x{H}x{W}x{Cn} (x{cnt})':>22s} {t_f*1e3:8.1f} {2*by/t_f/1e6:6.0f} {t_r*1e3:9.1f} {2*by/t_r/1e6:6.0f} {t_a*1e3:8.1f} "
-              f"{3*by/t_a/1e6:6.0f} {t_fin*1e3:11.1f} {t_s*1e3:8.1f}")
+              f"{3*by/t_a/1e6:6.0f} {t_fin*1e3:11.1f} {t_s*1e3:8.1f}   fwd->slice {t_fs*1e3:6.1f} us {2*by/t_fs/1e6:6.0f}")
         for k, t in (("fwd", t_f), ("reduce", t_r), ("apply", t_a), ("finalize", t_fin), ("sums", t_s)):
             tot[k] += t * cnt
     print("per task pass (ms): " + "  ".join(f"{k} {v:.2f}" for k, v in tot.items()))
