@@ -82,7 +82,7 @@ static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); 
 
 // tap-resident weight gradient (conv_wgrad_halo.hip), used by cdet_conv2d_wgrad (conv_wgrad.hip) for the stride-1 3x3 layers
 struct WgradHaloPlan {
-    int S, chunk, Kp, Cd_pad, n_cblk, n_iblk, XH, nci, narrow;
+    int S, chunk, Kp, Cd_pad, n_cblk, n_iblk, XH, nci, narrow, patch;
     size_t lds;
 };
 bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items = 1);

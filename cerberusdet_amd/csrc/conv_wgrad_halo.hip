@@ -43,6 +43,8 @@ struct WHArgs {
     int XH;  // halo rows per stage (multiple of 32)
     const cdet_wgrad_item* items;  // grouped launch: per-layer tensors (nullptr: the single layer above)
     unsigned magicW, magicH;  // 2^32 / W + 1, 2^32 / H + 1: exact quotients by v_mul_hi for every pixel index of the path
+                              // (PATCH form: 2^32 / tiles_x + 1 and 2^32 / tiles_per_img + 1, applied to the patch index)
+    int tiles_x, tiles_per_img;  // PATCH form: 8 x 16 pixel patches per image row / per image
     unsigned x_bytes, dy_bytes;
 };
 
@@ -55,11 +57,23 @@ constexpr int WH_ZERO = 4608;        // zero region: 512 lane bytes + the larges
 
 // NARROW (Cout <= 96, NCI = 2): the tile is 80 couts x 32 cins; the factor two the cout halves would take goes to the pixels -- four
 // groups of two waves, each reducing 32 of the stage's 128 pixels, summed through LDS in two levels at the end.
-template <int DT, int NCI, bool NARROW = false>
+// PATCH (NARROW only; H % 8 == 0, W % 16 == 0 -- the 160 x 160 and 80 x 80 maps): a stage is an 8 x 16 pixel PATCH instead of 128 consecutive
+// pixels. On a 160-wide map a run of 128 pixels drags 128 + 2 W + 2 = 450 halo rows along (3.5 rows of X per pixel), the patch 10 x 18 = 180; with
+// the dY images packed for 80 couts (3 cout pairs instead of 5) a stage shrinks from 70 KB to 36 KB of LDS-DMA traffic, and FOUR stage buffers fit
+// where two did: the DMA of stage st + 3 is issued during stage st and waited for with a counted vmcnt. Measured on the six grouped 160 x 160
+// 80 -> 80 layers (profiles/r04_wgrad_patch.txt): the linear form's stage loop is bound by its DMA stream (0.89 ms with the MFMAs removed, 0.47 ms
+// with the DMA removed, 0.94 ms complete). The halo is zero-filled by the DMA's out-of-range offsets, so the tap masks disappear: tap (ky, kx) of
+// patch row r is 16 consecutive halo rows from (r + ky) * 18 + kx.
+template <int DT, int NCI, bool NARROW = false, bool PATCH = false>
 __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     static_assert(!NARROW || NCI == 2, "the 80-cout tile exists for the 32-cin form only");
+    static_assert(!PATCH || NARROW, "the patch form exists for the 80-cout tile only");
     constexpr int KSL = NARROW ? 1 : (NCI == 4 ? 4 : 2);  // 32-pixel reduction steps a wave runs per stage
     constexpr int CO = NARROW ? 80 : 160;                  // couts of the tile
+    constexpr int NBUF = PATCH ? 4 : 2;                    // stage buffers
+    constexpr int DYBLK = PATCH ? 3072 : 5120;             // bytes of the dY images of one 16-pixel block (3 / 5 cout pairs)
+    constexpr int DYB = PATCH ? 8 * DYBLK : WH_DYB;        // dY bytes per stage
+    constexpr int HP = 18;                                 // PATCH: halo pitch (16 + 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -101,9 +115,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     const int nst = pbeg < pend ? (pend - pbeg + WH_P - 1) / WH_P : 0;
     const int W = a.W;
     const int XP = a.XH * 32;  // bytes of one 16-cin plane
-    const int STAGE = WH_DYB + NCI * XP;
-    const int ZOFF = 2 * STAGE;
-    for (int i = t; i < WH_ZERO / 4; i += 512) reinterpret_cast<uint32_t*>(smem + ZOFF)[i] = 0u;
+    const int STAGE = DYB + NCI * XP;
+    const int ZOFF = NBUF * STAGE;
+    if (!PATCH)
+        for (int i = t; i < WH_ZERO / 4; i += 512) reinterpret_cast<uint32_t*>(smem + ZOFF)[i] = 0u;
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xptr, 0, (int)x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)dyptr, 0, (int)a.dy_bytes, 0x00020000);
@@ -118,7 +133,43 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     const int yco_l = (lane >> 5) * 16 + (lane & 1) * 8;
     const unsigned ydl = (unsigned)(((lane >> 1) & 15) * ldyB + yco_l * 2);
     const unsigned xdl = (unsigned)((lane >> 1) * ldxB + (lane & 1) * 16);
+    // PATCH: the stage's patch (pid = first patch of the split + st) -> image n, origin (y0, x0); idx 0..2: dY images di = wave + 8 idx < 24 =
+    // (patch row di / 3, cout pair di % 3), idx 3..4: X pieces xi = wave + 8 (idx - 3) < 12 = (32-row block xi / 2, plane xi & 1) of the 10 x 18 halo
+    auto issue_dma_patch = [&](int idx, int st, int buf) {
+        if (st >= nst) return;
+        if ((WH_ABL & 1) && st > 0) return;
+        unsigned char* base = smem + buf * STAGE;
+        const unsigned pid = (unsigned)(pbeg / WH_P + st);
+        // (2^32 / 1 + 1 does not fit the magic word: a divisor of one is its own case)
+        const unsigned n = a.tiles_per_img == 1 ? pid : __umulhi(pid, a.magicH);
+        const unsigned r = pid - n * (unsigned)a.tiles_per_img;
+        const unsigned ty = a.tiles_x == 1 ? r : __umulhi(r, a.magicW);
+        const int y0 = (int)ty * 8, x0 = (int)(r - ty * (unsigned)a.tiles_x) * 16;
+        if (idx < 3) {
+            const int di = wave + 8 * idx;  // wave-uniform
+            const int pb = di / 3, cp = di - pb * 3;
+            const int cobase = c0 + cp * 32;
+            const unsigned sc = (unsigned)((((int)n * a.H + y0 + pb) * W + x0) * ldyB + (a.dy_coff + cobase) * 2);
+            const unsigned v = yco_l < a.Cd - cobase ? ydl + sc : WH_SENT;
+            wh_dma16(rs_y, v, base + pb * DYBLK + cp * 1024);
+        } else {
+            const int xi = wave + 8 * (idx - 3);  // wave-uniform
+            if (xi < NCI * 6) {
+                const int blk = xi / NCI, pl = xi - blk * NCI;
+                const int hr = blk * 32 + (lane >> 1);
+                const int hy = (hr * 3641) >> 16, hx = hr - hy * HP;  // hr / 18 for hr < 192
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bool ok = hr < 10 * HP && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)W && i0 + pl * 16 < a.Cs;
+                const unsigned off = (unsigned)((((int)n * a.H + y) * W + x) * ldxB + (src_coff + i0 + pl * 16) * 2 + (lane & 1) * 16);
+                wh_dma16(rs_x, ok ? off : WH_SENT, base + DYB + pl * XP + blk * 1024);
+            }
+        }
+    };
     auto issue_dma = [&](int idx, int st, int buf) {  // idx 0..4: dY images, 5..9: X pieces, of stage st -> buffer buf
+        if (PATCH) {
+            if (idx < 5) issue_dma_patch(idx, st, buf);
+            return;
+        }
         if (st >= nst) return;
         if ((WH_ABL & 1) && st > 0) return;
         unsigned char* base = smem + buf * STAGE;
@@ -147,8 +198,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     //   dY: K-step ks (32 px), 16-pixel block 2*ks + hh, cout group cog = wco*5 + j -> image (2*ks + hh)*5 + cog/2, half cog&1
     //       = byte (2*ks + hh)*5120 + cog*512
     //   X : halo row of pixel px and tap (ky, kx) = px + ky*W + kx, plane wci
-    const int yb0 = wco * 2560 + lane * 8 + (prow >> 5) * 10240;
-    const int xb0 = WH_DYB + wci * XP + prow * 32 + lane * 8;
+    const int yb0 = wco * 2560 + lane * 8 + (prow >> 5) * (2 * DYBLK);
+    // (PATCH: the wave's 32 pixels are patch rows 2 g, 2 g + 1 with g = prow / 32: halo rows from 2 g * 18)
+    const int xb0 = DYB + wci * XP + (PATCH ? (prow >> 4) * HP : prow) * 32 + lane * 8;
     const int zaddr = ZOFF + lane * 8;
     const int pix_l = prow + (lane >> 2);  // the lane's pixel inside a 16-pixel block, + the first pixel row of the wave's share
 
@@ -158,20 +210,36 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[tp][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stage 0
+    // ---- prologue: stage 0 (PATCH: stages 0 .. 2; every wave issues the same number of DMA instructions per stage -- 5 for waves 0 - 3, 4 for
+    //      waves 4 - 7 --, so "all but the last two stages' instructions have landed" is a constant vmcnt)
 #pragma unroll
     for (int i = 0; i < 10; ++i) issue_dma(i, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PATCH) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) issue_dma(i, 1, 1);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) issue_dma(i, 2, 2);
+        if (nst > 2) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
+        const int cur = PATCH ? (st & 3) : (st & 1);
+        const int nxt = PATCH ? ((st + 3) & 3) : (cur ^ 1);   // buffer of the stage whose DMA is issued during this one
+        const int ahead = PATCH ? 3 : 1;
         int vy = yb0 + cur * STAGE;
         int vx[3];
         vx[0] = xb0 + cur * STAGE;
-        vx[1] = vx[0] + W * 32;
-        vx[2] = vx[1] + W * 32;
+        vx[1] = vx[0] + (PATCH ? HP : W) * 32;
+        vx[2] = vx[1] + (PATCH ? HP : W) * 32;
         asm volatile("" : "+v"(vy), "+v"(vx[0]), "+v"(vx[1]), "+v"(vx[2]));
         const int pst = pbeg + st * WH_P + pix_l;
         wh_static_for(std::make_integer_sequence<int, KSL>{}, [&](auto KS) {
@@ -179,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             // validity of the lane's two pixels of this step: top / bottom / left / right neighbours inside the image
             uint64_t mt[2], mb[2], ml[2], mr[2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < (PATCH ? 0 : 2); ++hh) {
                 const unsigned p = (unsigned)(pst + ksl * 32 + hh * 16);
                 const unsigned r = __umulhi(p, a.magicW);
                 const int xx = (int)(p - r * (unsigned)W);
@@ -192,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             auto x_addr = [&](auto TP, int hh) -> int {
                 constexpr int tp = decltype(TP)::value;
                 constexpr int ky = tp / 3, kx = tp % 3;
-                if (tp == 4) return vx[1];
+                if (tp == 4 || PATCH) return vx[ky];
                 uint64_t m = ky == 0 ? mt[hh] : (ky == 2 ? mb[hh] : ~0ull);
                 if (kx == 0) m = ky == 1 ? ml[hh] : (m & ml[hh]);
                 if (kx == 2) m = ky == 1 ? mr[hh] : (m & mr[hh]);
@@ -203,14 +271,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             wh_static_for(std::make_integer_sequence<int, 5>{}, [&](auto J) {
                 constexpr int j = decltype(J)::value;
                 if ((WH_ABL & 16) && (st > 0 || ksl > 0)) return;
-                blo[j] = wh_tr<(2 * ksl) * 5120 + j * 512>(vy);
-                bhi[j] = wh_tr<(2 * ksl + 1) * 5120 + j * 512>(vy);
+                blo[j] = wh_tr<(2 * ksl) * DYBLK + j * 512>(vy);
+                bhi[j] = wh_tr<(2 * ksl + 1) * DYBLK + j * 512>(vy);
             });
             u32x2 alo[2], ahi[2];
             {
                 const int a0 = x_addr(std::integral_constant<int, 0>{}, 0), a1 = x_addr(std::integral_constant<int, 0>{}, 1);
                 alo[0] = wh_tr<(ksl * 32) * 32>(a0);
-                ahi[0] = wh_tr<(ksl * 32 + 16) * 32>(a1);
+                ahi[0] = wh_tr<(ksl * 32 + (PATCH ? HP : 16)) * 32>(a1);
             }
             wh_static_for(std::make_integer_sequence<int, 9>{}, [&](auto TP) {
                 constexpr int tp = decltype(TP)::value;
@@ -220,11 +288,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
                     const int a0 = x_addr(std::integral_constant<int, tp + 1>{}, 0);
                     const int a1 = x_addr(std::integral_constant<int, tp + 1>{}, 1);
                     alo[ns] = wh_tr<(ksl * 32 + kx) * 32>(a0);
-                    ahi[ns] = wh_tr<(ksl * 32 + 16 + kx) * 32>(a1);
+                    ahi[ns] = wh_tr<(ksl * 32 + (PATCH ? HP : 16) + kx) * 32>(a1);
                 }
                 // the next stage's operands, one DMA instruction per tap of the first two steps
-                if constexpr (ksl == 0) issue_dma(tp, st + 1, cur ^ 1);
-                if constexpr (ksl == 1 && tp == 0) issue_dma(9, st + 1, cur ^ 1);
+                if constexpr (ksl == 0) issue_dma(tp, st + ahead, nxt);
+                if constexpr (ksl == 1 && tp == 0) issue_dma(9, st + ahead, nxt);
                 if constexpr (tp == 0) wh_wait_b<2>(blo, bhi, alo[0], ahi[0]);
                 else if constexpr (tp + 1 < 9) wh_wait<2>(alo[cs], ahi[cs]);
                 else wh_wait<0>(alo[cs], ahi[cs]);
@@ -237,7 +305,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
                 }
             });
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next stage's operands must have landed (PATCH: everything but the two stages issued last, while a third one was issued in this stage)
+        if (PATCH && st + 3 < nst) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!(WH_ABL & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -445,8 +519,12 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
         if (force_nci == 0) return false;
     }
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
-    const int XH = (WH_P + 2 * (d->Ws + 1) + 31) / 32 * 32;
-    auto lds_of = [&](int nci) { return 2 * (size_t)(WH_DYB + nci * XH * 32) + WH_ZERO; };
+    // 80-cout tile on maps that split into 8 x 16 patches: the patch form (four stage buffers; CDET_WGRAD_PATCH=0 keeps the linear form -- the
+    // tests compare the two)
+    bool patch = narrow && d->Hs % 8 == 0 && d->Ws % 16 == 0;
+    if (const char* e = getenv("CDET_WGRAD_PATCH")) patch = patch && atoi(e) != 0;
+    const int XH = patch ? 192 : (WH_P + 2 * (d->Ws + 1) + 31) / 32 * 32;
+    auto lds_of = [&](int nci) { return patch ? 4 * (size_t)(8 * 3072 + nci * XH * 32) : 2 * (size_t)(WH_DYB + nci * XH * 32) + WH_ZERO; };
     // The 64-cin tile halves the L2 -> LDS traffic per flop and needs no half-sum (main loop 4 % faster on 40x40x320), but every
     // workgroup then writes a slab twice the size: with one workgroup per CU the split-K workspace is 256 x (tile bytes) whatever
     // the layer, 47 MB at 32 cins against 94 MB -- measured 0.096 vs 0.105 ms per launch (profiles/r02_wgrad_kstats.txt). The
@@ -454,7 +532,7 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     int nci = 2;
     if (!narrow && force_nci == 4 && d->Cs % 64 == 0 && lds_of(4) <= 160 * 1024) nci = 4;
     if (lds_of(nci) > 160 * 1024) return false;
-    if (nci * (XH / 32) > (narrow ? 32 : 40)) return false;  // 5 X pieces per wave (4 for the 80-cout form: one reduction step per stage)
+    if (!patch && nci * (XH / 32) > (narrow ? 32 : 40)) return false;  // 5 X pieces per wave (4 for the 80-cout form: one reduction step per stage)
     if (M * d->src_ld * 2 >= 0xC0000000ll || M * d->dst_ld * 2 >= 0xC0000000ll) return false;
     if (M >= (1 << 24)) return false;  // the magic-multiply quotients are exact far beyond this; keep a wide margin
     const int co_tile = narrow ? 80 : 160;
@@ -478,18 +556,19 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     out->XH = XH;
     out->nci = nci;
     out->narrow = narrow ? 1 : 0;
+    out->patch = patch ? 1 : 0;
     out->lds = lds_of(nci);
     return true;
 }
 
-template <int DT, int NCI, bool NARROW = false>
+template <int DT, int NCI, bool NARROW = false, bool PATCH = false>
 static void wgrad_halo_launch_t(const WHArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<DT, NCI, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<DT, NCI, NARROW, PATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad_halo_kernel<DT, NCI, NARROW>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((wgrad_halo_kernel<DT, NCI, NARROW, PATCH>), dim3(grid), dim3(512), lds, s, a);
 }
 
 int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const void* x, const void* dy, float* ws, hipStream_t s,
@@ -503,15 +582,24 @@ int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const voi
     a.Kp = p.Kp; a.Cd_pad = p.Cd_pad; a.chunk = p.chunk; a.S = p.S; a.n_cblk = p.n_cblk; a.n_iblk = p.n_iblk; a.XH = p.XH;
     a.magicW = (unsigned)((1ull << 32) / (unsigned)a.W + 1);
     a.magicH = (unsigned)((1ull << 32) / (unsigned)a.H + 1);
+    a.tiles_x = a.tiles_per_img = 0;
+    if (p.patch) {
+        a.tiles_x = a.W / 16;
+        a.tiles_per_img = (a.H / 8) * a.tiles_x;
+        a.magicW = (unsigned)((1ull << 32) / (unsigned)a.tiles_x + 1);
+        a.magicH = (unsigned)((1ull << 32) / (unsigned)a.tiles_per_img + 1);
+    }
     a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
     a.dy_bytes = (unsigned)((int64_t)a.M * d->dst_ld * 2);
     const int grid = (items_dev ? n_items : 1) * p.S * p.n_cblk * p.n_iblk;
     if (d->dtype == CDET_BF16) {
-        if (p.narrow) wgrad_halo_launch_t<CDET_BF16, 2, true>(a, grid, p.lds, s);
+        if (p.patch) wgrad_halo_launch_t<CDET_BF16, 2, true, true>(a, grid, p.lds, s);
+        else if (p.narrow) wgrad_halo_launch_t<CDET_BF16, 2, true>(a, grid, p.lds, s);
         else if (p.nci == 4) wgrad_halo_launch_t<CDET_BF16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_BF16, 2>(a, grid, p.lds, s);
     } else {
-        if (p.narrow) wgrad_halo_launch_t<CDET_F16, 2, true>(a, grid, p.lds, s);
+        if (p.patch) wgrad_halo_launch_t<CDET_F16, 2, true, true>(a, grid, p.lds, s);
+        else if (p.narrow) wgrad_halo_launch_t<CDET_F16, 2, true>(a, grid, p.lds, s);
         else if (p.nci == 4) wgrad_halo_launch_t<CDET_F16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_F16, 2>(a, grid, p.lds, s);
     }
@@ -558,6 +646,7 @@ bool wgrad_gemm_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     out->XH = 0;
     out->nci = 2;
     out->narrow = 0;
+    out->patch = 0;
     out->lds = 2 * (size_t)WG_STAGE;
     return true;
 }

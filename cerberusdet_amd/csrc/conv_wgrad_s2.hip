@@ -282,6 +282,7 @@ bool wgrad_s2_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     out->XH = 0;
     out->nci = 2;
     out->narrow = 0;
+    out->patch = 0;
     out->lds = 2 * (size_t)S2_STAGE;
     return true;
 }

@@ -185,6 +185,58 @@ def test_conv_wgrad_tap_resident(case, tile, monkeypatch):
     _close(dw, 2 * w.grad, 2e-3, 4e-3 * float(w.grad.abs().max()))
 
 
+WGRAD_PATCH_CASES = [
+    # N, H, W, Cin, Cout, dtype -- 80-cout tile on maps of whole 8 x 16 patches: the patch form of csrc/conv_wgrad_halo.hip (four stage buffers)
+    (1, 32, 160, 80, 80, torch.bfloat16),    # the C2f 160 x 160 Bottleneck rows: 40 patches, Cin 80 (the last 32-cin tile half empty)
+    (2, 16, 48, 80, 80, torch.bfloat16),     # 12 patches over two images
+    (1, 80, 80, 320, 80, torch.float16),     # head box-branch stem at 80 x 80: 10 cin tiles, fp16
+    (3, 8, 16, 96, 72, torch.bfloat16),      # ONE patch per image, three stages in all: the short-pipeline waits (nst <= 3)
+    (1, 24, 32, 32, 96, torch.bfloat16),     # Cout 96: two 80-cout blocks, the second 16 wide; 6 patches
+    (5, 8, 32, 64, 64, torch.bfloat16),      # 10 patches, Cout 64
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PATCH_CASES)
+def test_conv_wgrad_patch_form(case, monkeypatch):
+    """The 8 x 16 patch form of the narrow tap-resident weight gradient (default where the map splits into whole patches) against autograd, against
+    the linear 128-pixel-run form of the same kernel (CDET_WGRAD_PATCH=0) and against the im2col kernel: same bf16 products, fp32 sums in another
+    order. Source and gradient are channel slices of wider buffers; the accumulate variant doubles the result."""
+    ops = _ops()
+    N, H, W, Ci, Co, dtype = case
+    Cop = (Co + 7) // 8 * 8
+    g = torch.Generator().manual_seed(9)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype).requires_grad_(True)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = _rt(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    xb = torch.randn(N, H, W, Ci + 24, generator=g).to(dtype).to(DEV)
+    xb[..., 16:16 + Ci] = x.detach().permute(0, 2, 3, 1).to(dtype).to(DEV)
+    xv = ops.View(xb, 16, Ci)
+    yb = torch.randn(N, H, W, Cop + 8, generator=g).to(dtype).to(DEV)
+    yb[..., 8:8 + Cop] = 0
+    yb[..., 8:8 + Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
+    dyv = ops.View(yb, 8, Cop)
+    scale = float(w.grad.abs().max())
+    out = {}
+    for name, env in (("patch", {}), ("linear", {"CDET_WGRAD_PATCH": "0"}), ("im2col", {"CDET_WGRAD_HALO": "0"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
+        ops.conv2d_wgrad(xv, dyv, dw, 3, 1)
+        torch.cuda.synchronize()
+        out[name] = dw
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    _close(out["patch"], w.grad, 2e-3, 2e-3 * scale)
+    _close(out["patch"], out["linear"], 1e-4, 1e-4 * scale)
+    _close(out["patch"], out["im2col"], 1e-4, 1e-4 * scale)
+    again = out["patch"].clone()
+    ops.conv2d_wgrad(xv, dyv, again, 3, 1, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(again, 2 * out["patch"])  # the same launch twice: identical sums, g + g exact
+
+
 @pytest.mark.parametrize("case", [(2, 20, 20, 256, 160, torch.bfloat16), (1, 24, 40, 800, 320, torch.bfloat16), (3, 16, 16, 288, 136, torch.float16),
                                   (1, 13, 11, 1600, 200, torch.bfloat16), (1, 20, 20, 576, 640, torch.bfloat16)])
 def test_conv_wgrad_1x1_transpose_read_kernel(case, monkeypatch):
