@@ -57,23 +57,28 @@ constexpr int WH_ZERO = 4608;        // zero region: 512 lane bytes + the larges
 
 // NARROW (Cout <= 96, NCI = 2): the tile is 80 couts x 32 cins; the factor two the cout halves would take goes to the pixels -- four
 // groups of two waves, each reducing 32 of the stage's 128 pixels, summed through LDS in two levels at the end.
-// PATCH (NARROW only; H % 8 == 0, W % 16 == 0 -- the 160 x 160 and 80 x 80 maps): a stage is an 8 x 16 pixel PATCH instead of 128 consecutive
+// PATCH (NCI = 2 forms; H % 8 == 0, W % 16 == 0 -- the 160 x 160 and 80 x 80 maps): a stage is an 8 x 16 pixel PATCH instead of 128 consecutive
 // pixels. On a 160-wide map a run of 128 pixels drags 128 + 2 W + 2 = 450 halo rows along (3.5 rows of X per pixel), the patch 10 x 18 = 180; with
 // the dY images packed for 80 couts (3 cout pairs instead of 5) a stage shrinks from 70 KB to 36 KB of LDS-DMA traffic, and FOUR stage buffers fit
 // where two did: the DMA of stage st + 3 is issued during stage st and waited for with a counted vmcnt. Measured on the six grouped 160 x 160
 // 80 -> 80 layers (profiles/r04_wgrad_patch.txt): the linear form's stage loop is bound by its DMA stream (0.89 ms with the MFMAs removed, 0.47 ms
 // with the DMA removed, 0.94 ms complete). The halo is zero-filled by the DMA's out-of-range offsets, so the tap masks disappear: tap (ky, kx) of
-// patch row r is 16 consecutive halo rows from (r + ky) * 18 + kx.
+// patch row r is 16 consecutive halo rows from (r + ky) * 18 + kx. The 160-cout tile takes the same form with THREE stage buffers (40 KB of dY +
+// 12 KB of halo per stage; the linear form's two buffers + zero region leave no room for a third).
 template <int DT, int NCI, bool NARROW = false, bool PATCH = false>
 __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     static_assert(!NARROW || NCI == 2, "the 80-cout tile exists for the 32-cin form only");
-    static_assert(!PATCH || NARROW, "the patch form exists for the 80-cout tile only");
+    static_assert(!PATCH || NCI == 2, "the patch form exists for the 32-cin tiles only");
     constexpr int KSL = NARROW ? 1 : (NCI == 4 ? 4 : 2);  // 32-pixel reduction steps a wave runs per stage
     constexpr int CO = NARROW ? 80 : 160;                  // couts of the tile
-    constexpr int NBUF = PATCH ? 4 : 2;                    // stage buffers
-    constexpr int DYBLK = PATCH ? 3072 : 5120;             // bytes of the dY images of one 16-pixel block (3 / 5 cout pairs)
-    constexpr int DYB = PATCH ? 8 * DYBLK : WH_DYB;        // dY bytes per stage
+    constexpr int NBUF = PATCH ? (NARROW ? 4 : 3) : 2;     // stage buffers
+    constexpr int NPAIR = PATCH && NARROW ? 3 : 5;         // 32-cout pairs of dY images per 16-pixel block
+    constexpr int DYBLK = NPAIR * 1024;                    // bytes of the dY images of one 16-pixel block
+    constexpr int DYB = 8 * DYBLK;                         // dY bytes per stage (= WH_DYB for five pairs)
     constexpr int HP = 18;                                 // PATCH: halo pitch (16 + 2)
+    constexpr int NDY = NPAIR;                             // PATCH: dY DMA instructions per wave and stage (8 NPAIR images over 8 waves)
+    constexpr int KW = NDY + 1;                            // PATCH: DMA instructions per stage of waves 4 - 7 (one X piece); waves 0 - 3: + 1
+    constexpr int AHEAD = NBUF - 1;                        // PATCH: stages the DMA runs ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -133,8 +138,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     const int yco_l = (lane >> 5) * 16 + (lane & 1) * 8;
     const unsigned ydl = (unsigned)(((lane >> 1) & 15) * ldyB + yco_l * 2);
     const unsigned xdl = (unsigned)((lane >> 1) * ldxB + (lane & 1) * 16);
-    // PATCH: the stage's patch (pid = first patch of the split + st) -> image n, origin (y0, x0); idx 0..2: dY images di = wave + 8 idx < 24 =
-    // (patch row di / 3, cout pair di % 3), idx 3..4: X pieces xi = wave + 8 (idx - 3) < 12 = (32-row block xi / 2, plane xi & 1) of the 10 x 18 halo
+    // PATCH: the stage's patch (pid = first patch of the split + st) -> image n, origin (y0, x0); idx 0..NPAIR-1: dY images di = wave + 8 idx =
+    // (patch row di / NPAIR, cout pair di % NPAIR), idx NPAIR, NPAIR+1: X pieces xi = wave + 8 (idx - NPAIR) < 12 = (32-row block xi / 2, plane xi & 1)
+    // of the 10 x 18 halo
     auto issue_dma_patch = [&](int idx, int st, int buf) {
         if (st >= nst) return;
         if ((WH_ABL & 1) && st > 0) return;
@@ -145,15 +151,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
         const unsigned r = pid - n * (unsigned)a.tiles_per_img;
         const unsigned ty = a.tiles_x == 1 ? r : __umulhi(r, a.magicW);
         const int y0 = (int)ty * 8, x0 = (int)(r - ty * (unsigned)a.tiles_x) * 16;
-        if (idx < 3) {
+        if (idx < NDY) {
             const int di = wave + 8 * idx;  // wave-uniform
-            const int pb = di / 3, cp = di - pb * 3;
+            const int pb = di / NPAIR, cp = di - pb * NPAIR;
             const int cobase = c0 + cp * 32;
             const unsigned sc = (unsigned)((((int)n * a.H + y0 + pb) * W + x0) * ldyB + (a.dy_coff + cobase) * 2);
             const unsigned v = yco_l < a.Cd - cobase ? ydl + sc : WH_SENT;
             wh_dma16(rs_y, v, base + pb * DYBLK + cp * 1024);
         } else {
-            const int xi = wave + 8 * (idx - 3);  // wave-uniform
+            const int xi = wave + 8 * (idx - NDY);  // wave-uniform
             if (xi < NCI * 6) {
                 const int blk = xi / NCI, pl = xi - blk * NCI;
                 const int hr = blk * 32 + (lane >> 1);
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     };
     auto issue_dma = [&](int idx, int st, int buf) {  // idx 0..4: dY images, 5..9: X pieces, of stage st -> buffer buf
         if (PATCH) {
-            if (idx < 5) issue_dma_patch(idx, st, buf);
+            if (idx < NDY + 2) issue_dma_patch(idx, st, buf);
             return;
         }
         if (st >= nst) return;
@@ -216,12 +222,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     for (int i = 0; i < 10; ++i) issue_dma(i, 0, 0);
     if (PATCH) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) issue_dma(i, 1, 1);
+        for (int b = 1; b < AHEAD; ++b)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) issue_dma(i, 2, 2);
-        if (nst > 2) {
-            if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            for (int i = 0; i < NDY + 2; ++i) issue_dma(i, b, b);
+        if (nst >= AHEAD) {  // AHEAD stages in flight: all but the last AHEAD - 1 of them must have landed
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * (KW + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * KW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -232,9 +238,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
     for (int st = 0; st < nst; ++st) {
-        const int cur = PATCH ? (st & 3) : (st & 1);
-        const int nxt = PATCH ? ((st + 3) & 3) : (cur ^ 1);   // buffer of the stage whose DMA is issued during this one
-        const int ahead = PATCH ? 3 : 1;
+        const int cur = PATCH ? st % NBUF : (st & 1);
+        const int nxt = PATCH ? (st + AHEAD) % NBUF : (cur ^ 1);   // buffer of the stage whose DMA is issued during this one
+        const int ahead = PATCH ? AHEAD : 1;
         int vy = yb0 + cur * STAGE;
         int vx[3];
         vx[0] = xb0 + cur * STAGE;
@@ -277,8 +283,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
             u32x2 alo[2], ahi[2];
             {
                 const int a0 = x_addr(std::integral_constant<int, 0>{}, 0), a1 = x_addr(std::integral_constant<int, 0>{}, 1);
-                alo[0] = wh_tr<(ksl * 32) * 32>(a0);
-                ahi[0] = wh_tr<(ksl * 32 + (PATCH ? HP : 16)) * 32>(a1);
+                alo[0] = wh_tr<(ksl * (PATCH ? 2 * HP : 32)) * 32>(a0);
+                ahi[0] = wh_tr<(ksl * (PATCH ? 2 * HP : 32) + (PATCH ? HP : 16)) * 32>(a1);
             }
             wh_static_for(std::make_integer_sequence<int, 9>{}, [&](auto TP) {
                 constexpr int tp = decltype(TP)::value;
@@ -287,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
                     constexpr int kx = (tp + 1) % 3;
                     const int a0 = x_addr(std::integral_constant<int, tp + 1>{}, 0);
                     const int a1 = x_addr(std::integral_constant<int, tp + 1>{}, 1);
-                    alo[ns] = wh_tr<(ksl * 32 + kx) * 32>(a0);
-                    ahi[ns] = wh_tr<(ksl * 32 + (PATCH ? HP : 16) + kx) * 32>(a1);
+                    alo[ns] = wh_tr<(ksl * (PATCH ? 2 * HP : 32) + kx) * 32>(a0);
+                    ahi[ns] = wh_tr<(ksl * (PATCH ? 2 * HP : 32) + (PATCH ? HP : 16) + kx) * 32>(a1);
                 }
                 // the next stage's operands, one DMA instruction per tap of the first two steps
                 if constexpr (ksl == 0) issue_dma(tp, st + ahead, nxt);
@@ -305,10 +311,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_halo_kernel(const WHArgs a) {
                 }
             });
         });
-        // the next stage's operands must have landed (PATCH: everything but the two stages issued last, while a third one was issued in this stage)
-        if (PATCH && st + 3 < nst) {
-            if (wave < 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // the next stage's operands must have landed (PATCH: everything but the AHEAD - 1 stages issued last, when one was issued in this stage)
+        if (PATCH && st + AHEAD < nst) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * (KW + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * KW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -519,12 +525,15 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
         if (force_nci == 0) return false;
     }
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
-    // 80-cout tile on maps that split into 8 x 16 patches: the patch form (four stage buffers; CDET_WGRAD_PATCH=0 keeps the linear form -- the
-    // tests compare the two)
-    bool patch = narrow && d->Hs % 8 == 0 && d->Ws % 16 == 0;
-    if (const char* e = getenv("CDET_WGRAD_PATCH")) patch = patch && atoi(e) != 0;
+    // maps that split into 8 x 16 patches: the patch form of the 32-cin tiles (four / three stage buffers; CDET_WGRAD_PATCH=0 keeps the linear
+    // form -- the tests compare the two; 1: the 80-cout tile only)
+    bool patch = force_nci != 4 && d->Hs % 8 == 0 && d->Ws % 16 == 0;
+    if (const char* e = getenv("CDET_WGRAD_PATCH")) patch = patch && atoi(e) != 0 && (narrow || atoi(e) != 1);
     const int XH = patch ? 192 : (WH_P + 2 * (d->Ws + 1) + 31) / 32 * 32;
-    auto lds_of = [&](int nci) { return patch ? 4 * (size_t)(8 * 3072 + nci * XH * 32) : 2 * (size_t)(WH_DYB + nci * XH * 32) + WH_ZERO; };
+    auto lds_of = [&](int nci) {
+        return patch ? (narrow ? 4 * (size_t)(8 * 3072 + nci * XH * 32) : 3 * (size_t)(WH_DYB + nci * XH * 32))
+                     : 2 * (size_t)(WH_DYB + nci * XH * 32) + WH_ZERO;
+    };
     // The 64-cin tile halves the L2 -> LDS traffic per flop and needs no half-sum (main loop 4 % faster on 40x40x320), but every
     // workgroup then writes a slab twice the size: with one workgroup per CU the split-K workspace is 256 x (tile bytes) whatever
     // the layer, 47 MB at 32 cins against 94 MB -- measured 0.096 vs 0.105 ms per launch (profiles/r02_wgrad_kstats.txt). The
@@ -593,12 +602,14 @@ int wgrad_halo_launch(const cdet_conv_desc* d, const WgradHaloPlan& p, const voi
     a.dy_bytes = (unsigned)((int64_t)a.M * d->dst_ld * 2);
     const int grid = (items_dev ? n_items : 1) * p.S * p.n_cblk * p.n_iblk;
     if (d->dtype == CDET_BF16) {
-        if (p.patch) wgrad_halo_launch_t<CDET_BF16, 2, true, true>(a, grid, p.lds, s);
+        if (p.patch && p.narrow) wgrad_halo_launch_t<CDET_BF16, 2, true, true>(a, grid, p.lds, s);
+        else if (p.patch) wgrad_halo_launch_t<CDET_BF16, 2, false, true>(a, grid, p.lds, s);
         else if (p.narrow) wgrad_halo_launch_t<CDET_BF16, 2, true>(a, grid, p.lds, s);
         else if (p.nci == 4) wgrad_halo_launch_t<CDET_BF16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_BF16, 2>(a, grid, p.lds, s);
     } else {
-        if (p.patch) wgrad_halo_launch_t<CDET_F16, 2, true, true>(a, grid, p.lds, s);
+        if (p.patch && p.narrow) wgrad_halo_launch_t<CDET_F16, 2, true, true>(a, grid, p.lds, s);
+        else if (p.patch) wgrad_halo_launch_t<CDET_F16, 2, false, true>(a, grid, p.lds, s);
         else if (p.narrow) wgrad_halo_launch_t<CDET_F16, 2, true>(a, grid, p.lds, s);
         else if (p.nci == 4) wgrad_halo_launch_t<CDET_F16, 4>(a, grid, p.lds, s);
         else wgrad_halo_launch_t<CDET_F16, 2>(a, grid, p.lds, s);

@@ -193,6 +193,10 @@ WGRAD_PATCH_CASES = [
     (3, 8, 16, 96, 72, torch.bfloat16),      # ONE patch per image, three stages in all: the short-pipeline waits (nst <= 3)
     (1, 24, 32, 32, 96, torch.bfloat16),     # Cout 96: two 80-cout blocks, the second 16 wide; 6 patches
     (5, 8, 32, 64, 64, torch.bfloat16),      # 10 patches, Cout 64
+    (2, 16, 32, 64, 160, torch.bfloat16),    # 160-cout tile (three stage buffers): 8 patches, two cin tiles
+    (1, 40, 48, 96, 320, torch.float16),     # two cout blocks, three cin tiles, fp16, 15 patches
+    (4, 8, 16, 32, 136, torch.bfloat16),     # one patch per image, Cout not a multiple of 16
+    (1, 80, 80, 160, 160, torch.bfloat16),   # the 80 x 80 C2f Bottleneck geometry (one image)
 ]
 
 
