@@ -138,6 +138,12 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_finalize_kernel(const float
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
     double s, q;
     if (!bn_reduce_partials(stats, nblk, C, c, s, q)) return;
+    // The totals are rounded to fp32 before they are used: the SyncBatchNorm launch list all-reduces exactly these fp32 [sum, sumsq] vectors
+    // (bn_bwd_sums_kernel -> all-reduce -> this kernel with nblk = 1), so the per-GPU list and the synchronised one derive mean / invstd from the
+    // same numbers -- bit-identical at world 1, and exactly "twice the sums over twice the count" when two ranks hold the same shard
+    // (tests/test_gpu_distributed.py).
+    s = (double)(float)s;
+    q = (double)(float)q;
     const double m = s * inv_count;
     double var = q * inv_count - m * m;
     if (var < 0.0) var = 0.0;
