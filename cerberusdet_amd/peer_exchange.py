@@ -33,6 +33,13 @@ class PeerExchange:
         self.hostsync = os.environ.get("CDET_PEER_XCHG_HOSTSYNC", "0") == "1"
         self.n_calls = 0       # exchanges compiled into launch lists (collectives per iteration = those on the executed plans)
         self._bump = 256       # bytes handed out (the first 256 stay zero)
+        # One exchange at a time per rank, in host-enqueue order (what a communicator does for its collectives): an exchange kernel WAITS in the
+        # kernel for its peers, so two of them in flight on two streams of one rank could each sit in front of the kernel the other rank's
+        # counterpart is waiting for (streams can share a hardware queue) -- a cycle. Chained by an event, the exchanges of a rank run in the
+        # order the plan enqueued them, which is the same on every rank (bench.py --dry-comm asserts that order).
+        self._chain_ev = None
+        self._chain_last = None
+        self._ext = {}
         self._mine = C.c_void_p()
         self._peers = []
         with torch.cuda.device(self.device):
@@ -76,6 +83,13 @@ class PeerExchange:
 
         def call(st, t=t):  # (keeps `t` alive)
             state["epoch"] += 1
+            ext = self._ext.get(st)
+            if ext is None:
+                ext = self._ext[st] = torch.cuda.ExternalStream(st, device=self.device) if st else torch.cuda.default_stream(self.device)
+                if self._chain_ev is None:
+                    self._chain_ev = torch.cuda.Event()
+            if self._chain_last is not None and self._chain_last != st:
+                ext.wait_event(self._chain_ev)
             if hostsync:  # ranks sharing ONE GPU (tests): publish, host barrier, collect -- a spinning kernel would wait for a time-sliced peer
                 rc = lib.cdet_peer_allreduce(ptr, n, tab, world, rank, d_off, f_off, state["epoch"], err, 1, st)
                 torch.cuda.synchronize()
@@ -85,6 +99,8 @@ class PeerExchange:
                 rc = lib.cdet_peer_allreduce(ptr, n, tab, world, rank, d_off, f_off, state["epoch"], err, 0, st)
             if rc:
                 L.check(rc, "cdet_peer_allreduce")
+            self._chain_ev.record(ext)
+            self._chain_last = st
 
         call.__name__ = "peer_allreduce"
         return call
