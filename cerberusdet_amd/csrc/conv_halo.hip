@@ -475,17 +475,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             }
             tile_stats32(s16, q16, stl + (wave * 2 + 0) * HC + f * 32, stl + (wave * 2 + 1) * HC + f * 32, lane);
         }
-        __syncthreads();
-        if (t < HC && c0 + t < a.Cd) {
-            float sv = 0.f, qv = 0.f;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                sv += stl[(m * 2 + 0) * HC + t];
-                qv += stl[(m * 2 + 1) * HC + t];
-            }
-            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
-            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
-        }
+        // (the four waves' rows are added up and stored at the very end of the kernel: no block-wide barrier between a wave's statistics and its
+        //  output epilogue, and the short serial tail -- 160 threads, 8 LDS reads, 2 stores -- runs under the other waves' stores)
     }
 
     // ---- epilogue: a lane holds, per 32x32 tile, 4 runs (q) of 4 consecutive couts of ONE pixel; its partner lane (+32) holds the
@@ -604,6 +595,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();  // the next fragment overwrites the staging tile
+    }
+    if (a.stats != nullptr) {
+        const float* stl = reinterpret_cast<const float*>(smem + HZERO);
+        __syncthreads();
+        if (t < HC && c0 + t < a.Cd) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                sv += stl[(m * 2 + 0) * HC + t];
+                qv += stl[(m * 2 + 1) * HC + t];
+            }
+            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+        }
     }
 #ifdef CDET_PROFILING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
