@@ -93,9 +93,39 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __r
     }
 }
 
+// dst += src; src = 0 -- the per-task gradient buckets of the blocks several tasks share are folded into the block's bucket in task order
+__global__ __launch_bounds__(256) void accumulate_clear_kernel(float* __restrict__ dst, float* __restrict__ src, int64_t n) {
+    const int64_t n4 = n >> 2;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+        f32x4 a = reinterpret_cast<const f32x4*>(dst)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(src)[i];
+        a += b;
+        reinterpret_cast<f32x4*>(dst)[i] = a;
+        reinterpret_cast<f32x4*>(src)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        dst[i] += src[i];
+        src[i] = 0.f;
+    }
+}
+
 }  // namespace cdet
 
 using namespace cdet;
+
+extern "C" int cdet_accumulate_clear(float* dst, float* src, int64_t n, void* stream) {
+    CDET_CHECK_ARG(dst && src && n > 0, "cdet_accumulate_clear: bad arguments");
+    CDET_CHECK_ARG((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0, "cdet_accumulate_clear: 16-byte aligned buffers");
+    const int64_t n4 = n >> 2;
+    int grid = (int)((n4 + 256 * 8 - 1) / (256 * 8));
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(accumulate_clear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, void* stream) {
     CDET_CHECK_ARG(slots_dev && out && n_slots > 0, "cdet_grad_sqnorm: bad arguments");

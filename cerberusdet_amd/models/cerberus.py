@@ -398,6 +398,19 @@ class CerberusDet(nn.Module):
             self._pgrad[id(p)] = g
         return g
 
+    def _merge_alt_grads(self):
+        """Fold the per-task gradient buckets of the shared blocks (installed by trainers.Averaging; engine.Plan._alt_grad) into the blocks' own
+        buckets, in task order, on the current stream, and clear them. No-op for a model without such buckets."""
+        pairs = getattr(self, "_alt_pairs", None)
+        if not pairs:
+            return
+        from .. import _lib as L
+
+        lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream
+        for main, alt in pairs:
+            L.check(lib.cdet_accumulate_clear(main.data_ptr(), alt.data_ptr(), main.numel(), st), "cdet_accumulate_clear")
+
     def _autograd_anchor(self):
         a = getattr(self, "_anchor", None)
         if a is None or a.device != next(super().parameters()).device:
@@ -414,6 +427,7 @@ class CerberusDet(nn.Module):
                 saved[m] = st
         plans, pgrad, anchor = self._plans, self._pgrad, self.__dict__.pop("_anchor", None)
         peer = self.__dict__.pop("_peer_xchg", None)  # (IPC-mapped exchange buffers belong to the trainer's model, not to its EMA copy)
+        alt = (self.__dict__.pop("_pgrad_alt", None), self.__dict__.pop("_alt_pairs", None))  # (the trainer's per-task gradient buckets likewise)
         self._plans, self._pgrad = {}, {}
         try:
             new = self.__class__.__new__(self.__class__)
@@ -424,6 +438,8 @@ class CerberusDet(nn.Module):
             self._plans, self._pgrad = plans, pgrad
             if peer is not None:
                 self._peer_xchg = peer
+            if alt[0] is not None:
+                self._pgrad_alt, self._alt_pairs = alt
             if anchor is not None:
                 object.__setattr__(self, "_anchor", anchor)
             for m, st in saved.items():

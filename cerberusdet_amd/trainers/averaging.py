@@ -74,6 +74,7 @@ class GradReducer:
         self.handles: List = []
         self.reduced_bytes = 0
         self.skip_blocks = set()  # frozen blocks: no gradient to reduce
+        self.deferred = set()     # blocks whose bucket is complete only after the trainer folded the per-task buckets into it (reduce_deferred)
 
     def last_task(self, block_idx: int, active_tasks: Optional[Sequence[str]] = None) -> Optional[str]:
         tasks = [t for t in (active_tasks or self.task_order) if t in self.serving.get(block_idx, ())]
@@ -84,9 +85,25 @@ class GradReducer:
             return
         if self.last_task(block_idx, active_tasks) != task:
             return  # a later task of this iteration still adds to the bucket: reduce once, after local summation
+        if block_idx in self.deferred:
+            return  # the trainer reduces it after folding the tasks' buckets (reduce_deferred)
         b = self.buckets[block_idx]
         self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.reduced_bytes += b.numel() * b.element_size()
+
+    def reduce_deferred(self, active_tasks: Optional[Sequence[str]] = None, only_last_task: Optional[str] = None):
+        """All-reduce the buckets of the deferred blocks that an active task serves (only_last_task: just those this task completes)."""
+        if not self.enabled:
+            return
+        for block_idx in sorted(self.deferred):
+            if block_idx not in self.buckets or block_idx in self.skip_blocks:
+                continue
+            last = self.last_task(block_idx, active_tasks)
+            if last is None or (only_last_task is not None and last != only_last_task):
+                continue
+            b = self.buckets[block_idx]
+            self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.reduced_bytes += b.numel() * b.element_size()
 
     def wait(self):
         for h in self.handles:
@@ -151,6 +168,26 @@ class Averaging:
                 off += p.numel()
                 model._pgrad[id(p)] = g
                 p.grad = g
+        # Per-task gradient buckets on the blocks several tasks share: every serving task but the first accumulates into a bucket of its own, folded
+        # into the block's bucket in task order after the passes (model._merge_alt_grads: g_A + g_B, the sum the shared buffer held before). With
+        # them -- and the running-statistics updates of the later task deferred behind each block (engine.Plan.deferred_stats) -- the task passes of
+        # an iteration share no read-modify-write state: on two streams they overlap from the first kernel to the last instead of trailing each other
+        # through the trunk (profiles/r04_step_timeline.txt: 27 % of the iteration had two kernels in flight with the per-block event chain).
+        # CDET_TASK_DECOUPLE=0: the chained form.
+        model._pgrad_alt, model._alt_pairs = {}, []
+        self._shared_blocks = set()
+        if os.environ.get("CDET_TASK_DECOUPLE", "1") != "0" and torch.device(device).type == "cuda":
+            for bi, flat in buckets.items():
+                for j, t in enumerate(self.serving.get(bi, ())):
+                    if j == 0:
+                        continue
+                    alt = torch.zeros_like(flat)
+                    off = 0
+                    for p in model.blocks[bi].parameters():
+                        model._pgrad_alt[(id(p), t)] = alt[off:off + p.numel()].view_as(p)
+                        off += p.numel()
+                    model._alt_pairs.append((flat, alt))
+                    self._shared_blocks.add(bi)
         for k, p in names.items():
             bi = int(k.split(".")[1])
             self.slots_meta.append(dict(p=p, g=model._pgrad[id(p)], mom=torch.zeros_like(p), ema=ema_sd.get(k), group=group_of[id(p)],
@@ -166,6 +203,7 @@ class Averaging:
         self._norm_buf = torch.zeros(1 + 32 * self.n_slots, dtype=torch.float32, device=device)
         self._slot_key = None
         self.reducer = GradReducer(buckets, self.serving, self.task_ids)
+        self.reducer.deferred = set(self._shared_blocks)
         self.group_sizes = [len(g2), len(g0), len(g1)]  # optimizer.param_groups order of the reference: bias, decay, bn
 
     # ---------------------------------------------------------------------------------------------------- schedule
@@ -188,6 +226,8 @@ class Averaging:
             while True:
                 next(g)
         except StopIteration as e:
+            self.model._merge_alt_grads()  # p.grad holds the sum over the passes run so far, as with one shared buffer
+            self.reducer.reduce_deferred(active_tasks, only_last_task=task)
             return e.value
 
     def _pass_steps(self, task: str, batch: dict, n_max, active_tasks, fired):
@@ -212,13 +252,13 @@ class Averaging:
         there a per-block event chain keeps the reference's task order, so the results are bit-identical to the sequential
         schedule. What the overlap buys: one pass's latency-bound launches (BN partial-sum kernels, ~400 per pass) and the
         partly filled last round of its convolution grids run under the other pass's kernels (measured 113.8 -> 101.9 ms)."""
-        from ..engine import BlockSync, lane_stream
+        from ..engine import BlockSync, task_stream
 
         cur = torch.cuda.current_stream()
         key = tuple(active)
         cache = self.__dict__.setdefault("_stream_sync", {})
         if key not in cache:
-            streams = [lane_stream(self.device, k + 1) for k in range(len(active))]  # the process-wide lane streams (engine.py)
+            streams = [task_stream(self.device, k, len(active)) for k in range(len(active))]  # the process-wide lane streams (engine.py)
             syncs = {t: BlockSync() for t in active}
             for idx, ts in self.serving.items():
                 chain = [t for t in active if t in ts]
@@ -336,6 +376,8 @@ class Averaging:
             n_max = max(int(torch.stack(counts).max()), 1) if counts else 1
         if self.task_streams and len(active) > 1:
             self._run_tasks_on_streams(active, batches, n_max, out)
+            self.model._merge_alt_grads()
+            self.reducer.reduce_deferred(active)
         else:
             for t in active:
                 out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)

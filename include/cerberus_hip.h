@@ -443,6 +443,11 @@ int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* o
  * warm-up / schedule moves the rates (trainers/averaging.py:160-180 of the reference recomputes them every iteration). */
 int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm,
                       const float* lrs, int32_t n_groups, float momentum, float ema_decay, void* stream);
+/* dst[i] += src[i]; src[i] = 0 (fp32, 16-byte aligned). The reference accumulates the gradients of a block that several tasks share in one
+ * .grad tensor, task after task (trainers/averaging.py:140-160: backward per task, one optimizer step). Here every task but the first owns a
+ * gradient bucket of its own for those blocks, so that the task passes are independent launch streams; the buckets are folded into the block's
+ * bucket in task order before the norm / all-reduce -- the same sums (fp32 addition of the same two addends). */
+int cdet_accumulate_clear(float* dst, float* src, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SyncBatchNorm statistics exchange by peer writes (csrc/peer_exchange.hip, round 4; reference train.py:140-143 converts every BatchNorm to
