@@ -152,19 +152,24 @@ def test_two_iterations_vs_well_conditioned_reference_golden():
 
 
 @pytest.mark.parametrize("which", ["model_tiny2", "model_tiny3"])
-def test_task_streams_bit_identical_to_sequential_schedule(which):
-    """train_step with one HIP stream per task pass (event chain on the shared blocks) must give bit-identical weights, BN running
-    statistics, EMA and loss items to the sequential schedule of the reference (trainers/averaging.py:132-194)."""
+def test_task_streams_bit_identical_to_sequential_schedule(which, monkeypatch):
+    """train_step with one HIP stream per task pass must give bit-identical weights, BN running statistics, EMA and loss items to the
+    sequential schedule of the reference (trainers/averaging.py:132-194) -- in the decoupled form (per-task gradient buckets on the shared
+    blocks folded in task order, the later tasks' running-statistics updates behind each block: the passes wait for each other nowhere else)
+    and in the chained form (CDET_TASK_DECOUPLE=0: one shared gradient buffer, a per-block event chain), four runs, one result."""
     from cerberusdet_amd.trainers import Averaging
 
     arrays, meta = load_golden("trainer")
     _, mmeta = load_golden(which)  # tiny3: three tasks, blocks shared by all of them and by two of them
     tasks, ncs = mmeta["tasks"], mmeta["nc"]
     res = []
-    for streams in (False, True):
+    for streams, decouple in ((False, "0"), (True, "0"), (False, "1"), (True, "1")):
+        monkeypatch.setenv("CDET_TASK_DECOUPLE", decouple)
         m = _model(meta, mmeta)
         tr = Averaging(torch.device(DEV), m, meta["hyp"], tasks, epochs=100, nb=1000, task_streams=streams)
-        assert tr.task_streams == streams
+        assert tr.task_streams == streams and bool(m._alt_pairs) == (decouple == "1")
+        if decouple == "1":  # every later task of a shared block owns a bucket; its plans wait for nothing but their statistics updates
+            assert len(m._alt_pairs) == sum(len(ts) - 1 for bi, ts in tr.serving.items() if len(ts) > 1 and any(True for _ in m.blocks[bi].parameters()))
         items = []
         for it in range(3):
             batches = {}
@@ -176,15 +181,15 @@ def test_task_streams_bit_identical_to_sequential_schedule(which):
             items.append({t: v.clone() for t, v in out.items()})
         torch.cuda.synchronize()
         res.append((items, {k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in tr.ema.ema.state_dict().items()}))
-    (ia, sa, ea), (ib, sb, eb) = res
-    for x, y in zip(ia, ib):
-        for t in x:
-            assert torch.equal(x[t], y[t]), t
-    changed = 0
-    for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
-        assert torch.equal(ea[k], eb[k]), k
-        changed += int(not torch.equal(sa[k].float().cpu(), torch.from_numpy(synth.det_tensor(mmeta["seed"], k, sa[k].shape)).float()))
+    ia, sa, ea = res[0]
+    for ib, sb, eb in res[1:]:
+        for x, y in zip(ia, ib):
+            for t in x:
+                assert torch.equal(x[t], y[t]), t
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+            assert torch.equal(ea[k], eb[k]), k
+    changed = sum(int(not torch.equal(sa[k].float().cpu(), torch.from_numpy(synth.det_tensor(mmeta["seed"], k, sa[k].shape)).float())) for k in sa)
     assert changed > len(sa) // 2  # the steps really moved the model
 
 
