@@ -658,9 +658,23 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
     const int o0 = (lb / tiles_i) * 32, i0 = (lb % tiles_i) * 32;
     const int ni = min(32, p.I - i0), no = min(32, p.O - o0);
     const int run = ni * taps;
-    for (int e = threadIdx.x; e < 32 * 32 * taps; e += 256) {
-        const int o = e / (32 * taps), r = e - o * (32 * taps);
-        tile[o][r] = (o < no && r < run) ? p.w_oihw[((int64_t)(o0 + o) * p.I + i0) * taps + r] : 0.f;
+    if ((((int64_t)p.I * taps) & 3) == 0 && ((i0 * taps) & 3) == 0 && (run & 3) == 0 && (reinterpret_cast<uintptr_t>(p.w_oihw) & 15) == 0) {
+        // 16-byte loads: a row's ni * taps master values are contiguous and start 16-byte aligned (Cin a multiple of 4)
+        const int R4 = 8 * taps, r4 = run >> 2;
+        for (int e = threadIdx.x; e < 32 * R4; e += 256) {
+            const int o = e / R4, q = e - o * R4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (o < no && q < r4) v = *reinterpret_cast<const f32x4*>(p.w_oihw + ((int64_t)(o0 + o) * p.I + i0) * taps + 4 * q);
+            tile[o][4 * q + 0] = v[0];
+            tile[o][4 * q + 1] = v[1];
+            tile[o][4 * q + 2] = v[2];
+            tile[o][4 * q + 3] = v[3];
+        }
+    } else {
+        for (int e = threadIdx.x; e < 32 * 32 * taps; e += 256) {
+            const int o = e / (32 * taps), r = e - o * (32 * taps);
+            tile[o][r] = (o < no && r < run) ? p.w_oihw[((int64_t)(o0 + o) * p.I + i0) * taps + r] : 0.f;
+        }
     }
     __syncthreads();
     uint16_t* wf = reinterpret_cast<uint16_t*>(p.w_fwd);

@@ -9,14 +9,31 @@ namespace cdet {
 constexpr int OPT_BLOCKS_PER_SLOT = 32;   // partial sums per slot of the norm kernel (fixed: it sizes the caller's buffer)
 constexpr int OPT_SGD_BLOCKS = 256;       // update kernel: measured 1.18 / 1.08 / 1.01 / 0.98 / 0.99 ms at 32 / 64 / 128 / 256 / 512 blocks per slot
 
+// Block b of a slot sums the contiguous chunk [b n / B, (b + 1) n / B) of the gradient: 16-byte loads over the aligned middle of the chunk (the bucket
+// slices behind an odd-sized bias vector start unaligned), four independent partial sums per lane. (The strided scalar form ran at 1.5 TB/s: 0.28 ms of
+// the iteration's serial tail for 420 MB.)
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const cdet_param_slot* __restrict__ slots, float* __restrict__ out) {
     __shared__ float sh[4];
     const cdet_param_slot sl = slots[blockIdx.y];
     float acc = 0.f;
     if (sl.g) {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sl.n; i += (int64_t)gridDim.x * 256) {
-            const float g = sl.g[i];
-            acc += g * g;
+        const int64_t per = (sl.n + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per;
+        const int64_t hi = lo + per < sl.n ? lo + per : sl.n;
+        if (lo < hi) {
+            const float* g = sl.g;
+            int64_t a0 = lo + ((4 - (int)((reinterpret_cast<uintptr_t>(g + lo) >> 2) & 3)) & 3);
+            if (a0 > hi) a0 = hi;
+            for (int64_t i = lo + threadIdx.x; i < a0; i += 256) acc += g[i] * g[i];
+            const int64_t n4 = (hi - a0) >> 2;
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(g + a0);
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+            for (int64_t j = threadIdx.x; j < n4; j += 256) {
+                const f32x4 v = g4[j];
+                a4 += v * v;
+            }
+            acc += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            for (int64_t i = a0 + (n4 << 2) + threadIdx.x; i < hi; i += 256) acc += g[i] * g[i];
         }
     }
 #pragma unroll
@@ -26,13 +43,13 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const cdet_param_slot*
     if (threadIdx.x == 0) out[1 + blockIdx.y * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void sqnorm_finish_kernel(float* out, int n) {
-    __shared__ double sh[256];
+__global__ __launch_bounds__(1024) void sqnorm_finish_kernel(float* out, int n) {
+    __shared__ double sh[1024];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += (double)out[1 + i];
+    for (int i = threadIdx.x; i < n; i += 1024) acc += (double)out[1 + i];
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
@@ -132,7 +149,7 @@ extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slot
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(OPT_BLOCKS_PER_SLOT, n_slots), dim3(256), 0, s, slots_dev, out);
     CDET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(256), 0, s, out, n_slots * OPT_BLOCKS_PER_SLOT);
+    hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(1024), 0, s, out, n_slots * OPT_BLOCKS_PER_SLOT);
     CDET_LAUNCH_CHECK();
     return 0;
 }
