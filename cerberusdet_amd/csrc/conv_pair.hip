@@ -236,12 +236,13 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
             float s16[16], q16[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float s_ = 0.f, q_ = 0.f;
+                float s_ = acc[f][0][r];  // (starting from the first fragment, not from 0.f: "0 + x" is an instruction under IEEE signed-zero rules)
+                float q_ = s_ * s_;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
+                for (int g = 1; g < NG; ++g) {
                     const float v0 = acc[f][g][r];
                     s_ += v0;
-                    q_ += v0 * v0;
+                    q_ = fmaf(v0, v0, q_);
                 }
                 s16[r] = s_;
                 q16[r] = q_;
