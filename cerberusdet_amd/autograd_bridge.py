@@ -39,6 +39,7 @@ class _PlanFunction(torch.autograd.Function):
                 else:
                     d[..., :64 + nc].copy_(g.permute(0, 2, 3, 1))
         plan.run_backward()
+        plan.model._merge_alt_grads()  # (a trainer-managed model keeps per-task gradient buckets on its shared blocks: p.grad must hold the sum)
         return None, None, None, None
 
 
