@@ -56,8 +56,8 @@ class AugTile(C.Structure):
 
 
 class AugSample(C.Structure):
-    _fields_ = [("tiles", AugTile * 8), ("minv", C.c_double * 12), ("mix_ratio", C.c_double), ("n_mosaic", i32), ("flipud", i32),
-                ("fliplr", i32), ("use_hsv", i32), ("canvas", i32), ("reserved", i32), ("lut", C.c_uint8 * 768)]
+    _fields_ = [("tiles", AugTile * 8), ("minv", C.c_double * 18), ("mix_ratio", C.c_double), ("n_mosaic", i32), ("flipud", i32),
+                ("fliplr", i32), ("use_hsv", i32), ("canvas", i32), ("perspective", i32), ("lut", C.c_uint8 * 768)]
 
 
 class MergeDesc(C.Structure):

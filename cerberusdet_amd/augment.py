@@ -16,8 +16,9 @@ data/augmentations.py:43-57 `augment_hsv`, 93-202 `random_perspective`, 205-211 
 Pixel arithmetic restates OpenCV's published 8-bit algorithms (no cv2 in this image): parity unpinned, like the letterbox kernel; the
 kernel is bit-exact against `oracle/augment.py`, the numpy restatement of the same arithmetic.
 
-Not reproduced: Albumentations (a no-op in the reference when the package is missing, augmentations.py:16-40), `perspective` != 0 (the
-shipped hyper-parameters use 0.0: warpPerspective is not implemented), rectangular training, image weights, the label cache.
+Not reproduced: Albumentations (a no-op in the reference when the package is missing, augmentations.py:16-40), rectangular training,
+image weights, the label cache. `perspective` != 0 (cold: every shipped hyper-parameter file uses 0.0) switches the warp to
+cv2.warpPerspective's arithmetic and the label warp to the homogeneous division (augmentations.py:152-153, 172).
 Both branches of `__getitem__` are covered: the mosaic (probability hyp["mosaic"], with mixup) and the single letterboxed image.
 """
 from __future__ import annotations
@@ -50,6 +51,7 @@ class Mosaic:
     labels: np.ndarray       # [n, 6] (cls, prob, x1, y1, x2, y2) in output pixels, after the candidate filter
     canvas: int = 0          # side of the square the tiles are pasted on: 2s for a mosaic, s for the single letterboxed image
     shapes: Optional[tuple] = None  # single image: ((h0, w0), ((h / h0, w / w0), (dw, dh))) like the reference's `shapes`
+    perspective: bool = False  # hyp["perspective"] != 0: cv2.warpPerspective instead of cv2.warpAffine (augmentations.py:152-155)
 
 
 @dataclass
@@ -133,14 +135,16 @@ def box_candidates(box1, box2, wh_thr=2, ar_thr=20, area_thr=0.1, eps=1e-16):
     return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + eps) > area_thr) & (ar < ar_thr)
 
 
-def warp_labels(targets, M, s, width, height):
-    """Label part of random_perspective (augmentations.py:164-190): corners through M, axis-aligned hull, clip, candidate filter."""
+def warp_labels(targets, M, s, width, height, perspective=False):
+    """Label part of random_perspective (augmentations.py:164-190): corners through M (divided by the homogeneous coordinate when
+    perspective != 0, line 172), axis-aligned hull, clip, candidate filter."""
     n = len(targets)
     if not n:
         return targets
     xy = np.ones((n * 4, 3))
     xy[:, :2] = targets[:, [2, 3, 4, 5, 2, 5, 4, 3]].reshape(n * 4, 2)
-    xy = (xy @ M.T)[:, :2].reshape(n, 8)
+    xy = xy @ M.T
+    xy = (xy[:, :2] / xy[:, 2:3] if perspective else xy[:, :2]).reshape(n, 8)
     x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
     new = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
     new[:, [0, 2]] = new[:, [0, 2]].clip(0, width)
@@ -153,8 +157,6 @@ def warp_labels(targets, M, s, width, height):
 
 def sample_mosaic(rng: random.Random, index, indices: Sequence[int], sizes, labels, s, hyp) -> Mosaic:
     """load_mosaic (datasets.py:483-542). `sizes[i]` = (h0, w0) of image i, `labels[i]` = [n, 6] (cls, prob, x, y, w, h) normalised."""
-    if hyp["perspective"]:
-        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not implemented; the shipped hyper-parameters use 0.0")
     border = (-s // 2, -s // 2)
     yc, xc = (int(rng.uniform(-b, 2 * s + b)) for b in border)
     picks = [index] + rng.choices(list(indices), k=3)
@@ -181,15 +183,14 @@ def sample_mosaic(rng: random.Random, index, indices: Sequence[int], sizes, labe
     lab4 = np.concatenate(lab4, 0)
     np.clip(lab4[:, 2:], 0, 2 * s, out=lab4[:, 2:])
     M, sc, width, height = sample_affine(rng, (2 * s, 2 * s), hyp, border)
-    return Mosaic(tiles, M, warp_labels(lab4, M, sc, width, height), canvas=2 * s)
+    persp = bool(hyp["perspective"])
+    return Mosaic(tiles, M, warp_labels(lab4, M, sc, width, height, persp), canvas=2 * s, perspective=persp)
 
 
 def sample_single(rng: random.Random, index, sizes, labels, s, hyp) -> Mosaic:
     """The non-mosaic branch of __getitem__ (datasets.py:376-402): load_image, letterbox(auto=False, scaleup=True), random_perspective
     without border. (When load_image's truncation leaves the long side at s - 1 the reference resizes a second time inside letterbox;
     here the original is resized once to that final size -- the labels are the reference's either way.)"""
-    if hyp["perspective"]:
-        raise NotImplementedError("perspective != 0 (cv2.warpPerspective) is not implemented; the shipped hyper-parameters use 0.0")
     h0, w0 = sizes[index]
     h, w = resized_hw((h0, w0), s)
     r = min(s / h, s / w)
@@ -201,7 +202,9 @@ def sample_single(rng: random.Random, index, sizes, labels, s, hyp) -> Mosaic:
     if lb.size:
         lb[:, 2:] = xywhn2xyxy(lb[:, 2:], r * w, r * h, padw=dw, padh=dh)
     M, sc, width, height = sample_affine(rng, (s, s), hyp)
-    return Mosaic([tile], M, warp_labels(lb, M, sc, width, height), canvas=s, shapes=((h0, w0), ((h / h0, w / w0), (dw, dh))))
+    persp = bool(hyp["perspective"])
+    return Mosaic([tile], M, warp_labels(lb, M, sc, width, height, persp), canvas=s, shapes=((h0, w0), ((h / h0, w / w0), (dw, dh))),
+                  perspective=persp)
 
 
 def hsv_luts(nprng: np.random.RandomState, hyp):
@@ -252,6 +255,21 @@ def warp_coefficients(M):
     return np.array([a11, a12, b1, a21, a22, b2], np.float64)
 
 
+def warp_coefficients_perspective(M):
+    """cv2.warpPerspective's view of a FORWARD matrix: the row-major 3x3 inverse (dst -> src) as cv::invert's closed 3x3 form computes
+    it in double (determinant by the first row, cofactors times 1/det), nine doubles for the kernel."""
+    m = np.asarray(M, np.float64)
+    d = (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+         + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+    if d == 0:
+        return np.zeros(9, np.float64)  # cv::invert leaves a zero matrix behind a singular input
+    d = 1.0 / d
+    return np.array([(m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) * d, (m[0, 2] * m[2, 1] - m[0, 1] * m[2, 2]) * d, (m[0, 1] * m[1, 2] - m[0, 2] * m[1, 1]) * d,
+                     (m[1, 2] * m[2, 0] - m[1, 0] * m[2, 2]) * d, (m[0, 0] * m[2, 2] - m[0, 2] * m[2, 0]) * d, (m[0, 2] * m[1, 0] - m[0, 0] * m[1, 2]) * d,
+                     (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]) * d, (m[0, 1] * m[2, 0] - m[0, 0] * m[2, 1]) * d, (m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]) * d],
+                    np.float64)
+
+
 def render_batch(plans: Sequence[AugPlan], images, s, device):
     """Launch cdet_mosaic_augment_batch for a batch of plans. `images[i]` = uint8 HWC BGR tensor of image i ON THE DEVICE (only the ones
     the plans use need to be present). Returns uint8 [B, 3, s, s] RGB."""
@@ -274,10 +292,12 @@ def render_batch(plans: Sequence[AugPlan], images, s, device):
         sm.use_hsv = int(p.hsv_lut is not None)
         if p.hsv_lut is not None:
             C.memmove(sm.lut, np.ascontiguousarray(p.hsv_lut, np.uint8).ctypes.data, 768)
+        sm.perspective = int(p.mosaics[0].perspective)
         for m, mo in enumerate(p.mosaics):
-            co = warp_coefficients(mo.M)
-            for k in range(6):
-                sm.minv[m * 6 + k] = float(co[k])
+            assert mo.perspective == p.mosaics[0].perspective
+            co = warp_coefficients_perspective(mo.M) if mo.perspective else warp_coefficients(mo.M)
+            for k in range(len(co)):
+                sm.minv[m * 9 + k] = float(co[k])
             for t, tl in enumerate(mo.tiles):
                 it = sm.tiles[m * 4 + t]
                 img = images[tl.index]

@@ -6,8 +6,8 @@
 // (cerberusdet_amd/augment.py) in the reference's order of draws; this kernel only renders.
 //
 // One thread = one output pixel (3 channels):
-//   1. undo the flips; 2. cv2.warpAffine's INTER_LINEAR for 8-bit images: inverse map in 10-bit fixed point, coordinates with 5 fractional
-//   bits, four taps weighted by (32-fx)(32-fy)*32 ... / 2^15, taps outside the canvas = 114; 3. a tap on the canvas is the pixel of the tile
+//   1. undo the flips; 2. cv2.warpAffine's INTER_LINEAR for 8-bit images: inverse map in 10-bit fixed point (or cv2.warpPerspective's
+//   per-pixel division in double when hyp['perspective'] != 0), coordinates with 5 fractional bits, four taps weighted by (32-fx)(32-fy)*32 ... / 2^15, taps outside the canvas = 114; 3. a tap on the canvas is the pixel of the tile
 //   that covers it (else 114), i.e. cv2.resize's INTER_LINEAR sample of the original image (11-bit coefficients, two integer passes; exact
 //   2x shrink = area average), evaluated on the fly -- the resized images and the canvas are never materialised; 4. mixup: a second mosaic
 //   rendered the same way, (a*r + b*(1-r)) truncated; 5. BGR -> HSV (OpenCV's 8-bit integer form, H in [0,180)), three lookup tables,
@@ -84,11 +84,8 @@ __device__ __forceinline__ int aug_round_sat(double x) {  // saturate_cast<int>(
     return x >= 2147483647.0 ? 2147483647 : (x <= -2147483648.0 ? (int)-2147483648ll : (int)x);
 }
 
-// cv2.warpAffine(canvas, M, (s, s), borderValue=114) at (x, y)
-__device__ __forceinline__ void aug_warp_pixel(const cdet_aug_tile* tiles, const double* m, int canvas, int x, int y, int v[3]) {
-    const int adelta = aug_round_sat(m[0] * x * 1024.0), bdelta = aug_round_sat(m[3] * x * 1024.0);
-    const int X0 = aug_round_sat((m[1] * y + m[2]) * 1024.0) + 16, Y0 = aug_round_sat((m[4] * y + m[5]) * 1024.0) + 16;
-    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+// remapBilinear (INTER_LINEAR, BORDER_CONSTANT 114) at the fixed-point coordinate (X, Y): 5 fractional bits each
+__device__ __forceinline__ void aug_remap_pixel(const cdet_aug_tile* tiles, int canvas, int X, int Y, int v[3]) {
     int sx = X >> 5, sy = Y >> 5;
     sx = min(max(sx, -32768), 32767);
     sy = min(max(sy, -32768), 32767);
@@ -101,6 +98,26 @@ __device__ __forceinline__ void aug_warp_pixel(const cdet_aug_tile* tiles, const
     aug_canvas_pixel(tiles, canvas, sx + 1, sy + 1, p11);
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = (p00[c] * w00 + p01[c] * w01 + p10[c] * w10 + p11[c] * w11 + (1 << 14)) >> 15;
+}
+
+// cv2.warpAffine(canvas, M, (s, s), borderValue=114) at (x, y): inverse map in 10-bit fixed point
+__device__ __forceinline__ void aug_warp_pixel(const cdet_aug_tile* tiles, const double* m, int canvas, int x, int y, int v[3]) {
+    const int adelta = aug_round_sat(m[0] * x * 1024.0), bdelta = aug_round_sat(m[3] * x * 1024.0);
+    const int X0 = aug_round_sat((m[1] * y + m[2]) * 1024.0) + 16, Y0 = aug_round_sat((m[4] * y + m[5]) * 1024.0) + 16;
+    aug_remap_pixel(tiles, canvas, (X0 + adelta) >> 5, (Y0 + bdelta) >> 5, v);
+}
+
+// cv2.warpPerspective(canvas, M, (s, s), borderValue=114) at (x, y) (data/augmentations.py:152-153, hyp['perspective'] != 0): OpenCV
+// walks the output in blocks 64 wide, evaluates the homogeneous coordinate of the block's first column in double, adds the column
+// offset, divides per pixel (W = 32 / w, 0 when w == 0) and rounds to 5 fractional bits -- the summation order is kept
+__device__ __forceinline__ void aug_warp_persp_pixel(const cdet_aug_tile* tiles, const double* m, int canvas, int x, int y, int v[3]) {
+    const int xb = x & ~63, x1 = x & 63;
+    const double X0 = m[0] * xb + m[1] * y + m[2], Y0 = m[3] * xb + m[4] * y + m[5], W0 = m[6] * xb + m[7] * y + m[8];
+    double W = W0 + m[6] * x1;
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + m[0] * x1) * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + m[3] * x1) * W));
+    aug_remap_pixel(tiles, canvas, aug_round_sat(fX), aug_round_sat(fY), v);
 }
 
 // cv2.cvtColor(BGR2HSV) for 8-bit images: integer form with 12-bit reciprocal tables, H in [0, 180)
@@ -156,10 +173,12 @@ __global__ __launch_bounds__(256) void mosaic_augment_kernel(const cdet_aug_samp
     // output pixel (x, y) = pixel (xs, ys) of the image before np.flipud / np.fliplr
     const int xs = sm.fliplr ? s - 1 - x : x, ys = sm.flipud ? s - 1 - y : y;
     int v[3];
-    aug_warp_pixel(sm.tiles, sm.minv, sm.canvas, xs, ys, v);
+    if (sm.perspective) aug_warp_persp_pixel(sm.tiles, sm.minv, sm.canvas, xs, ys, v);
+    else aug_warp_pixel(sm.tiles, sm.minv, sm.canvas, xs, ys, v);
     if (sm.n_mosaic > 1) {  // mixup: (im * r + im2 * (1 - r)).astype(np.uint8) in float64
         int v2[3];
-        aug_warp_pixel(sm.tiles + 4, sm.minv + 6, sm.canvas, xs, ys, v2);
+        if (sm.perspective) aug_warp_persp_pixel(sm.tiles + 4, sm.minv + 9, sm.canvas, xs, ys, v2);
+        else aug_warp_pixel(sm.tiles + 4, sm.minv + 9, sm.canvas, xs, ys, v2);
         const double r = sm.mix_ratio;
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = (int)((double)v[c] * r + (double)v2[c] * (1.0 - r));

@@ -259,12 +259,13 @@ typedef struct {
 } cdet_aug_tile;
 typedef struct {
     cdet_aug_tile tiles[8];        /* mosaic 0: tiles 0..3; the mixup partner: tiles 4..7              */
-    double minv[12];               /* per mosaic a11 a12 b1 a21 a22 b2: output -> canvas, the inverse cv2.warpAffine derives */
+    double minv[18];               /* per mosaic 9 doubles, output -> canvas. perspective == 0: a11 a12 b1 a21 a22 b2 (+3 unused), the
+                                    * inverse cv2.warpAffine derives; perspective != 0: the row-major 3x3 inverse cv2.warpPerspective derives */
     double mix_ratio;              /* weight of mosaic 0 (np.random.beta(32, 32))                      */
     int32_t n_mosaic;              /* 1, or 2 with mixup                                               */
     int32_t flipud, fliplr, use_hsv;
     int32_t canvas;                /* side of the square the tiles sit on: 2s (mosaic) or s (one letterboxed image, tile 0 only) */
-    int32_t reserved;
+    int32_t perspective;           /* hyp['perspective'] != 0: cv2.warpPerspective (augmentations.py:152-153) instead of cv2.warpAffine */
     uint8_t lut[768];              /* augment_hsv's hue / sat / val lookup tables                      */
 } cdet_aug_sample;
 int cdet_mosaic_augment_batch(const cdet_aug_sample* samples, int32_t B, void* out_u8_nchw, int32_t s, void* stream);

@@ -1,7 +1,7 @@
 """CPU restatement (numpy) of the PIXEL side of the reference's training augmentation -- TEST INFRASTRUCTURE, never imported by the product.
 
 Follows, image by image, what a reference DataLoader worker does with cv2 (data/datasets.py:470-477 load_image, 483-527 load_mosaic,
-data/augmentations.py:151 cv2.warpAffine inside random_perspective, 205-211 mixup, 43-57 augment_hsv, datasets.py:420-438 flips and the
+data/augmentations.py:152-155 cv2.warpPerspective / cv2.warpAffine inside random_perspective, 205-211 mixup, 43-57 augment_hsv, datasets.py:420-438 flips and the
 final transpose), materialising every intermediate image the way the reference does -- the HIP kernel (csrc/augment.hip) computes the
 same values on the fly and must equal this bit for bit.
 
@@ -34,6 +34,55 @@ def _round_sat(x):
     return np.clip(np.rint(x), -2147483648.0, 2147483647.0).astype(np.int64)
 
 
+def _remap_bilinear_u8(src, X, Y, border):
+    """remapBilinear for 8-bit 3-channel images, BORDER_CONSTANT: X, Y fixed-point source coordinates with 5 fractional bits."""
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    H, W = src.shape[:2]
+
+    def tap(xx, yy):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.int64)
+        v[~ok] = border
+        return v
+
+    w00, w01, w10, w11 = (32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32
+    out = (tap(sx, sy) * w00[..., None] + tap(sx + 1, sy) * w01[..., None] + tap(sx, sy + 1) * w10[..., None] + tap(sx + 1, sy + 1) * w11[..., None] + (1 << 14)) >> 15
+    return out.astype(np.uint8)
+
+
+def invert3x3(M):
+    """cv::invert of a 3x3 double matrix (the closed form OpenCV takes for sizes <= 3: determinant by the first row, cofactors / det)."""
+    m = np.asarray(M, np.float64)
+    d = (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+         + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+    if d == 0:
+        return np.zeros((3, 3))
+    d = 1.0 / d
+    return np.array([[(m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) * d, (m[0, 2] * m[2, 1] - m[0, 1] * m[2, 2]) * d, (m[0, 1] * m[1, 2] - m[0, 2] * m[1, 1]) * d],
+                     [(m[1, 2] * m[2, 0] - m[1, 0] * m[2, 2]) * d, (m[0, 0] * m[2, 2] - m[0, 2] * m[2, 0]) * d, (m[0, 2] * m[1, 0] - m[0, 0] * m[1, 2]) * d],
+                     [(m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]) * d, (m[0, 1] * m[2, 0] - m[0, 0] * m[2, 1]) * d, (m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]) * d]])
+
+
+def warp_perspective_u8(src, M, dsize, border=114):
+    """cv2.warpPerspective(src, M, dsize, borderValue=(114,)*3) (data/augmentations.py:152-153): INTER_LINEAR, BORDER_CONSTANT, 8-bit
+    3-channel. OpenCV (imgwarp.cpp WarpPerspectiveInvoker) inverts M, walks the output in blocks 64 columns wide, evaluates the homogeneous
+    coordinate of a block's first column in double, adds the column offset, divides per pixel (32 / w, 0 for w == 0), saturates and rounds
+    to 5 fractional bits, then runs the same remapBilinear as warpAffine."""
+    m = invert3x3(M).reshape(9)
+    width, height = dsize
+    xs = np.arange(width, dtype=np.int64)
+    xb, x1 = ((xs // 64) * 64).astype(np.float64)[None, :], (xs % 64).astype(np.float64)[None, :]
+    ys = np.arange(height, dtype=np.float64)[:, None]
+    X0, Y0, W0 = m[0] * xb + m[1] * ys + m[2], m[3] * xb + m[4] * ys + m[5], m[6] * xb + m[7] * ys + m[8]
+    W = W0 + m[6] * x1
+    with np.errstate(divide="ignore"):
+        W = np.where(W != 0, 32.0 / np.where(W != 0, W, 1.0), 0.0)
+    fX = np.maximum(-2147483648.0, np.minimum(2147483647.0, (X0 + m[0] * x1) * W))
+    fY = np.maximum(-2147483648.0, np.minimum(2147483647.0, (Y0 + m[3] * x1) * W))
+    return _remap_bilinear_u8(src, _round_sat(fX), _round_sat(fY), border)
+
+
 def warp_affine_u8(src, M, dsize, border=114):
     """cv2.warpAffine(src, M[:2], dsize, borderValue=(114,)*3): INTER_LINEAR, BORDER_CONSTANT, 8-bit 3-channel."""
     A = np.asarray(M, np.float64)[:2]
@@ -50,19 +99,7 @@ def warp_affine_u8(src, M, dsize, border=114):
     Y0 = _round_sat((a22 * ys + b2) * 1024.0) + 16
     X = (X0[:, None] + adelta[None, :]) >> 5
     Y = (Y0[:, None] + bdelta[None, :]) >> 5
-    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
-    fx, fy = X & 31, Y & 31
-    H, W = src.shape[:2]
-
-    def tap(xx, yy):
-        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
-        v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.int64)
-        v[~ok] = border
-        return v
-
-    w00, w01, w10, w11 = (32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32
-    out = (tap(sx, sy) * w00[..., None] + tap(sx + 1, sy) * w01[..., None] + tap(sx, sy + 1) * w10[..., None] + tap(sx + 1, sy + 1) * w11[..., None] + (1 << 14)) >> 15
-    return out.astype(np.uint8)
+    return _remap_bilinear_u8(src, X, Y, border)
 
 
 def bgr2hsv_u8(im):
@@ -107,9 +144,10 @@ def augment_hsv(im, lut):
     return hsv2bgr_u8(lut[0][h].astype(np.int64), lut[1][s].astype(np.int64), lut[2][v].astype(np.int64))
 
 
-def render(mosaics, mix_ratio, lut, flipud, fliplr, images, s):
+def render(mosaics, mix_ratio, lut, flipud, fliplr, images, s, perspective=False):
     """mosaics: [(tiles, M, canvas)] (one, or two with mixup) -> uint8 [3, s, s] RGB exactly as `__getitem__` returns it."""
-    ims = [warp_affine_u8(build_canvas(tiles, images, canvas), M, (s, s)) for tiles, M, canvas in mosaics]
+    warp = warp_perspective_u8 if perspective else warp_affine_u8  # augmentations.py:152-155
+    ims = [warp(build_canvas(tiles, images, canvas), M, (s, s)) for tiles, M, canvas in mosaics]
     im = ims[0]
     if len(ims) > 1:
         im = (im * mix_ratio + ims[1] * (1 - mix_ratio)).astype(np.uint8)

@@ -243,6 +243,8 @@ AUG_CASES = {
     "hyp_default": dict(seed=41, n=12, s=640, samples=12, hyp=_AUG_HYP),
     "rotate_flip_mix": dict(seed=42, n=9, s=320, samples=10, hyp=dict(_AUG_HYP, degrees=10.0, shear=5.0, flipud=0.5, mixup=0.7, scaleup=0.6)),
     "half_mosaic": dict(seed=44, n=8, s=192, samples=10, hyp=dict(_AUG_HYP, mosaic=0.5, degrees=5.0)),  # both branches of __getitem__
+    # hyp["perspective"] != 0: cv2.warpPerspective + the homogeneous division of the label corners (augmentations.py:152-153, 172)
+    "perspective": dict(seed=45, n=8, s=256, samples=8, hyp=dict(_AUG_HYP, perspective=0.0008, degrees=8.0, mosaic=0.75, mixup=0.5)),
     "no_hsv_no_mix": dict(seed=43, n=6, s=256, samples=6, hyp=dict(_AUG_HYP, hsv_h=0.0, hsv_s=0.0, hsv_v=0.0, mixup=0.0, fliplr=0.0, flipud=0.0)),
 }
 

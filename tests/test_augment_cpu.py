@@ -29,7 +29,8 @@ def test_parameters_and_labels_equal_the_reference(name):
         assert len(plan.mosaics) == len(want["M"]), (name, k)
         n_mix += len(plan.mosaics) - 1
         for mo, M in zip(plan.mosaics, want["M"]):
-            assert np.array_equal(mo.M[:2], np.array(M)), (name, k)
+            assert np.array_equal(mo.M[:len(M)], np.array(M)), (name, k)  # 2x3 handed to cv2.warpAffine, 3x3 to cv2.warpPerspective
+            assert mo.perspective == (len(M) == 3) == bool(c["hyp"]["perspective"])
             for t in mo.tiles:  # the paste rectangle and the source window have the same extent and stay inside both images
                 (x1a, y1a, x2a, y2a), (x1b, y1b) = t.dst, t.src
                 assert 0 <= x1a <= x2a <= 2 * c["s"] and 0 <= y1a <= y2a <= 2 * c["s"]
@@ -58,6 +59,39 @@ def test_warp_coefficients_invert_the_matrix():
     a = A.warp_coefficients(M)
     inv = np.array([[a[0], a[1], a[2]], [a[3], a[4], a[5]], [0, 0, 1]])
     assert np.allclose(inv @ M, np.eye(3), atol=1e-9) and (w, h) == (128, 128)
+
+
+def test_perspective_coefficients_and_restatement():
+    """hyp["perspective"] != 0 (augmentations.py:152-153): the nine kernel coefficients are the inverse homography; the numpy restatement of
+    cv2.warpPerspective returns the canvas under the identity, equals the restated cv2.warpAffine for a pure integer shift (every weight
+    exact in both arithmetics) and follows a real homography to within one bilinear cell of the float evaluation."""
+    from oracle import augment as OA
+
+    rng = random.Random(5)
+    M, s, w, h = A.sample_affine(rng, (256, 256), dict(A.HYP_DEFAULT, degrees=10.0, perspective=0.001), (-64, -64))
+    assert M[2, 0] != 0 and M[2, 1] != 0
+    inv = A.warp_coefficients_perspective(M).reshape(3, 3)
+    assert np.allclose(inv @ M, np.eye(3), atol=1e-9) and np.array_equal(inv, OA.invert3x3(M))
+    nrng = np.random.RandomState(1)
+    canvas = nrng.randint(0, 256, (128, 160, 3)).astype(np.uint8)  # wider than one 64-column block of the walk
+    assert np.array_equal(OA.warp_perspective_u8(canvas, np.eye(3), (160, 128)), canvas)
+    shift = np.array([[1, 0, 7.0], [0, 1, -4.0], [0, 0, 1]])
+    assert np.array_equal(OA.warp_perspective_u8(canvas, shift, (160, 128)), OA.warp_affine_u8(canvas, shift, (160, 128)))
+    smooth = np.zeros((256, 256, 3), np.uint8)
+    smooth[..., 0], smooth[..., 1] = np.arange(256)[None, :], np.arange(256)[:, None]  # channel 0 = x, channel 1 = y of the source
+    out = OA.warp_perspective_u8(smooth, M, (w, h)).astype(float)
+    ys, xs = np.mgrid[0:h, 0:w]
+    src = inv @ np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    sx, sy = (src[0] / src[2]).reshape(h, w), (src[1] / src[2]).reshape(h, w)
+    inside = (sx > 1) & (sx < 254) & (sy > 1) & (sy < 254)
+    assert inside.mean() > 0.3 and np.abs(out[..., 0] - sx)[inside].max() <= 1.0 and np.abs(out[..., 1] - sy)[inside].max() <= 1.0
+    # labels: the corners go through the homogeneous division
+    t = np.array([[0, 1, 100.0, 110.0, 150.0, 160.0]])
+    got = A.warp_labels(t.copy(), M, 1.0, w, h, perspective=True)
+    c = np.array([[100, 110, 1], [150, 160, 1], [100, 160, 1], [150, 110, 1.0]]) @ M.T
+    c = c[:, :2] / c[:, 2:3]
+    want = [c[:, 0].min().clip(0, w), c[:, 1].min().clip(0, h), c[:, 0].max().clip(0, w), c[:, 1].max().clip(0, h)]
+    assert len(got) == 1 and np.allclose(got[0, 2:], want)
 
 
 def test_pixel_restatement_identity_cases():

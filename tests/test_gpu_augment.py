@@ -1,5 +1,5 @@
 """The augmentation kernel (csrc/augment.hip, cdet_mosaic_augment_batch) against the numpy restatement of the reference's pixel chain
-(oracle/augment.py: cv2.resize of load_image, the mosaic paste, cv2.warpAffine, mixup, augment_hsv, flips, BGR->RGB CHW -- reference
+(oracle/augment.py: cv2.resize of load_image, the mosaic paste, cv2.warpAffine / cv2.warpPerspective, mixup, augment_hsv, flips, BGR->RGB CHW -- reference
 data/datasets.py:361-438,470-527, data/augmentations.py:43-57,151,205-211). Integer / uint8 work: **bit-exact**. The plans come from
 cerberusdet_amd/augment.py with the generator states of tests/golden/augment.json, i.e. the reference's own parameters."""
 import random
@@ -41,7 +41,7 @@ def test_rendered_batch_equals_the_numpy_restatement(name):
     n_mix = n_flip = 0
     for k, p in enumerate(plans):
         mos = [([(t.index, t.hw, t.dst, t.src) for t in m.tiles], m.M, m.canvas) for m in p.mosaics]
-        want = OA.render(mos, p.mix_ratio, p.hsv_lut, p.flipud, p.fliplr, images, c["s"])
+        want = OA.render(mos, p.mix_ratio, p.hsv_lut, p.flipud, p.fliplr, images, c["s"], perspective=p.mosaics[0].perspective)
         bad = got[k] != want
         assert not bad.any(), f"{name} sample {k}: {int(bad.sum())} of {bad.size} bytes differ, max |diff| {np.abs(got[k].astype(int) - want.astype(int)).max()}"
         n_mix += p.mix_ratio is not None

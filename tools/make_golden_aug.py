@@ -5,7 +5,7 @@ reference (`/root/reference`: data/datasets.py `LoadImagesAndLabels.__getitem__`
 
 The reference's own functions run on a minimal stand-in for the dataset object (sizes, labels and cached images; no files) with the
 global `random` / `np.random` generators seeded per sample. cv2 is absent from this image: a RECORDING stub captures what the reference
-hands to it -- the affine matrix of every cv2.warpAffine call, the three lookup tables of cv2.LUT -- and returns blank images; the one
+hands to it -- the matrix of every cv2.warpAffine / cv2.warpPerspective call, the three lookup tables of cv2.LUT -- and returns blank images; the one
 value it computes, cv2.getRotationMatrix2D(center=(0, 0)), follows OpenCV's documented formula. Pixels are therefore NOT part of this
 fixture (oracle/augment.py restates them, parity unpinned); what IS pinned: the order of the random draws, mosaic centre / partners /
 paste rectangles (through the labels they move), M, the label warp + clip + box_candidates filter, mixup's partner and ratio, the HSV
@@ -49,6 +49,11 @@ def _install_cv2():
         assert tuple(borderValue) == (114, 114, 114)
         return np.zeros((dsize[1], dsize[0], 3), np.uint8)
 
+    def warpPerspective(im, M, dsize, borderValue=None):
+        REC.setdefault("M", []).append(np.array(M, np.float64).tolist())  # the full 3x3 matrix
+        assert tuple(borderValue) == (114, 114, 114) and np.array(M).shape == (3, 3)
+        return np.zeros((dsize[1], dsize[0], 3), np.uint8)
+
     def LUT(ch, lut):
         REC.setdefault("lut", []).append(np.asarray(lut).astype(int).tolist())
         return ch
@@ -65,6 +70,7 @@ def _install_cv2():
     cv2.BORDER_CONSTANT, cv2.INTER_LINEAR, cv2.INTER_AREA = 0, 1, 3
     cv2.getRotationMatrix2D = getRotationMatrix2D
     cv2.warpAffine = warpAffine
+    cv2.warpPerspective = warpPerspective
     cv2.LUT = LUT
     cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 40, 54
     cv2.cvtColor = lambda im, code, dst=None: im
