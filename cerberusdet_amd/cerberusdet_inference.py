@@ -4,6 +4,10 @@
 Execution differs: the all-heads forward is one compiled gfx950 launch list (backbone + shared neck once, each branch once),
 per-task NMS is ONE batched launch sequence per task, and the per-image combine / cross-task NMS / rescale runs on the few
 hundred surviving rows after a single device->host copy (the reference does `.cpu()` + python lambdas per task per image).
+
+Beyond the reference's synchronous `predict`: `predict_async` enqueues forward + NMS + merge + an asynchronous copy into pinned host
+memory and returns a `PendingPrediction` whose `.result()` builds the reference's list of dicts; `predict_stream` keeps a few batches in
+flight so that the host-side dict building of batch i runs under the GPU work of batch i + 1 (same results, same order).
 """
 from __future__ import annotations
 
@@ -50,6 +54,33 @@ def attempt_load(weights, map_location=None) -> CerberusDet:
     return model.eval()
 
 
+class PendingPrediction:
+    """The device work of one `predict` call in flight: rows [bs, max_det, 6] and counts [bs] on their way into pinned host memory behind
+    `event`. `.result()` waits for the event and builds the reference's output (cerberusdet_inference.py:150-186): per image a list of
+    {"box": [x1, y1, x2, y2] ints, "score", "label" (global id), "label_name", "task"}."""
+
+    def __init__(self, rows, cnt, event, class_names, task_of_label):
+        self._rows, self._cnt, self._event, self._names, self._task_of = rows, cnt, event, class_names, task_of_label
+        self._done = None
+
+    def ready(self) -> bool:
+        return self._done is not None or self._event.query()
+
+    def result(self) -> List[List[Dict]]:
+        if self._done is None:
+            self._event.synchronize()
+            rows, cnt, names, task_of = self._rows.numpy(), self._cnt.numpy().tolist(), self._names, self._task_of
+            out = []
+            for i, n in enumerate(cnt):
+                r = rows[i, :n]
+                # (int(v) truncates like the reference's int(); the rows were rounded on the device by scale_boxes().round())
+                boxes, scores, labels = r[:, :4].astype(np.int64).tolist(), r[:, 4].tolist(), r[:, 5].astype(np.int64).tolist()
+                out.append([{"box": b, "score": sc, "label": c, "label_name": names[c], "task": task_of[c]} for b, sc, c in zip(boxes, scores, labels)])
+            self._done = out
+            self._rows = self._cnt = None
+        return self._done
+
+
 class CerberusDetInference:
     def __init__(self, weights, device: str = "", conf_thres: float = 0.25, iou_thres: float = 0.45, iou_thres_between_tasks: float = 0.8,
                  half: bool = False, img_size: int = 640):
@@ -66,6 +97,7 @@ class CerberusDetInference:
         self.names: Dict[str, List[str]] = getattr(self.model, "names", None) or {t: [str(i) for i in range(self.model.get_head(t).nc)]
                                                                                   for t in self.model.heads}
         self.categories_inds_map, self.all_class_names = self._get_categories_map(self.names)
+        self._task_of_label = None
         dummy = check_img_size(img_size, s=self.stride)
         self.model(torch.zeros(1, 3, dummy, dummy, device=self.device, dtype=torch.float16 if self.half else torch.float32))  # warm-up
 
@@ -85,12 +117,42 @@ class CerberusDetInference:
         conf_thres = self.conf_thres if conf_thres is None else conf_thres
         iou_thres = self.iou_thres if iou_thres is None else iou_thres
         iou_bt = self.iou_thres_between_tasks if iou_thres_between_tasks is None else iou_thres_between_tasks
+        return self.predict_async(tensor, original_shape, max_det, agnostic_nms, conf_thres, iou_thres, iou_bt).result()
+
+    @torch.no_grad()
+    def predict_async(self, tensor: torch.Tensor, original_shape=None, max_det: int = 300, agnostic_nms: bool = False, conf_thres: float = None,
+                      iou_thres: float = None, iou_thres_between_tasks: float = None) -> PendingPrediction:
+        """`predict` without the wait: everything is enqueued on the current stream (forward, per-task NMS, cross-task merge, the copy
+        into pinned host memory); the caller may enqueue the next batch before asking for `.result()`. The forward's plan-owned
+        outputs are consumed by the NMS launches of the same call, in stream order, before a later forward can overwrite them."""
+        conf_thres = self.conf_thres if conf_thres is None else conf_thres
+        iou_thres = self.iou_thres if iou_thres is None else iou_thres
+        iou_bt = self.iou_thres_between_tasks if iou_thres_between_tasks is None else iou_thres_between_tasks
         all_out = self.model(tensor.to(self.device), zero_copy=True)  # consumed by NMS right away
-        return self.postprocess({t: o[0] for t, o in all_out.items()}, tuple(tensor.shape[2:]), original_shape, max_det, agnostic_nms,
-                                conf_thres, iou_thres, iou_bt)
+        return self.postprocess_async({t: o[0] for t, o in all_out.items()}, tuple(tensor.shape[2:]), original_shape, max_det, agnostic_nms,
+                                      conf_thres, iou_thres, iou_bt)
+
+    def predict_stream(self, batches, depth: int = 2, **kwargs):
+        """Generator over an iterable of batches -- tensors, or (tensor, original_shape) pairs -- yielding `predict`'s result for each, in
+        order, with up to `depth` batches in flight: the result dicts of batch i are built while the GPU runs batch i + 1."""
+        from collections import deque
+
+        assert depth >= 1
+        pending = deque()
+        for b in batches:
+            tensor, shape = b if isinstance(b, (tuple, list)) else (b, None)
+            pending.append(self.predict_async(tensor, original_shape=shape, **kwargs))
+            while len(pending) >= depth + 1:
+                yield pending.popleft().result()
+        while pending:
+            yield pending.popleft().result()
 
     def postprocess(self, y_per_task: Dict[str, torch.Tensor], net_shape, original_shape=None, max_det=300, agnostic_nms=False,
                     conf_thres=0.25, iou_thres=0.45, iou_thres_between_tasks=0.8) -> List[List[Dict]]:
+        return self.postprocess_async(y_per_task, net_shape, original_shape, max_det, agnostic_nms, conf_thres, iou_thres, iou_thres_between_tasks).result()
+
+    def postprocess_async(self, y_per_task: Dict[str, torch.Tensor], net_shape, original_shape=None, max_det=300, agnostic_nms=False,
+                          conf_thres=0.25, iou_thres=0.45, iou_thres_between_tasks=0.8) -> PendingPrediction:
         from . import ops
 
         tasks = list(y_per_task.keys())
@@ -110,18 +172,19 @@ class CerberusDetInference:
                 sc.append([gain, (net_shape[1] - shp[1] * gain) / 2, (net_shape[0] - shp[0] * gain) / 2, shp[0], shp[1]])
             scale = torch.tensor(sc, dtype=torch.float32, device=dev)
         out, cnt = ops.merge_tasks(rows, cnts, offs, iou_thres_between_tasks, scale)
-        out, cnt = out.cpu(), cnt.cpu().tolist()
-        bounds = []
-        for t in tasks:
-            ids = self.categories_inds_map[t]
-            bounds.append((min(ids.values()), max(ids.values()), t))
-        results = []
-        for i in range(bs):
-            img = []
-            for row in out[i, :cnt[i]].tolist():
-                c = int(row[5])
-                task = next((tn for lo, hi, tn in bounds if lo <= c <= hi), "unknown")
-                img.append({"box": [int(v) for v in row[:4]], "score": float(row[4]), "label": c, "label_name": self.all_class_names[c],
-                            "task": task})
-            results.append(img)
-        return results
+        h_out = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        h_cnt = torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True)
+        h_out.copy_(out, non_blocking=True)
+        h_cnt.copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        st = torch.cuda.current_stream(dev)
+        out.record_stream(st)
+        cnt.record_stream(st)
+        if getattr(self, "_task_of_label", None) is None:  # global label id -> task name (cerberusdet_inference.py:72-83 get_task_by_label)
+            task_of = ["unknown"] * len(self.all_class_names)
+            for t, ids in self.categories_inds_map.items():
+                for g in ids.values():
+                    task_of[g] = t
+            self._task_of_label = task_of
+        return PendingPrediction(h_out, h_cnt, ev, self.all_class_names, self._task_of_label)

@@ -433,6 +433,15 @@ def test_inference_api_predict_matches_reference_golden(tmp_path):
     x = torch.from_numpy(synth.det_image(mmeta["seed"], mmeta["bs"], mmeta["imgsz"]))
     out = api.predict(x, original_shape=(48, 64))
     assert len(out) == mmeta["bs"] and all(isinstance(r, list) for r in out)
+    # predict_async / predict_stream (several batches in flight, dicts built under the next batch's GPU work): same results, same order
+    xs = [torch.from_numpy(synth.det_image(mmeta["seed"] + k, mmeta["bs"], mmeta["imgsz"])) for k in range(5)]
+    one_by_one = [api.predict(xk, original_shape=(48, 64)) for xk in xs]
+    assert sum(len(r) for res_k in one_by_one for r in res_k) > 0 and one_by_one[0] == out and one_by_one[1] != out
+    pend = [api.predict_async(xk, original_shape=(48, 64)) for xk in xs]  # all five enqueued before the first result is read
+    assert [p.result() for p in pend] == one_by_one and all(p.ready() for p in pend)
+    for depth in (1, 2, 4):
+        assert list(api.predict_stream(((xk, (48, 64)) for xk in xs), depth=depth)) == one_by_one
+    assert list(api.predict_stream(xs[:2])) == [api.predict(xk) for xk in xs[:2]]  # bare tensors: no rescale
     y_direct = m.eval()(x.to(DEV))
     y_loaded = api.model(x.to(DEV))
     for t in mmeta["tasks"]:
