@@ -170,7 +170,8 @@ class CerberusDetInference:
             for shp in shapes:
                 gain = min(net_shape[0] / shp[0], net_shape[1] / shp[1])
                 sc.append([gain, (net_shape[1] - shp[1] * gain) / 2, (net_shape[0] - shp[0] * gain) / 2, shp[0], shp[1]])
-            scale = torch.tensor(sc, dtype=torch.float32, device=dev)
+            # pinned + non_blocking: a pageable host->device copy would wait for everything already enqueued on the stream (the forward)
+            scale = torch.tensor(sc, dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
         out, cnt = ops.merge_tasks(rows, cnts, offs, iou_thres_between_tasks, scale)
         h_out = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
         h_cnt = torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True)

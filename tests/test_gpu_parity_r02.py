@@ -209,6 +209,16 @@ def test_gpu_letterbox_preprocess_bit_exact_vs_oracle(half):
     g = got.cpu().numpy()
     for i in range(len(images)):
         assert np.array_equal(g[i], want[i]), (shapes[i], float(np.abs(g[i].astype(np.float32) - want[i].astype(np.float32)).max()))
+    # with work pending on the caller's stream (predict_stream keeps batches in flight) the upload takes the staged form -- one pinned
+    # buffer, one asynchronous copy, the kernel on the pre-processor's side stream: same bits, several times over (the staging ring rotates)
+    busy = torch.randn(1 << 28, device=DEV)  # 1 GiB: a pass over it takes ~0.4 ms
+    for _ in range(5):
+        for _ in range(60):
+            busy.mul_(1.0001)
+        assert not torch.cuda.current_stream().query()
+        again = pre.preprocess(images, torch.device(DEV))
+        assert pre._stage, "the staged upload was not taken"
+        assert torch.equal(again, got)
     # auto=True (minimum rectangle): same-shape images give a non-square batch
     pre2 = CerberusPreprocessor(img_size=640, stride=32, half=half, auto=True)
     a = pre2.preprocess(images[:1] * 2, torch.device(DEV))
