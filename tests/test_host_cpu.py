@@ -230,3 +230,39 @@ def test_tiled_kernels_refuse_buffers_their_32_bit_addressing_cannot_reach():
     wok, wbig = desc(32, 80, 80, 320, 320, 3, 1), desc(800, 80, 80, 320, 320, 3, 1)
     assert lib.cdet_conv2d_wgrad_ws_elems(C.byref(wok)) > 0
     assert lib.cdet_conv2d_wgrad_groupable(C.byref(wok)) == 1 and lib.cdet_conv2d_wgrad_groupable(C.byref(wbig)) == 0
+
+
+def test_pending_prediction_builds_the_reference_result_dicts():
+    """`PendingPrediction.result()` (host side of CerberusDetInference.predict / predict_async / predict_stream): merged rows [bs, max, 6] +
+    counts -> per image the reference's list of {"box", "score", "label", "label_name", "task"} (cerberusdet_inference.py:150-186): boxes
+    truncated to int like the reference's int(), the score as the fp32 value, the task found from the global label id; only the first
+    `count` rows of an image are read. No GPU: the event is a stand-in."""
+    from cerberusdet_amd.cerberusdet_inference import CerberusDetInference, PendingPrediction
+
+    class _Ev:
+        waited = 0
+
+        def synchronize(self):
+            self.waited += 1
+
+        def query(self):
+            return True
+
+    names = {"voc": ["a", "b", "c"], "animals": ["x", "y"]}
+    cmap, all_names = CerberusDetInference._get_categories_map(names)
+    assert cmap == {"voc": {0: 0, 1: 1, 2: 2}, "animals": {0: 3, 1: 4}} and all_names == ["a", "b", "c", "x", "y"]
+    task_of = ["voc"] * 3 + ["animals"] * 2
+    rows = torch.zeros(2, 4, 6)
+    rows[0, 0] = torch.tensor([10.0, 20.0, 110.0, 220.0, 0.75, 4.0])
+    rows[0, 1] = torch.tensor([0.0, 1.0, 2.0, 3.0, 0.3333333, 1.0])
+    rows[0, 2] = torch.tensor([9.0, 9.0, 9.0, 9.0, 0.9, 2.0])  # beyond the count: must not appear
+    rows[1, 0] = torch.tensor([5.0, 6.0, 7.0, 8.0, 0.5, 0.0])
+    ev = _Ev()
+    p = PendingPrediction(rows, torch.tensor([2, 1], dtype=torch.int32), ev, all_names, task_of)
+    assert p.ready()
+    res = p.result()
+    assert res == [[{"box": [10, 20, 110, 220], "score": 0.75, "label": 4, "label_name": "y", "task": "animals"},
+                    {"box": [0, 1, 2, 3], "score": float(torch.tensor(0.3333333).item()), "label": 1, "label_name": "b", "task": "voc"}],
+                   [{"box": [5, 6, 7, 8], "score": 0.5, "label": 0, "label_name": "a", "task": "voc"}]]
+    assert all(isinstance(v, int) for v in res[0][0]["box"]) and isinstance(res[0][0]["label"], int) and isinstance(res[0][0]["score"], float)
+    assert p.result() is res and ev.waited == 1  # built once
