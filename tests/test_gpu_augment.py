@@ -80,3 +80,9 @@ def test_augmenting_dataset_yields_the_reference_batch_dict(tmp_path):
         assert float((b["img"] != 114).float().mean()) > 0.3
     again = list(TaskDataset(str(tmp_path / "images"), s, 4, 20, DEV, shuffle=False, augment=True, seed=11))
     assert torch.equal(again[0]["img"], batches[0]["img"]) and torch.equal(again[0]["bboxes"], batches[0]["bboxes"])  # seeded: reproducible
+    # hyp["perspective"] != 0 travels from the hyper-parameter dict to the kernel's warpPerspective branch (augmentations.py:152-153)
+    persp = list(TaskDataset(str(tmp_path / "images"), s, 4, 20, DEV, shuffle=False, augment=True, seed=11, hyp={"perspective": 0.001}))
+    assert persp[0]["img"].shape == batches[0]["img"].shape and not torch.equal(persp[0]["img"], batches[0]["img"])
+    assert float((persp[0]["img"] != 114).float().mean()) > 0.3
+    if persp[0]["bboxes"].numel():
+        assert float(persp[0]["bboxes"].min()) >= 0 and float(persp[0]["bboxes"].max()) <= 1
