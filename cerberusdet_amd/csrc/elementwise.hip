@@ -789,7 +789,15 @@ __global__ __launch_bounds__(256) void pool5_bwd_kernel(const uint16_t* __restri
     __shared__ unsigned s_rarg[TI * TW];  // first kx of the row maximum, 4 bits per channel
     __shared__ u32x4 s_g[TW * TW];
     __shared__ unsigned long long s_idx[TW * TW];
-    int b = blockIdx.x;
+    // Consecutive block ids go to consecutive XCDs, each with an L2 of its own. The eight channel vectors that share a 128-byte line of a
+    // pixel row (the 16-byte pieces of neighbouring blocks) are therefore given to blocks of ONE XCD: logical id = position inside the XCD's
+    // contiguous share of the grid (the mapping of wgrad_gemm_kernel) -- with the plain id every XCD fetched every line (197 MB per launch
+    // for 16 MB of tensors, profiles/r04_pmc_traffic.json).
+    int b;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7, j = blockIdx.x >> 3;
+        b = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + j;
+    }
     const int c = (b % CV) * 8;
     b /= CV;
     const int x0 = (b % tiles_x) * T;
