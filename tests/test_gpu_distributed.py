@@ -362,11 +362,18 @@ def test_peer_exchange_kernel_virtual_ranks_on_streams(monkeypatch):
 
     monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_virtual_ranks_worker, args=(q,))
-    p.start()
-    res = q.get(timeout=600)
-    p.join(60)
+    # Whether three streams of a process get three hardware queues that the GPU runs side by side is the runtime's decision (queues of all
+    # processes on the box share the hardware slots); a time-out of the very precondition -- not a wrong sum, which is never retried -- gets
+    # two more tries in fresh processes (seen once in ~10 full-suite runs).
+    for attempt in range(3):
+        q = ctx.Queue()
+        p = ctx.Process(target=_virtual_ranks_worker, args=(q,))
+        p.start()
+        res = q.get(timeout=600)
+        p.join(60)
+        if res == "ok" or "did not run side by side" not in res:
+            break
+        print(f"attempt {attempt}: the three streams were not concurrent; retrying in a fresh process")
     assert res == "ok", res
 
 
