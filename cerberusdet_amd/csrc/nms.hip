@@ -194,10 +194,19 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 }
 
 constexpr int KEPT_MAX = 2048;  // LDS list of kept boxes (max_det is clamped to this)
-__global__ __launch_bounds__(64) void nms_greedy_kernel(const NmsArgs a) {
+// Greedy suppression, one workgroup of FOUR waves per image over tiles of 64 score-sorted candidates. All waves hold the tile (lane = candidate).
+//   1. against the boxes kept so far: wave w tests kept boxes w, w + 4, ... -- "suppressed by ANY earlier kept box" is an OR, so the split changes
+//      nothing; the four dead masks meet in LDS;
+//   2. inside the tile: row `lane` of the suppression matrix (later candidates this one would suppress), wave w computing columns 16 w .. 16 w + 15;
+//   3. wave 0 walks the tile in order (keep the first alive candidate, clear its row from the alive mask, ...) exactly as the one-wave form did,
+//      appends the kept boxes to the LDS list and writes the output rows.
+// One wave doing all of 1 and 2 spent ~11 k clocks per tile (a division per pair: torchvision's iou > thr is kept as it is); four waves ~3 k.
+__global__ __launch_bounds__(256) void nms_greedy_kernel(const NmsArgs a) {
     __shared__ float kx1[KEPT_MAX], ky1[KEPT_MAX], kx2[KEPT_MAX], ky2[KEPT_MAX], kar[KEPT_MAX];
+    __shared__ unsigned long long s_dead[4], s_row[4][64];
+    __shared__ int s_nkept;
     const int n = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int cnt = a.count[n];
     if (cnt > a.max_nms) cnt = a.max_nms;  // general.py:459
     const Cand* cand = a.cand + (int64_t)n * a.max_cand;
@@ -210,43 +219,53 @@ __global__ __launch_bounds__(64) void nms_greedy_kernel(const NmsArgs a) {
         const bool have = i < cnt;
         Cand c;
         c.x1 = c.y1 = c.x2 = c.y2 = c.conf = c.cls = 0.f;
+        c.anchor = 0u;
         if (have) c = cand[(uint32_t)(keys[i] & 0xffffffffull)];
         const float off = a.agnostic ? 0.f : c.cls * MAX_WH;
         const float bx1 = c.x1 + off, by1 = c.y1 + off, bx2 = c.x2 + off, by2 = c.y2 + off;
         const float area = (bx2 - bx1) * (by2 - by1);
-        bool alive = have;
-        for (int k = 0; k < nkept && alive; ++k)
-            if (iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], bx1, by1, bx2, by2, area, thr)) alive = false;
-        // intra-tile: row `lane` of the suppression matrix = later lanes this box would suppress
+        bool dead = false;
+        for (int k = wave; k < nkept && !dead; k += 4)
+            if (iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], bx1, by1, bx2, by2, area, thr)) dead = true;
+        const unsigned long long dm = __ballot(dead);
+        if (lane == 0) s_dead[wave] = dm;
+        // intra-tile: row `lane` of the suppression matrix = later lanes this box would suppress (this wave's 16 columns)
         unsigned long long row = 0ull;
-        for (int j = 0; j < 64; ++j) {
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = wave * 16 + jj;
             const float ox1 = __shfl(bx1, j), oy1 = __shfl(by1, j), ox2 = __shfl(bx2, j), oy2 = __shfl(by2, j), oar = __shfl(area, j);
             if (j > lane && iou_gt(bx1, by1, bx2, by2, area, ox1, oy1, ox2, oy2, oar, thr)) row |= (1ull << j);
         }
-        unsigned long long alive_mask = __ballot(alive);
-        unsigned long long keep_mask = 0ull;
-        int kept_here = 0;
-        for (int j = 0; j < 64; ++j) {
-            if (!((alive_mask >> j) & 1ull)) continue;
-            if (nkept + kept_here >= a.max_det) break;
-            keep_mask |= (1ull << j);
-            ++kept_here;
-            const unsigned long long rj = __shfl(row, j);  // uniform j: broadcast lane j's row
-            alive_mask &= ~rj;
-        }
-        if ((keep_mask >> lane) & 1ull) {
-            const int slot = nkept + __popcll(keep_mask & ((1ull << lane) - 1ull));
-            if (slot < KEPT_MAX) {
-                kx1[slot] = bx1; ky1[slot] = by1; kx2[slot] = bx2; ky2[slot] = by2; kar[slot] = area;
-            }
-            float* r = rows + (int64_t)slot * 6;
-            r[0] = c.x1; r[1] = c.y1; r[2] = c.x2; r[3] = c.y2; r[4] = c.conf; r[5] = c.cls;
-            if (a.out_anchor != nullptr) a.out_anchor[(int64_t)n * a.max_det + slot] = (int)c.anchor;
-        }
-        nkept += kept_here;
+        s_row[wave][lane] = row;
         __syncthreads();
+        if (wave == 0) {
+            row = s_row[0][lane] | s_row[1][lane] | s_row[2][lane] | s_row[3][lane];
+            unsigned long long alive_mask = __ballot(have) & ~(s_dead[0] | s_dead[1] | s_dead[2] | s_dead[3]);
+            unsigned long long keep_mask = 0ull;
+            int kept_here = 0;
+            for (int j = 0; j < 64; ++j) {
+                if (!((alive_mask >> j) & 1ull)) continue;
+                if (nkept + kept_here >= a.max_det) break;
+                keep_mask |= (1ull << j);
+                ++kept_here;
+                const unsigned long long rj = __shfl(row, j);  // uniform j: broadcast lane j's row
+                alive_mask &= ~rj;
+            }
+            if ((keep_mask >> lane) & 1ull) {
+                const int slot = nkept + __popcll(keep_mask & ((1ull << lane) - 1ull));
+                if (slot < KEPT_MAX) {
+                    kx1[slot] = bx1; ky1[slot] = by1; kx2[slot] = bx2; ky2[slot] = by2; kar[slot] = area;
+                }
+                float* r = rows + (int64_t)slot * 6;
+                r[0] = c.x1; r[1] = c.y1; r[2] = c.x2; r[3] = c.y2; r[4] = c.conf; r[5] = c.cls;
+                if (a.out_anchor != nullptr) a.out_anchor[(int64_t)n * a.max_det + slot] = (int)c.anchor;
+            }
+            if (lane == 0) s_nkept = nkept + kept_here;
+        }
+        __syncthreads();
+        nkept = s_nkept;
     }
-    if (lane == 0) a.out_count[n] = nkept;
+    if (threadIdx.x == 0) a.out_count[n] = nkept;
 }
 
 static inline int next_pow2(int v) {
@@ -471,7 +490,7 @@ extern "C" int cdet_nms_batched_idx(const cdet_nms_desc* d, const void* pred, fl
     CDET_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_sort_kernel, dim3(d->N), dim3(1024), 0, s, a);
     CDET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(d->N), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(d->N), dim3(256), 0, s, a);
     CDET_LAUNCH_CHECK();
     return 0;
 }
