@@ -66,6 +66,8 @@ struct NmsArgs {
     unsigned long long* keys;  // [N][cap2]
     int cap2;
     int* count;             // [N]
+    int* seg_count;         // [N][n_seg]: candidates per anchor segment (filter pass 1 -> the slot base of pass 2)
+    int n_seg, seg_len;     // anchors are split into n_seg runs of seg_len (a multiple of 256)
     float* out_rows;
     int* out_count;
     int* out_anchor;        // optional [N][max_det]
@@ -78,22 +80,35 @@ __device__ __forceinline__ bool class_allowed(const NmsArgs& a, int c) {
     return false;
 }
 
+// One workgroup per (image, anchor segment). The compacted list keeps the ANCHOR order (its position is the tie rule of the sort), so a
+// segment needs the number of candidates in front of it: pass 1 (WRITE = false) counts per segment, pass 2 (WRITE = true) starts from the
+// sum of the earlier segments' counts and writes. One workgroup walking all 8400 anchors of an image in 33 dependent rounds took 290 us.
+constexpr int NMS_SEG_MAX = 32;
+template <bool WRITE>
 __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs a) {
     __shared__ int sh_wave[4];
     __shared__ int sh_base;
-    const int n = blockIdx.x;
+    const int n = blockIdx.x / a.n_seg, seg = blockIdx.x - n * a.n_seg;
     const int A = a.A, nc = a.nc;
     const float thr = round_to(a.conf_thres, a.dtype);
     const int64_t img = (int64_t)n * (4 + nc) * A;
     Cand* out = a.cand + (int64_t)n * a.max_cand;
-    if (threadIdx.x == 0) sh_base = 0;
+    if (threadIdx.x == 0) {
+        int b = 0;
+        if (WRITE)
+            for (int s = 0; s < seg; ++s) b += a.seg_count[n * a.n_seg + s];
+        sh_base = b;
+    }
     __syncthreads();
-    for (int a0 = 0; a0 < A; a0 += 256) {
+    const int first = sh_base;
+    const int a_end = min(A, (seg + 1) * a.seg_len);
+    __syncthreads();
+    for (int a0 = seg * a.seg_len; a0 < a_end; a0 += 256) {
         const int an = a0 + threadIdx.x;
         int cnt = 0;
         float best = -INFINITY;
         int bestc = 0;
-        if (an < A) {
+        if (an < a_end) {
             for (int c = 0; c < nc; ++c) {
                 const float s = load_elem(a.pred, img + (int64_t)(4 + c) * A + an, a.dtype);
                 if (s > best) {  // first maximum wins, like torch.max(1)
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs a) {
         int total;
         const int excl = block_exclusive_scan(cnt, sh_wave, total);
         const int base = sh_base;
-        if (cnt > 0) {
+        if (WRITE && cnt > 0) {
             const float cx = load_elem(a.pred, img + 0 * (int64_t)A + an, a.dtype), cy = load_elem(a.pred, img + 1 * (int64_t)A + an, a.dtype);
             const float w = load_elem(a.pred, img + 2 * (int64_t)A + an, a.dtype), h = load_elem(a.pred, img + 3 * (int64_t)A + an, a.dtype);
             const float hw = round_to(w / 2.f, a.dtype), hh = round_to(h / 2.f, a.dtype);
@@ -142,7 +157,10 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs a) {
         if (threadIdx.x == 0) sh_base = base + total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.count[n] = sh_base < a.max_cand ? sh_base : a.max_cand;
+    if (threadIdx.x == 0) {
+        if (!WRITE) a.seg_count[n * a.n_seg + seg] = sh_base - first;
+        else if (seg == a.n_seg - 1) a.count[n] = sh_base < a.max_cand ? sh_base : a.max_cand;
+    }
 }
 
 // key = (~ord(conf) << 32) | pos : ascending sort == conf descending, original position ascending
@@ -463,7 +481,8 @@ static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 extern "C" int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d) {
     if (!d) return -1;
     const int cap2 = next_pow2(d->max_cand);
-    return align256((int64_t)d->N * d->max_cand * sizeof(Cand)) + align256((int64_t)d->N * cap2 * 8) + align256((int64_t)d->N * 4);
+    return align256((int64_t)d->N * d->max_cand * sizeof(Cand)) + align256((int64_t)d->N * cap2 * 8) + align256((int64_t)d->N * 4) +
+           align256((int64_t)d->N * NMS_SEG_MAX * 4);
 }
 
 extern "C" int cdet_nms_batched_idx(const cdet_nms_desc* d, const void* pred, float* out_rows, int32_t* out_count, int32_t* out_anchor, void* ws,
@@ -483,10 +502,22 @@ extern "C" int cdet_nms_batched_idx(const cdet_nms_desc* d, const void* pred, fl
     char* p = (char*)ws;
     a.cand = (Cand*)p; p += align256((int64_t)d->N * d->max_cand * sizeof(Cand));
     a.keys = (unsigned long long*)p; p += align256((int64_t)d->N * a.cap2 * 8);
-    a.count = (int*)p;
+    a.count = (int*)p; p += align256((int64_t)d->N * 4);
+    a.seg_count = (int*)p;
+    // enough segments to put a few workgroups on every CU, each a whole number of 256-anchor rounds
+    int n_seg = (1024 + d->N - 1) / d->N;
+    if (n_seg > NMS_SEG_MAX) n_seg = NMS_SEG_MAX;
+    const int rounds = (d->A + 255) / 256;
+    if (n_seg > rounds) n_seg = rounds;
+    a.seg_len = (rounds + n_seg - 1) / n_seg * 256;
+    a.n_seg = (d->A + a.seg_len - 1) / a.seg_len;
     a.out_rows = out_rows; a.out_count = out_count; a.out_anchor = out_anchor;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_filter_kernel, dim3(d->N), dim3(256), 0, s, a);
+    if (a.n_seg > 1) {
+        hipLaunchKernelGGL(nms_filter_kernel<false>, dim3(d->N * a.n_seg), dim3(256), 0, s, a);
+        CDET_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(nms_filter_kernel<true>, dim3(d->N * a.n_seg), dim3(256), 0, s, a);
     CDET_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_sort_kernel, dim3(d->N), dim3(1024), 0, s, a);
     CDET_LAUNCH_CHECK();

@@ -32,7 +32,7 @@ def main():
         print("intervals ms:", np.round(iv, 1).tolist())
 
     CI.CerberusDetInference.predict_stream = logged
-    out = bench.predict_e2e(model, device)
+    out = bench.predict_e2e(model, device)  # (in-process: the probe wants the patched predict_stream)
     print({k: v for k, v in out.items() if "images" in k}, out["infer_e2e"]["pipelined_ms_per_batch"])
 
 
