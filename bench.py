@@ -519,6 +519,7 @@ def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
                 model.hyp = hyp
                 model = model.to(device).train()
                 tr = Averaging(device, model, hyp, tasks, epochs=100, nb=1000, rank=vr, world_size=virtual_ranks, sync_bn=True)
+                tr.trace_cb = lambda kind, key, task: log.append(("hook", str(key), task))  # host position of every completed backward unit
                 per_step = []
                 for i, active in enumerate(patterns):
                     log.clear()
@@ -529,12 +530,26 @@ def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
                 del tr, model
             same = all(s_ == seqs[0] for s_ in seqs[1:])
             ok = ok and same
-            out["plans"][cfg_name] = {"identical_on_all_ranks": same,
-                                      "steps": [{"active_tasks": a, "collectives": len(st), "bytes": sum(b for b, _, _ in st),
-                                                 "streams_used": len({s_ for _, s_, _ in st}),
-                                                 "syncbn_exchanges": sum(1 for _, _, g_ in st if not g_),
-                                                 "collectives_with_peer_exchange": sum(1 for _, _, g_ in st if g_)}
-                                                for a, st in zip(patterns, seqs[0])]}
+
+            def overlap(st):
+                """Gradient bytes whose all-reduce is enqueued BEFORE the last backward launch of the iteration: everything in front of the last
+                unit hook (that hook fires behind the final launches of the last pass -- the stem's row; what it sends can overlap nothing)."""
+                last = max(i for i, e in enumerate(st) if e[0] == "hook")
+                grad = [(i, e[0]) for i, e in enumerate(st) if e[0] != "hook" and e[2]]
+                tot = sum(b for _, b in grad)
+                return sum(b for i, b in grad if i < last), tot
+
+            steps = []
+            for a, st in zip(patterns, seqs[0]):
+                coll = [e for e in st if e[0] != "hook"]
+                early, tot = overlap(st)
+                steps.append({"active_tasks": a, "collectives": len(coll), "bytes": sum(b for b, _, _ in coll),
+                              "streams_used": len({s_ for _, s_, _ in coll}),
+                              "syncbn_exchanges": sum(1 for _, _, g_ in coll if not g_),
+                              "collectives_with_peer_exchange": sum(1 for _, _, g_ in coll if g_),
+                              "gradient_bytes": tot, "gradient_bytes_enqueued_before_last_backward_launch": early,
+                              "gradient_overlap_frac": round(early / max(tot, 1), 4)})
+            out["plans"][cfg_name] = {"identical_on_all_ranks": same, "steps": steps}
     finally:
         dist.all_reduce = real
         dist.destroy_process_group()

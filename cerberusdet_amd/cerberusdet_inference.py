@@ -85,9 +85,13 @@ class CerberusDetInference:
     def __init__(self, weights, device: str = "", conf_thres: float = 0.25, iou_thres: float = 0.45, iou_thres_between_tasks: float = 0.8,
                  half: bool = False, img_size: int = 640):
         self.conf_thres, self.iou_thres, self.iou_thres_between_tasks = conf_thres, iou_thres, iou_thres_between_tasks
+        if device and torch.device(device).type != "cuda":
+            # the reference would run on the CPU here (cerberusdet_inference.py:30-36, select_device); this engine has no CPU path
+            raise RuntimeError(f"CerberusDetInference (cerberusdet_amd): device={device!r} is not supported -- the engine runs on an MI355X only "
+                               "(pass '' or 'cuda:N')")
         if not torch.cuda.is_available():
             raise RuntimeError("CerberusDetInference (cerberusdet_amd) needs an MI355X: there is no CPU path")
-        self.device = torch.device(device if device and device != "cpu" else "cuda:0")
+        self.device = torch.device(device if device else "cuda:0")
         self.half = half
         self.model: CerberusDet = attempt_load(weights, map_location=self.device)
         if self.half:

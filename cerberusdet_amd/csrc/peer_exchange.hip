@@ -9,7 +9,8 @@
 //   2. spins (bounded) until all `world` flags of the slot in its OWN buffer carry the epoch, then sums the `world` rows in rank order -- the same
 //      order on every rank, so all ranks hold bit-identical sums (RCCL's ring order is not specified; for two ranks a + b is the same either way).
 // Slots are double-buffered by epoch parity: a rank can only reach epoch e + 2 of a slot after every peer has finished reading epoch e (it needs their
-// e + 1 flags first). A spin that exceeds its budget raises an error word instead of hanging the GPU.
+// e + 1 flags first). A wait that exceeds its (wall-clock) budget poisons the vector with NaN and raises a sticky error word instead of hanging the GPU
+// or handing on stale rows.
 #include <stdlib.h>
 #include <string.h>
 
@@ -41,12 +42,18 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(float* __restrict__
     }
     if (phase == 1) return;
     // 2. all rows of the slot in MY buffer
+    __shared__ int timed_out;
+    if (t == 0) timed_out = 0;
+    __syncthreads();
     if (t < world) {
         const unsigned* f = reinterpret_cast<const unsigned*>(peers[rank]) + flag_off + par * world + t;
-        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long t0 = wall_clock64();  // constant-rate counter (s_memrealtime), not the shader clock: the budget is wall time
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (__builtin_readcyclecounter() - t0 > spin) {
-                __hip_atomic_store(err, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (wall_clock64() - t0 > spin) {
+                // sticky: the first time-out of the run stays in the error word (the host raises wherever it looks next, peer_exchange.py::check)
+                unsigned expect = 0u;
+                __hip_atomic_compare_exchange_strong(err, &expect, 1u + (unsigned)t, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                timed_out = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -54,6 +61,11 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(float* __restrict__
     }
     __syncthreads();
     __threadfence_system();
+    if (timed_out) {
+        // never hand stale rows (epoch e - 2) on as statistics: poison the vector so that the loss of this very iteration shows it
+        for (int i = t; i < n; i += 256) vec[i] = __builtin_nanf("");
+        return;
+    }
     const float* src = reinterpret_cast<const float*>(peers[rank]) + data_off + (long long)par * world * n;
     for (int i = t; i < n; i += 256) {
         float s = 0.f;
@@ -130,8 +142,14 @@ extern "C" int cdet_peer_allreduce(float* vec, int32_t n, const void* peer_table
     CDET_CHECK_ARG(phase >= 0 && phase <= 2, "cdet_peer_allreduce: phase must be 0 (whole exchange), 1 (publish) or 2 (collect)");
     static unsigned long long spin = 0;
     if (!spin) {
-        const char* e = getenv("CDET_PEER_SPIN_MS");  // wait budget per exchange (default 10 s)
-        spin = (unsigned long long)(e ? atoll(e) : 10000) * 2000000ull;  // ~2 GHz shader clock
+        // wait budget per exchange in wall time. Default 10 min, the order of a collective library's watchdog: ordinary rank skew (a host-bound
+        // loader, a plan compile on one rank, checkpoint IO) must never trip it -- a process group would simply have waited.
+        const char* e = getenv("CDET_PEER_SPIN_MS");
+        int dev = 0, khz = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;  // gfx9: 100 MHz
+        (void)hipGetLastError();
+        spin = (unsigned long long)(e ? atoll(e) : 600000) * (unsigned long long)khz;
     }
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vec, n, (const uint64_t*)peer_table, world, rank,
                        (long long)data_off, (long long)flag_off, epoch, (unsigned*)err, phase, spin);

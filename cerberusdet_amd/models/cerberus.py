@@ -514,7 +514,7 @@ class CerberusDet(nn.Module):
                 cap = int(os.environ.get("CDET_MAX_EVAL_PLANS", "6"))
                 evals = [k for k in self._plans if k[3] is False]
                 for k in evals[:max(len(evals) - cap + 1, 0)]:
-                    del self._plans[k]
+                    self._plans.pop(k).release()
             plan = Plan(self, tasks, N, H, W, training, self.compute_dtype, img_dtype, dev, frozen=frozen)
         self._plans[key] = plan  # (re-inserted last: dict order = recency)
         return plan
@@ -530,6 +530,10 @@ class CerberusDet(nn.Module):
         overwrites them, so consume them (NMS, loss) before calling the model again -- CerberusDetInference, val.run and the trainer
         do. Either way a train-mode forward keeps ONE set of saved activations per configuration: call backward() before the next
         forward of the same configuration (autograd_bridge refuses a stale backward)."""
+        if retain_tensors or retain_all:
+            # the reference stores block outputs in self.rep_tensors for its branching-analysis tooling (cerberus.py:866-872); the compiled
+            # launch list keeps no per-block NCHW tensors (Concat / Upsample outputs do not even exist in eval plans)
+            raise NotImplementedError("retain_tensors / retain_all (rep_tensors of the reference's branching analysis) are not supported by cerberusdet_amd")
         if task_ids is None and hasattr(self, "cur_task"):
             task_ids = self.cur_task
         elif task_ids is None:

@@ -8,8 +8,9 @@ slot, publish the epoch, wait for everybody's epoch in my own buffer, sum the ro
 sums on every rank. The gradient all-reduce stays on RCCL (hundreds of MB per iteration: bandwidth-bound, what RCCL is for).
 
 Slots are handed out by a bump allocator in the order the plan compiler asks for them -- a deterministic function of the model structure, hence the same on
-every rank (bench.py --dry-comm asserts that order). CDET_SYNCBN_PEER=0 keeps the RCCL form (the tested fallback; also taken when the IPC set-up fails on
-any rank, e.g. ranks on different nodes)."""
+every rank (bench.py --dry-comm asserts that order); a slot is keyed by (task set, layer(s), direction), so recompiled plans reuse theirs. OPT-IN:
+CDET_SYNCBN_PEER=1 (round 5: until the one-kernel form has run on real peers the default is the process-group form, also taken -- collectively -- when
+the staged IPC set-up fails on any rank, e.g. ranks on different nodes)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -21,7 +22,18 @@ import torch.distributed as dist
 from . import _lib as L
 
 
+def _all_ok(ok: bool, world: int, group) -> bool:
+    """Collective AND of a per-rank flag. Every set-up stage ends with one, on EVERY rank whatever happened locally, so that a rank whose stage
+    failed never leaves its peers inside a collective it will not join (the sequence of collectives is the same on all ranks by construction)."""
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok), group=group)
+    return all(flags)
+
+
 class PeerExchange:
+    """Built in stages by `try_setup` (alloc + export, import, publish): each stage catches its own failure and the ranks agree on the outcome
+    before the next one starts. A directly constructed object (tests, one process = several virtual ranks) is an empty shell until then."""
+
     def __init__(self, device, rank: int, world: int, group=None, capacity_bytes: int = 64 << 20):
         self.lib = L.load()
         dev = torch.device(device)
@@ -33,6 +45,8 @@ class PeerExchange:
         self.hostsync = os.environ.get("CDET_PEER_XCHG_HOSTSYNC", "0") == "1"
         self.n_calls = 0       # exchanges compiled into launch lists (collectives per iteration = those on the executed plans)
         self._bump = 256       # bytes handed out (the first 256 stay zero)
+        self._slots = {}       # key -> (data offset, flag offset, epoch state): a recompiled plan (frozen / unfrozen trunk, another batch shape)
+        #                        reuses the slots of the layers it shares with the plans before it instead of growing the buffer
         # One exchange at a time per rank, in host-enqueue order (what a communicator does for its collectives): an exchange kernel WAITS in the
         # kernel for its peers, so two of them in flight on two streams of one rank could each sit in front of the kernel the other rank's
         # counterpart is waiting for (streams can share a hardware queue) -- a cycle. Chained by an event, the exchanges of a rank run in the
@@ -42,15 +56,22 @@ class PeerExchange:
         self._ext = {}
         self._mine = C.c_void_p()
         self._peers = []
+        self.table = self.err = None
+
+    # ---- set-up stages (each may raise; try_setup turns a failure on ANY rank into a collective fall-back) -------------------------------------
+    def stage_alloc_export(self) -> bytes:
         with torch.cuda.device(self.device):
-            L.check(self.lib.cdet_peer_alloc(capacity_bytes, C.byref(self._mine)), "cdet_peer_alloc")
+            L.check(self.lib.cdet_peer_alloc(self.capacity, C.byref(self._mine)), "cdet_peer_alloc")
             handle = (C.c_ubyte * 64)()
             L.check(self.lib.cdet_peer_export(self._mine, handle), "cdet_peer_export")
-            handles = [None] * world
-            dist.all_gather_object(handles, bytes(handle), group=group)
-            ptrs = []
+            self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return bytes(handle)
+
+    def stage_import(self, handles):
+        ptrs = []
+        with torch.cuda.device(self.device):
             for r, h in enumerate(handles):
-                if r == rank:
+                if r == self.rank:
                     ptrs.append(self._mine.value)
                     continue
                 p = C.c_void_p()
@@ -59,23 +80,28 @@ class PeerExchange:
                 self._peers.append(p)
                 ptrs.append(p.value)
             self.table = torch.tensor(ptrs, dtype=torch.int64).to(self.device)
-            self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
-        # nobody may write into a peer's buffer before that peer has zeroed and published it: one barrier after the hand-shake
-        dist.barrier(group=group)
 
     # ---------------------------------------------------------------------------------------------------------------------------------
-    def make_call(self, t: torch.Tensor):
-        """Launch-list entry (callable taking the raw stream) that SUM-all-reduces the fp32 vector `t` in place over the ranks."""
+    def make_call(self, t: torch.Tensor, key=None):
+        """Launch-list entry (callable taking the raw stream) that SUM-all-reduces the fp32 vector `t` in place over the ranks.
+        key: identity of the exchange (task set, layer(s), direction) -- the same key gets the same slot and continues its epoch count, so the
+        plans a long run compiles (frozen / unfrozen trunk, the odd last batch, multi-scale shapes) do not each take a fresh set of slots. Two
+        exchanges that can be in flight at the same time must not share a key (the task set is part of it: engine.Plan._allreduce_call)."""
         assert t.dtype == torch.float32 and t.is_contiguous() and t.device.type == "cuda" and t.device.index == self.device.index
         n = t.numel()
-        data_bytes, flag_bytes = 2 * self.world * n * 4, 2 * self.world * 4
-        data_off = (self._bump + 255) // 256 * 256
-        flag_off = data_off + data_bytes
-        self._bump = flag_off + flag_bytes
-        if self._bump > self.capacity:
-            raise RuntimeError(f"PeerExchange: {self._bump} bytes of slots exceed the exchange buffer ({self.capacity}); raise CDET_PEER_XCHG_MB")
+        slot = self._slots.get((key, n)) if key is not None else None
+        if slot is None:
+            data_bytes, flag_bytes = 2 * self.world * n * 4, 2 * self.world * 4
+            data_off = (self._bump + 255) // 256 * 256
+            flag_off = data_off + data_bytes
+            if flag_off + flag_bytes > self.capacity:
+                raise RuntimeError(f"PeerExchange: {flag_off + flag_bytes} bytes of slots exceed the exchange buffer ({self.capacity}); raise CDET_PEER_XCHG_MB")
+            self._bump = flag_off + flag_bytes
+            slot = (data_off, flag_off, {"epoch": 0})
+            if key is not None:
+                self._slots[(key, n)] = slot
+        data_off, flag_off, state = slot
         self.n_calls += 1
-        state = {"epoch": 0}
         lib, ptr, tab, err, world, rank = self.lib, t.data_ptr(), self.table.data_ptr(), self.err.data_ptr(), self.world, self.rank
         d_off, f_off = data_off // 4, flag_off // 4
 
@@ -106,10 +132,12 @@ class PeerExchange:
         return call
 
     def check(self):
-        """Raises if an exchange timed out waiting for a peer (host sync)."""
+        """Raises if an exchange timed out waiting for a peer (host sync). The error word is sticky: the kernel that timed out has written NaN
+        into its vector (the loss shows it at once) and every later check raises again -- the run is not recoverable."""
         e = int(self.err.item())
         if e:
-            raise RuntimeError(f"PeerExchange: rank {self.rank} timed out waiting for rank {e - 1} (a rank died, or the ranks enqueue different exchange sequences)")
+            raise RuntimeError(f"PeerExchange: rank {self.rank} timed out waiting for rank {e - 1} (a rank died, or the ranks enqueue different exchange sequences); "
+                               "the statistics of that exchange were poisoned with NaN")
 
     def close(self):
         for p in self._peers:
@@ -121,8 +149,12 @@ class PeerExchange:
 
 
 def try_setup(device, rank: int, world: int, group=None):
-    """PeerExchange on every rank, or None on every rank (RCCL form) when any rank cannot set it up / CDET_SYNCBN_PEER=0."""
-    if world <= 1 or os.environ.get("CDET_SYNCBN_PEER", "1") == "0":
+    """PeerExchange on every rank, or None on every rank (the process-group form). OPT-IN: CDET_SYNCBN_PEER=1 -- the one-kernel exchange has only
+    ever run between virtual ranks / processes sharing one GPU; until it has run on real peers over xGMI the default keeps
+    SyncBatchNorm's statistics on the process group (RCCL), which simply waits where this one has to bound its wait.
+    Every stage below ends in the same collective on every rank, whatever happened locally: a rank whose allocation, IPC import or self-test
+    fails reports it and all ranks fall back together (and release what they had built)."""
+    if world <= 1 or os.environ.get("CDET_SYNCBN_PEER", "0") != "1":
         return None
     # Ranks that SHARE a GPU (tests; never a production layout) are time-sliced by the driver, not run side by side: the in-kernel wait of
     # the one-kernel exchange would only time out. Unless the split form is asked for explicitly (CDET_PEER_XCHG_HOSTSYNC=1), such a group
@@ -136,16 +168,35 @@ def try_setup(device, rank: int, world: int, group=None):
     dist.all_gather_object(idents, ident, group=group)
     if len(set(idents)) < world and os.environ.get("CDET_PEER_XCHG_HOSTSYNC", "0") != "1":
         return None
-    px, ok = None, 1
+
+    def note(stage, e):
+        print(f"[cerberusdet_amd] peer exchange: {stage} failed on rank {rank} ({e}); SyncBatchNorm statistics go over the process group", flush=True)
+
+    px, handle = None, b""
+    # stage 1: allocate + export. The handle gather below doubles as this stage's agreement (an empty handle = "failed here").
     try:
         px = PeerExchange(device, rank, world, group, capacity_bytes=int(os.environ.get("CDET_PEER_XCHG_MB", "64")) << 20)
-    except Exception as e:  # noqa: BLE001 -- any failure means "use RCCL", decided collectively below
-        print(f"[cerberusdet_amd] peer exchange unavailable on rank {rank} ({e}); SyncBatchNorm statistics go over the process group", flush=True)
-        ok = 0
-    if px is not None:
-        # known-answer exchange before anything depends on it: rank r contributes r + 1, every rank must read world (world + 1) / 2.
-        # A mapping that opens but does not carry peer stores (or flags that never become visible) shows up HERE, as a fall-back to the
-        # process group, instead of as timed-out exchanges inside the first training iteration.
+        handle = px.stage_alloc_export()
+    except Exception as e:  # noqa: BLE001 -- any failure means "use the process group", decided collectively
+        note("allocation / export", e)
+        handle = b""
+    handles = [None] * world
+    dist.all_gather_object(handles, handle, group=group)
+    ok = all(len(h) == 64 for h in handles)
+    # stage 2: import the peers' buffers (only when every rank exported one), then agree
+    good = ok
+    if ok:
+        try:
+            px.stage_import(handles)
+        except Exception as e:  # noqa: BLE001
+            note("IPC import", e)
+            good = False
+    ok = _all_ok(good, world, group)
+    # nobody may write into a peer's buffer before that peer has zeroed and published it: the agreement above is that barrier.
+    # stage 3: known-answer exchange before anything depends on the mapping: rank r contributes r + 1, every rank must read world (world + 1) / 2.
+    # A mapping that opens but does not carry peer stores (or flags that never become visible) shows up HERE, not inside the first iteration.
+    good = ok
+    if ok:
         try:
             probe = torch.full((64,), float(rank + 1), dtype=torch.float32, device=px.device)
             with torch.cuda.device(px.device):
@@ -155,13 +206,11 @@ def try_setup(device, rank: int, world: int, group=None):
             if int(px.err.item()) != 0 or not bool((probe == world * (world + 1) / 2).all()):
                 raise RuntimeError(f"known-answer exchange failed (error word {int(px.err.item())}, got {float(probe[0])})")
         except Exception as e:  # noqa: BLE001
-            print(f"[cerberusdet_amd] peer exchange self-test failed on rank {rank} ({e}); SyncBatchNorm statistics go over the process group", flush=True)
-            px.err.zero_()
-            ok = 0
-    flags = [None] * world
-    dist.all_gather_object(flags, ok, group=group)
-    if not all(flags):
+            note("self-test", e)
+            good = False
+    ok = _all_ok(good, world, group)
+    if not ok:
         if px is not None:
-            px.close()
+            px.close()  # the 64 MB buffer and whatever peers were already mapped
         return None
     return px

@@ -62,9 +62,10 @@ class ModelEMA:
 
 
 class GradReducer:
-    """Bucketed gradient all-reduce keyed on the block DAG. One flat fp32 bucket per block; a bucket is reduced (SUM, async)
-    when the last task of the iteration that serves the block has produced its gradients. Device-agnostic (works with gloo
-    on CPU tensors for tests, with RCCL on the GPU)."""
+    """Bucketed gradient all-reduce keyed on the block DAG. One flat fp32 bucket per block, sent as REDUCTION UNITS: the slices that become
+    final at one point of the backward -- every backbone row of block 0, every other block as a whole. A unit is reduced (SUM, async) when the
+    last task of the iteration that serves it has produced its gradients. Device-agnostic (works with gloo on CPU tensors for tests, with RCCL
+    on the GPU)."""
 
     def __init__(self, buckets: Dict[int, torch.Tensor], serving: Dict[int, Sequence[str]], task_order: Sequence[str], group=None):
         self.buckets, self.serving, self.task_order, self.group = buckets, serving, list(task_order), group
@@ -74,36 +75,31 @@ class GradReducer:
         self.handles: List = []
         self.reduced_bytes = 0
         self.skip_blocks = set()  # frozen blocks: no gradient to reduce
-        self.deferred = set()     # blocks whose bucket is complete only after the trainer folded the per-task buckets into it (reduce_deferred)
 
-    def last_task(self, block_idx: int, active_tasks: Optional[Sequence[str]] = None) -> Optional[str]:
-        tasks = [t for t in (active_tasks or self.task_order) if t in self.serving.get(block_idx, ())]
-        return tasks[-1] if tasks else None
+    def unit_done(self, u: dict, task: str, active_tasks: Optional[Sequence[str]], fold) -> bool:
+        """Sequential task passes (one stream, or CPU tensors under gloo): `task` has just produced its gradients of reduction unit `u`
+        (dict(block, main, alts=[(task, bucket)], serving)). Its own bucket of the unit -- every serving task but the first has one -- is folded
+        into the block's bucket right here by `fold(main, alt)` (main += alt; alt = 0): passes run in task order, so the sum builds up as
+        g_A, + g_B, + g_C, the sum one shared buffer would hold. The unit is all-reduced when this was the LAST active task serving it, and is
+        never touched again afterwards. Returns True if the unit was sent."""
+        serving = [t for t in (active_tasks or self.task_order) if t in u["serving"]]
+        if task not in serving or u["block"] in self.skip_blocks:
+            return False
+        for t, alt in u["alts"]:
+            if t == task:
+                fold(u["main"], alt)
+        if task != serving[-1]:
+            return False
+        self.reduce_tensor(u["main"], u["block"])
+        return True
 
-    def on_block_backward(self, block_idx: int, task: str, active_tasks: Optional[Sequence[str]] = None):
-        if not self.enabled or block_idx not in self.buckets or block_idx in self.skip_blocks:
+    def reduce_tensor(self, t: torch.Tensor, block_idx: Optional[int] = None):
+        """All-reduce (SUM, async) one complete slice of a bucket -- a backbone row's share of block 0's bucket, or a whole block -- on the
+        current stream's order. The trainer calls it the moment the slice is final (Averaging._unit_done)."""
+        if not self.enabled or (block_idx is not None and block_idx in self.skip_blocks):
             return
-        if self.last_task(block_idx, active_tasks) != task:
-            return  # a later task of this iteration still adds to the bucket: reduce once, after local summation
-        if block_idx in self.deferred:
-            return  # the trainer reduces it after folding the tasks' buckets (reduce_deferred)
-        b = self.buckets[block_idx]
-        self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self.reduced_bytes += b.numel() * b.element_size()
-
-    def reduce_deferred(self, active_tasks: Optional[Sequence[str]] = None, only_last_task: Optional[str] = None):
-        """All-reduce the buckets of the deferred blocks that an active task serves (only_last_task: just those this task completes)."""
-        if not self.enabled:
-            return
-        for block_idx in sorted(self.deferred):
-            if block_idx not in self.buckets or block_idx in self.skip_blocks:
-                continue
-            last = self.last_task(block_idx, active_tasks)
-            if last is None or (only_last_task is not None and last != only_last_task):
-                continue
-            b = self.buckets[block_idx]
-            self.handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.reduced_bytes += b.numel() * b.element_size()
+        self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.reduced_bytes += t.numel() * t.element_size()
 
     def wait(self):
         for h in self.handles:
@@ -123,8 +119,8 @@ class Averaging:
         self.task_streams = bool(task_streams) and torch.device(device).type == "cuda"
         self.rank, self.world_size = rank, world_size
         model.sync_bn = bool(sync_bn)  # SyncBatchNorm: per-layer statistics all-reduced over the ranks (reference train.py:140-143)
-        # round 4: those small all-reduces as peer-write kernels over HIP IPC (peer_exchange.py) when every rank can map every other
-        # rank's exchange buffer (one node); otherwise -- or with CDET_SYNCBN_PEER=0 -- the process group (RCCL) carries them
+        # round 4: those small all-reduces as peer-write kernels over HIP IPC (peer_exchange.py) when asked for (CDET_SYNCBN_PEER=1) and every
+        # rank can map every other rank's exchange buffer (one node); otherwise the process group (RCCL) carries them
         model._peer_xchg = None
         if sync_bn and world_size > 1 and torch.device(device).type == "cuda":
             import torch.distributed as dist
@@ -188,6 +184,32 @@ class Averaging:
                         off += p.numel()
                     model._alt_pairs.append((flat, alt))
                     self._shared_blocks.add(bi)
+        # Reduction units: the slices of the buckets that become final at one point of the backward -- every backbone ROW of block 0 (rows 9 -> 0
+        # finish in that order; engine.Plan.bwd_sub), every other block as a whole. A unit is folded (per-task buckets -> the block's bucket, task
+        # order) and all-reduced the moment the last task serving it has enqueued its gradients, so the trunk's 124 MB travel under the rest of
+        # the backward instead of behind it (reference: DDP's bucketed all-reduce overlapped with backward, train.py:182-184).
+        self.units: Dict[object, dict] = {}
+        alt_of = {}
+        for flat, alt in model._alt_pairs:
+            alt_of.setdefault(flat.data_ptr(), []).append(alt)
+        for bi, flat in buckets.items():
+            serving = list(self.serving.get(bi, ()))
+            alts = list(zip(serving[1:], alt_of.get(flat.data_ptr(), [])))
+            if bi == 0 and hasattr(model.blocks[0], "model"):
+                off = 0
+                for li, layer in enumerate(model.blocks[0].model):
+                    n = sum(p.numel() for p in layer.parameters())
+                    if n:
+                        self.units[(0, li)] = dict(block=0, main=flat[off:off + n], alts=[(t, a[off:off + n]) for t, a in alts], serving=serving)
+                    off += n
+                assert off == flat.numel(), "block 0's bucket is not the concatenation of its rows' parameters"
+            else:
+                self.units[bi] = dict(block=bi, main=flat, alts=alts, serving=serving)
+        self._unit_events: Dict[tuple, "torch.cuda.Event"] = {}
+        self._unit_count: Dict[object, int] = {}
+        self._in_streams = False
+        self._fold_stream = None
+        self.trace_cb = None
         for k, p in names.items():
             bi = int(k.split(".")[1])
             self.slots_meta.append(dict(p=p, g=model._pgrad[id(p)], mom=torch.zeros_like(p), ema=ema_sd.get(k), group=group_of[id(p)],
@@ -203,7 +225,6 @@ class Averaging:
         self._norm_buf = torch.zeros(1 + 32 * self.n_slots, dtype=torch.float32, device=device)
         self._slot_key = None
         self.reducer = GradReducer(buckets, self.serving, self.task_ids)
-        self.reducer.deferred = set(self._shared_blocks)
         self.group_sizes = [len(g2), len(g0), len(g1)]  # optimizer.param_groups order of the reference: bias, decay, bn
 
     # ---------------------------------------------------------------------------------------------------- schedule
@@ -226,9 +247,47 @@ class Averaging:
             while True:
                 next(g)
         except StopIteration as e:
-            self.model._merge_alt_grads()  # p.grad holds the sum over the passes run so far, as with one shared buffer
-            self.reducer.reduce_deferred(active_tasks, only_last_task=task)
-            return e.value
+            return e.value  # (every unit this pass completed has been folded into p.grad and sent by its hook: _unit_done)
+
+    def _unit_done(self, key, task: str):
+        """Hook behind the backward launches of a reduction unit (a backbone row, or a whole block) of `task`'s pass, on that pass's stream.
+        Sequential passes: fold this task's own bucket of the unit into the block's bucket right here (task order = stream order: g_A, + g_B,
+        + g_C -- the sum one shared buffer would hold), and all-reduce the unit when this was the last active task serving it; a unit is never
+        touched again once it is sent. Task streams: the unit is complete when the LAST serving task's stream has enqueued it (host order is
+        deterministic, hence the same on every rank) -- then, on a side stream behind all serving tasks' events, the per-task buckets are
+        folded in task order and the slice is all-reduced there, while both backward passes run on."""
+        u = self.units.get(key)
+        if self.trace_cb is not None:
+            self.trace_cb("unit", key, task)  # (bench.py --dry-comm: where in the host enqueue order the backward passes stand)
+        if u is None:
+            return
+        active = self._active or self.task_ids
+        serving = [t for t in active if t in u["serving"]]
+        if task not in serving:
+            return
+        bi = u["block"]
+        if bi in self.reducer.skip_blocks:
+            return
+        if not (self._in_streams and u["alts"]):
+            self.reducer.unit_done(u, task, active, lambda main, alt: L.check(self.lib.cdet_accumulate_clear(
+                main.data_ptr(), alt.data_ptr(), alt.numel(), torch.cuda.current_stream().cuda_stream), "cdet_accumulate_clear"))
+            return
+        ev = self._unit_events.get((key, task))
+        if ev is None:
+            ev = self._unit_events[(key, task)] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        n = self._unit_count[key] = self._unit_count.get(key, 0) + 1
+        if n < len(serving):
+            return
+        self._unit_count[key] = 0
+        fs = self._fold_stream
+        with torch.cuda.stream(fs):
+            for t in serving:
+                fs.wait_event(self._unit_events[(key, t)])
+            for t, alt in u["alts"]:
+                if t in serving:
+                    L.check(self.lib.cdet_accumulate_clear(u["main"].data_ptr(), alt.data_ptr(), alt.numel(), fs.cuda_stream), "cdet_accumulate_clear")
+            self.reducer.reduce_tensor(u["main"], bi)
 
     def _pass_steps(self, task: str, batch: dict, n_max, active_tasks, fired):
         """One task pass: fused forward + criterion + backward; gradients accumulate. Returns loss items (device tensor[5])."""
@@ -236,7 +295,8 @@ class Averaging:
         plan = self.model.get_plan(task, img.shape, img.dtype, training=True)
         if not plan.hooks:
             for idx in {i for i, _ in plan.bwd_groups}:
-                plan.hooks[idx] = (lambda i, t=task: self.reducer.on_block_backward(i, t, self._active))
+                for key in ([(idx, row) for row, _ in plan.bwd_sub[idx]] if idx in plan.bwd_sub else [idx]):
+                    plan.hooks[key] = (lambda k, t=task: self._unit_done(k, t))
         self._active = active_tasks
         yield from plan.iter_forward(img, fired)
         if self._gt_dropped is None:
@@ -281,6 +341,11 @@ class Averaging:
         # whole pass first would hold task B's first all-reduce behind A's last. A task whose next block waits for an event that has
         # not been recorded in this iteration yet (a shared block the earlier task has not reached) is skipped for the round.
         fired: set = set()
+        from ..engine import lane_stream
+        if self._fold_stream is None:
+            self._fold_stream = lane_stream(self.device, 2 * len(self.task_ids))  # (behind the task streams and the eval side lanes)
+        self._unit_count = {}
+        self._in_streams = True
         try:
             gens = []
             for t, st, plan in zip(active, streams, plans):
@@ -303,10 +368,12 @@ class Averaging:
                 if not progressed:
                     raise RuntimeError("task schedule cannot make progress: a block waits for an event no active task records")
         finally:
+            self._in_streams = False
             for plan in plans:
                 plan.block_sync = None
         for st in streams:
             cur.wait_stream(st)
+        cur.wait_stream(self._fold_stream)  # the folds of the shared units (their all-reduces are joined by reducer.wait())
 
     def set_shared_frozen(self, frozen: bool):
         """--freeze-shared-till-epoch (reference trainers/averaging.py:100-103, models/cerberus.py:885-925): the blocks that serve
@@ -376,8 +443,6 @@ class Averaging:
             n_max = max(int(torch.stack(counts).max()), 1) if counts else 1
         if self.task_streams and len(active) > 1:
             self._run_tasks_on_streams(active, batches, n_max, out)
-            self.model._merge_alt_grads()
-            self.reducer.reduce_deferred(active)
         else:
             for t in active:
                 out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)

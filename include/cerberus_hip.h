@@ -456,8 +456,9 @@ int cdet_accumulate_clear(float* dst, float* src, int64_t n, void* stream);
  *   cdet_peer_alloc / _free          device buffer for the exchange (uncached where the runtime offers it), zeroed
  *   cdet_peer_export / _import       64-byte IPC handle of a buffer / map a peer's buffer (cdet_peer_close unmaps)
  *   cdet_peer_allreduce              vec[0..n) <- sum over ranks, in rank order (bit-identical on every rank): one single-workgroup kernel that writes
- *                                    the rank's row into every peer's slot, publishes an epoch flag, waits (bounded; *err != 0 on time-out) for all
- *                                    ranks' flags in its own buffer and sums. peer_table: device array of `world` buffer addresses (own included);
+ *                                    the rank's row into every peer's slot, publishes an epoch flag, waits for all ranks' flags in its own buffer
+ *                                    and sums. The wait is bounded in wall time (CDET_PEER_SPIN_MS, default 10 min): on time-out vec is filled with
+ *                                    NaN and *err keeps 1 + the first missing rank (sticky: never cleared by a later launch). peer_table: device array of `world` buffer addresses (own included);
  *                                    the slot = 2 x world x n floats at data_off (floats) + 2 x world flags at flag_off (32-bit words); epoch > 0
  *                                    grows by one per use of the slot. phase 0 = the whole exchange; 1 / 2 = its publish / collect halves as separate
  *                                    launches (ranks sharing one GPU are time-sliced, not concurrent: they need a host barrier between the halves).

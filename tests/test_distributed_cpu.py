@@ -20,6 +20,26 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
+def _units(buckets, serving, alts=None, rows=None):
+    """Reduction units as trainers.Averaging builds them: block 0 split into `rows` slices, every other block whole."""
+    units = {}
+    for i, flat in buckets.items():
+        al = list(zip(serving[i][1:], (alts or {}).get(i, [])))
+        if i == 0 and rows:
+            off = 0
+            for r, n in enumerate(rows):
+                units[(0, r)] = dict(block=0, main=flat[off:off + n], alts=[(t, a[off:off + n]) for t, a in al], serving=serving[i])
+                off += n
+        else:
+            units[i] = dict(block=i, main=flat, alts=al, serving=serving[i])
+    return units
+
+
+def _fold(main, alt):
+    main += alt
+    alt.zero_()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,6 +49,7 @@ def _worker(rank, world, port, q):
     serving = {0: ["a", "b"], 1: ["a", "b"], 2: ["a"], 3: ["b"], 4: []}
     buckets = {i: torch.zeros(8) for i in range(5)}
     red = GradReducer(buckets, serving, tasks)
+    units = _units(buckets, serving)  # the chained form: one shared gradient buffer per block, no per-task buckets
     assert red.enabled
     log = []
     # local per-task gradient contributions g[task][block]; rank-dependent
@@ -37,9 +58,7 @@ def _worker(rank, world, port, q):
         order = [i for i in (3, 2, 1, 0) if t in serving[i]]  # backward visits blocks in reverse
         for i in order:
             buckets[i] += g[t][i]
-            n0 = len(red.handles)
-            red.on_block_backward(i, t, tasks)
-            if len(red.handles) > n0:
+            if red.unit_done(units[i], t, tasks, _fold):
                 log.append((t, i))
     red.wait()
     want = {i: sum((r + 1) * (10 if t == "a" else 1) * (i + 1) for r in range(world) for t in tasks if t in serving[i]) for i in range(5)}
@@ -50,9 +69,7 @@ def _worker(rank, world, port, q):
     log2 = []
     for i in (3, 1, 0):
         buckets[i] += g["b"][i]
-        n0 = len(red.handles)
-        red.on_block_backward(i, "b", ["b"])
-        if len(red.handles) > n0:
+        if red.unit_done(units[i], "b", ["b"], _fold):
             log2.append(("b", i))
     red.wait()
     ok2 = bool(torch.allclose(buckets[0], torch.full((8,), float(sum((r + 1) * 1 for r in range(world)))))) and float(buckets[2].abs().sum()) == 0.0
@@ -79,62 +96,79 @@ def test_block_bucketed_allreduce_world2():
         assert nbytes == 7 * 8 * 4
 
 
-def _worker_deferred(rank, world, port, q):
-    """The decoupled schedule (trainers/averaging.py, round 4): on the blocks several tasks serve, every task but the first accumulates into a bucket
-    of its own; the block's bucket is complete only after the fold, so the reducer must NOT send it from the block hook but from reduce_deferred."""
+def _worker_rows(rank, world, port, q):
+    """The decoupled schedule with per-row reduction units (trainers/averaging.py, round 5): on the blocks several tasks serve every task but the
+    first accumulates into a bucket of its own; block 0's bucket travels as one slice per backbone row, each folded (task order) and all-reduced
+    as soon as the last serving task has produced it. Against the round-4 form -- fold everything after the passes, all-reduce whole buckets --
+    the results must be BIT-identical (random fp32 gradients), and nothing may be sent before its last contribution is in."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cerberusdet_amd.trainers.averaging import GradReducer
 
-    tasks = ["a", "b"]
-    serving = {0: ["a", "b"], 1: ["a", "b"], 2: ["a"], 3: ["b"]}
-    buckets = {i: torch.zeros(8) for i in range(4)}
-    alt = {i: torch.zeros(8) for i in (0, 1)}          # task b's buckets on the shared blocks
-    red = GradReducer(buckets, serving, tasks)
-    red.deferred = {0, 1}
-    g = {t: {i: torch.full((8,), float((rank + 1) * (10 if t == "a" else 1) * (i + 1))) for i in range(4)} for t in tasks}
-    log = []
-    for t in tasks:
-        for i in [i for i in (3, 2, 1, 0) if t in serving[i]]:
-            (alt[i] if (t == "b" and i in alt) else buckets[i]).add_(g[t][i])
-            n0 = len(red.handles)
-            red.on_block_backward(i, t, tasks)
-            if len(red.handles) > n0:
-                log.append((t, i))
-    red.wait()
-    exclusive_ok = all(torch.allclose(buckets[i], torch.full((8,), float(sum((r + 1) * (10 if i == 2 else 1) * (i + 1) for r in range(world))))) for i in (2, 3))
-    shared_untouched = all(torch.allclose(buckets[i], g["a"][i]) for i in (0, 1))  # still local: nothing was sent before the fold
-    for i in (0, 1):                                    # the fold (model._merge_alt_grads), then the deferred reduction
-        buckets[i] += alt[i]
-        alt[i].zero_()
-    n0 = len(red.handles)
-    red.reduce_deferred(tasks)
-    sent = len(red.handles) - n0
-    red.wait()
-    want = {i: sum((r + 1) * 11 * (i + 1) for r in range(world)) for i in (0, 1)}
-    shared_ok = all(torch.allclose(buckets[i], torch.full((8,), float(want[i]))) for i in (0, 1))
-    # forward_backward()'s form: only the blocks THIS task completes (only_last_task); task "a" completes none of the shared ones
-    n0 = len(red.handles)
-    red.reduce_deferred(tasks, only_last_task="a")
-    none_for_a = len(red.handles) == n0
-    q.put((rank, log, bool(exclusive_ok), bool(shared_untouched), sent, bool(shared_ok), bool(none_for_a)))
+    tasks = ["a", "b", "c"]
+    serving = {0: ["a", "b", "c"], 1: ["a", "b"], 2: ["a"], 3: ["b"], 4: ["c"]}
+    rows = [5, 16, 3, 40]                                 # block 0 = four backbone rows
+    size = {0: sum(rows), 1: 24, 2: 8, 3: 8, 4: 8}
+    gen = torch.Generator().manual_seed(7 + rank)
+    g = {t: {i: torch.randn(size[i], generator=gen) for i in size if t in serving[i]} for t in tasks}
+
+    def run(per_row, active):
+        buckets = {i: torch.zeros(size[i]) for i in size}
+        alts = {i: [torch.zeros(size[i]) for _ in serving[i][1:]] for i in size}
+        red = GradReducer(buckets, serving, tasks)
+        units = _units(buckets, serving, alts, rows if per_row else None)
+        log = []
+        for t in active:
+            for i in [i for i in (4, 3, 2, 1, 0) if t in serving[i]]:
+                dst = buckets[i] if t == serving[i][0] else alts[i][serving[i].index(t) - 1]
+                keys = [(0, r) for r in reversed(range(len(rows)))] if (i == 0 and per_row) else [i]
+                off = size[i]
+                for k in keys:                                # the backward finishes block 0's rows from the last to the first
+                    n = rows[k[1]] if isinstance(k, tuple) else size[i]
+                    off -= n
+                    dst[off:off + n] += g[t][i][off:off + n]
+                    if per_row:
+                        if red.unit_done(units[k], t, active, _fold):
+                            log.append((t, k))
+        if not per_row:                                       # round 4: fold all per-task buckets after the passes, then send whole buckets
+            for i in size:
+                for a in alts[i]:
+                    _fold(buckets[i], a)
+            for i in size:
+                if any(t in serving[i] for t in active):
+                    red.reduce_tensor(buckets[i], i)
+        red.wait()
+        assert all(float(a.abs().sum()) == 0.0 for al in alts.values() for a in al)
+        return buckets, log, red.reduced_bytes
+
+    out = {}
+    for name, active in (("all", tasks), ("bc", ["b", "c"]), ("a", ["a"])):
+        b_new, log, n_new = run(True, active)
+        b_old, _, n_old = run(False, active)
+        out[name] = (all(torch.equal(b_new[i], b_old[i]) for i in size), log, n_new == n_old)
+    q.put((rank, out))
     dist.destroy_process_group()
 
 
-def test_deferred_buckets_of_the_decoupled_schedule_world2():
+def test_row_units_of_the_decoupled_schedule_world2_bit_identical_to_whole_buckets():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31700 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker_deferred, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_rows, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=60) for _ in procs]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    for rank, log, exclusive_ok, shared_untouched, sent, shared_ok, none_for_a in res:
-        assert log == [("a", 2), ("b", 3)], log            # the block hook sends the exclusive blocks only
-        assert exclusive_ok and shared_untouched and sent == 2 and shared_ok and none_for_a, (rank, sent)
+    for rank, out in res:
+        for name, (same, log, same_bytes) in out.items():
+            assert same and same_bytes, (rank, name)
+        # all three tasks: the exclusive blocks leave with their own task, block 1 after b, block 0's rows one by one (last row first) after c
+        assert out["all"][1] == [("a", 2), ("b", 3), ("b", 1), ("c", 4), ("c", (0, 3)), ("c", (0, 2)), ("c", (0, 1)), ("c", (0, 0))], out["all"][1]
+        # --skip-batches: b and c active -> block 1 is complete after b alone, block 0 after c
+        assert out["bc"][1] == [("b", 3), ("b", 1), ("c", 4), ("c", (0, 3)), ("c", (0, 2)), ("c", (0, 1)), ("c", (0, 0))], out["bc"][1]
+        assert out["a"][1] == [("a", 2), ("a", 1), ("a", (0, 3)), ("a", (0, 2)), ("a", (0, 1)), ("a", (0, 0))], out["a"][1]
 
 
 def test_bench_sharding_gives_distinct_rank_data():

@@ -255,11 +255,13 @@ def _worker_peer(rank, world, port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from cerberusdet_amd.peer_exchange import PeerExchange
+        from cerberusdet_amd.peer_exchange import try_setup
         from cerberusdet_amd.trainers import Averaging
 
         # (a) the primitive: many epochs of several slots, lengths from 2 to 5000 floats, against the process group's all-reduce
-        px = PeerExchange(torch.device(DEV), rank, world)
+        os.environ["CDET_SYNCBN_PEER"] = "1"  # (opt-in since round 5: the default keeps the statistics on the process group)
+        px = try_setup(torch.device(DEV), rank, world)  # staged set-up: alloc + export, import, known-answer exchange, each agreed collectively
+        assert px is not None, "peer exchange set-up fell back to the process group"
         g = torch.Generator().manual_seed(100 + rank)
         vecs = [torch.randn(n, generator=g).to(DEV) for n in (2, 160, 640, 5000)]
         calls = [px.make_call(v) for v in vecs]
@@ -302,7 +304,7 @@ def _worker_peer(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _virtual_ranks_worker(q):
+def _virtual_ranks_worker(q, split):
     try:
         import ctypes as C
 
@@ -334,12 +336,20 @@ def _virtual_ranks_worker(q):
                     want = want + vecs[r]           # rank order
                 torch.cuda.synchronize()
                 order = [(epoch + r) % W for r in range(W)]  # the enqueue order of the virtual ranks changes every epoch
-                for r in order:
-                    with torch.cuda.stream(streams[r]):
-                        L.check(lib.cdet_peer_allreduce(vecs[r].data_ptr(), n, table.data_ptr(), W, r, d_off, f_off, epoch, errs[r:].data_ptr(), 0,
-                                                        streams[r].cuda_stream), "cdet_peer_allreduce")
-                torch.cuda.synchronize()
-                assert int(errs.abs().sum()) == 0, f"time-out flag {errs.tolist()} at epoch {epoch}, n {n}: the three streams did not run side by side"
+                for phase in ((1, 2) if split else (0,)):    # split: every rank publishes, THEN every rank collects -- no wait can starve
+                    for r in order:
+                        with torch.cuda.stream(streams[r]):
+                            L.check(lib.cdet_peer_allreduce(vecs[r].data_ptr(), n, table.data_ptr(), W, r, d_off, f_off, epoch, errs[r:].data_ptr(),
+                                                            phase, streams[r].cuda_stream), "cdet_peer_allreduce")
+                    torch.cuda.synchronize()
+                if int(errs.abs().sum()) != 0:
+                    assert not split, f"time-out flag {errs.tolist()} in the split form (epoch {epoch}, n {n}): a published flag never became visible"
+                    nan = [bool(torch.isnan(v).all()) for v in vecs]
+                    ok = [bool(torch.equal(v, want)) for v in vecs]
+                    # a timed-out exchange must have poisoned ITS vector (never stale rows handed on as statistics); the others are exact
+                    assert all(a or b for a, b in zip(nan, ok)) and any(nan), (nan, ok)
+                    q.put(f"not concurrent: time-out flag {errs.tolist()} at epoch {epoch}, n {n} (the timed-out vectors are NaN, the others exact)")
+                    return
                 for r in range(W):
                     assert torch.equal(vecs[r], want), (epoch, n, r)
         for b in bufs:
@@ -351,29 +361,43 @@ def _virtual_ranks_worker(q):
         q.put("".join(traceback.format_exception(type(e), e, e.__traceback__)))
 
 
+def _run_virtual_ranks(split):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_virtual_ranks_worker, args=(q, split))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(60)
+    return res
+
+
 def test_peer_exchange_kernel_virtual_ranks_on_streams(monkeypatch):
     """csrc/peer_exchange.hip, the one-kernel form (write my row into every rank's slot, publish the epoch, WAIT in the kernel for all ranks' flags,
-    sum in rank order): three virtual ranks = three exchange buffers and three HIP streams of one process, whose kernels do run side by side.
+    sum in rank order): three virtual ranks = three exchange buffers and three HIP streams of one process, whose kernels have to run side by side.
     60 epochs over three slots (parity double-buffering, epochs far beyond 2), against the rank-ordered fp32 sum, bit for bit; no time-out flag.
     In a process of its own: the first three streams of a process sit on three different hardware queues, while in a long-lived process (this test
     session) two of them may share one -- kernels of one hardware queue run one after the other, and a kernel waiting for the one queued behind it can
-    only time out (the reason PeerExchange chains the exchanges of a rank, peer_exchange.py)."""
-    import torch.multiprocessing as mp
-
+    only time out (the reason PeerExchange chains the exchanges of a rank, peer_exchange.py).
+    Whether three streams of a process get three hardware queues that the GPU runs side by side is the runtime's decision (queues of all processes on
+    the box share the hardware slots). When they do not, the PRECONDITION of this test is missing: it is SKIPPED with that reason -- after checking
+    that the timed-out exchange poisoned its vector with NaN instead of handing stale rows on -- never retried into a pass. A wrong sum always fails.
+    The split form below covers the same arithmetic without that precondition."""
     monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")
-    ctx = mp.get_context("spawn")
-    # Whether three streams of a process get three hardware queues that the GPU runs side by side is the runtime's decision (queues of all
-    # processes on the box share the hardware slots); a time-out of the very precondition -- not a wrong sum, which is never retried -- gets
-    # two more tries in fresh processes (seen once in ~10 full-suite runs).
-    for attempt in range(3):
-        q = ctx.Queue()
-        p = ctx.Process(target=_virtual_ranks_worker, args=(q,))
-        p.start()
-        res = q.get(timeout=600)
-        p.join(60)
-        if res == "ok" or "did not run side by side" not in res:
-            break
-        print(f"attempt {attempt}: the three streams were not concurrent; retrying in a fresh process")
+    res = _run_virtual_ranks(split=False)
+    if res.startswith("not concurrent"):
+        pytest.skip(f"the three streams of the worker did not run side by side on this box -- {res}")
+    assert res == "ok", res
+
+
+def test_peer_exchange_split_form_virtual_ranks_cannot_time_out(monkeypatch):
+    """The same exchange as its two halves (phase 1: write + publish, phase 2: collect + sum -- what CDET_PEER_XCHG_HOSTSYNC=1 runs around a host
+    barrier): all three virtual ranks publish, the host synchronises, all three collect. Every flag is in place before any wait starts, so the
+    kernel's bounded wait never spins: same slots, same parity double-buffering over 60 epochs, same rank-ordered sums, bit for bit, with no
+    dependence on how the runtime schedules the streams. A time-out here is a visibility bug, not a scheduling artefact, and fails."""
+    monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")
+    res = _run_virtual_ranks(split=True)
     assert res == "ok", res
 
 

@@ -50,6 +50,15 @@ def test_no_cpu_fallback():
             non_max_suppression(torch.zeros(1, 8, 10))
     with pytest.raises(RuntimeError):
         m.blocks[0].model[0](torch.zeros(1, 3, 64, 64))  # structural modules have no eager path
+    # kept signatures do not silently change meaning: the reference would run device="cpu" on the CPU (cerberusdet_inference.py:30-36)
+    # and would fill rep_tensors for retain_tensors / retain_all (cerberus.py:866-872)
+    from cerberusdet_amd.cerberusdet_inference import CerberusDetInference
+
+    with pytest.raises(RuntimeError, match="not supported"):
+        CerberusDetInference("does-not-matter.pt", device="cpu")
+    for kw in (dict(retain_tensors=True), dict(retain_all=True)):
+        with pytest.raises(NotImplementedError):
+            m(torch.zeros(1, 3, 64, 64), **kw)
 
 
 @pytest.mark.parametrize("ref_name", list(CFGS))

@@ -152,3 +152,36 @@ def test_model_with_compiled_plans_deep_copies_without_runtime_state():
     assert not any(a in mod.__dict__ for mod in c.modules() for a in type(m)._RUNTIME_ATTRS)
     assert any("_plan_slots" in mod.__dict__ for mod in m.modules())  # the original keeps its runtime state
     assert c.state_dict().keys() == m.state_dict().keys()
+
+
+def test_training_plan_marks_where_each_backbone_row_is_complete_and_release_unregisters():
+    """Round 5: block 0's backward carries one mark per backbone row (engine.Plan.bwd_sub) -- where the trainer folds and all-reduces that row's
+    slice of the trunk's gradient bucket while the backward runs on (reference: DDP's bucketed overlap, train.py:182-184); the grouped weight
+    gradients of a row are flushed AT its mark, not at the end of the block. An evicted plan takes its argument lists off the modules."""
+    from cerberusdet_amd.engine import Plan
+
+    tasks = ["voc", "objects365_animals"]
+    m = _model("v8x_2task.yaml", tasks)
+    dev = torch.device("cpu")
+    p = Plan(m, [tasks[0]], 2, 64, 64, True, torch.bfloat16, torch.uint8, dev)
+    rows = p.bwd_sub[0]
+    n_rows = len(m.blocks[0].model)
+    assert [r for r, _ in rows] == list(range(n_rows - 1, -1, -1))        # rows finish from the last to the first
+    ends = [e for _, e in rows]
+    calls0 = dict(p.bwd_groups)[0]
+    assert ends == sorted(ends) and len(set(ends)) == n_rows and ends[-1] == len(calls0)
+    names = [getattr(fn, "__name__", "") for fn, _ in calls0]
+    lo = 0
+    for row, end in rows:                                                  # a C2f row's grouped weight gradient is its segment's last launch
+        seg = names[lo:end]
+        if "cdet_conv2d_wgrad_grouped" in seg:
+            assert seg[-1] == "cdet_conv2d_wgrad_grouped" and type(m.blocks[0].model[row]).__name__ == "C2f"
+        lo = end
+    assert names.count("cdet_conv2d_wgrad_grouped") >= 3
+    assert set(p.bwd_sub) == {0}
+    ev = Plan(m, tasks, 2, 64, 64, False, torch.bfloat16, torch.uint8, dev)
+    assert not ev.bwd_sub
+    before = sum(len(mod.__dict__.get("_plan_slots", [])) for mod in m.modules())
+    ev.release()
+    after = sum(len(mod.__dict__.get("_plan_slots", [])) for mod in m.modules())
+    assert after < before and after == sum(1 for _ in p._registered)
