@@ -219,3 +219,103 @@ def check_backward(plan, rep, tol16=2.0 ** -7):
             rep.add("conv", "dw(grouped)", r, r["m"].conv.weight.grad - cw0[id(r)], dw_ref, 1e-3, name)
     assert n_checked == len(recs)
     return n_checked
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# EVAL plans (round 5): the launch list the north-star forward and CerberusDetInference run -- folded-BatchNorm epilogues, virtual Concat /
+# Upsample sources, the fused first two backbone rows, fp32 projections, the one-launch SPPF pool chain, decode.
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+def _cat_input(x):
+    """fp32 NHWC tensor of a unit's input: a View, or the parts of a virtual Concat (an upsampled part is read through (y/2, x/2),
+    reference nn.Upsample(nearest, 2) + Concat, models/common.py:288-295)."""
+    if hasattr(x, "parts"):
+        ts = []
+        for v, up in x.parts:
+            t = _f(v)
+            ts.append(t.repeat_interleave(2, 1).repeat_interleave(2, 2) if up else t)
+        return torch.cat(ts, 3)
+    return _f(x)
+
+
+def _folded(m):
+    """(scale | None, bias) of the eval-form epilogue, as the engine packed them (engine._pack_conv: BatchNorm folded, reference
+    utils/torch_utils.py:191-217), recomputed here from the module's own state."""
+    if m.fused:
+        return None, m.conv.bias.detach().float()
+    bn = m.bn
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+    return scale, (bn.bias - bn.running_mean * scale).detach().float()
+
+
+def _eval_act(z, m):
+    scale, bias = _folded(m)
+    return R.silu(z * scale + bias if scale is not None else z + bias)
+
+
+def decode_ref(feats, nc, strides):
+    """Eval branch of Detect.forward incl. DFL (reference models/yolo.py:57-59, 93-100; utils/tal.py:181-205) on the padded NHWC fp32 head maps
+    [N, h, w, 64 + pad8(nc)] -> y [N, 4 + nc, A] fp32."""
+    boxes, clss, pts, sts = [], [], [], []
+    for f, s in zip(feats, strides):
+        N, h, w, _ = f.shape
+        boxes.append(f[..., :64].reshape(N, h * w, 4, 16))
+        clss.append(f[..., 64:64 + nc].reshape(N, h * w, nc))
+        yy, xx = torch.meshgrid(torch.arange(h, device=f.device, dtype=torch.float32) + 0.5,
+                                torch.arange(w, device=f.device, dtype=torch.float32) + 0.5, indexing="ij")
+        pts.append(torch.stack((xx, yy), -1).view(-1, 2))
+        sts.append(torch.full((h * w, 1), float(s), device=f.device))
+    box, cls, pt, st = torch.cat(boxes, 1), torch.cat(clss, 1), torch.cat(pts), torch.cat(sts)
+    dist = (box.softmax(3) * torch.arange(16, device=box.device, dtype=torch.float32)).sum(3)  # [N, A, 4] ltrb
+    x1y1, x2y2 = pt - dist[..., :2], pt + dist[..., 2:]
+    dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 2) * st
+    return torch.cat((dbox, cls.sigmoid()), 2).permute(0, 2, 1)
+
+
+def check_eval_forward(plan, rep, tol16=2.0 ** -7):
+    """Every unit of a compiled EVAL plan from the engine's own input buffers (call after plan.run_forward + synchronize; the plan must write its
+    home outputs: plan.fresh_outputs(False)). Returns the number of units checked per kind."""
+    assert not plan.training
+    n = {}
+    for rec in plan.trace:
+        kind = rec["kind"]
+        n[kind] = n.get(kind, 0) + 1
+        if kind == "econv":
+            m, x, y, res = rec["m"], rec["x"], rec["y"], rec["res"]
+            w = _w_rounded(m.conv.weight, plan.dtype)
+            if x is None:
+                xin, name = _stem_input(plan), f"stem ->{m.c2}"
+            else:
+                xin = _cat_input(x)
+                name = f"{y.H * m.s}x{y.W * m.s} {xin.shape[3]}->{m.c2} k{m.k} s{m.s}" + (" [virtual cat]" if hasattr(x, "parts") else "")
+            ref = _eval_act(R.conv_fwd(xin, w, m.s), m)
+            if res is not None:
+                ref = ref + _f(res)
+            rep.add("econv", "y", rec, _f(y), ref, tol16, name)
+        elif kind == "stemc1":
+            m0, m1, y = rec["m0"], rec["m1"], rec["y"]
+            s0 = _eval_act(R.conv_fwd(_stem_input(plan), _w_rounded(m0.conv.weight, plan.dtype), m0.s), m0)
+            s0 = s0.to(plan.dtype).float()  # the stem's map lives in LDS in the compute dtype (csrc/stem_conv1.hip), as the two-kernel path stores it
+            ref = _eval_act(R.conv_fwd(s0, _w_rounded(m1.conv.weight, plan.dtype), m1.s), m1)
+            rep.add("stemc1", "y", rec, _f(y), ref, tol16, f"3->{m0.c2}->{m1.c2}")
+        elif kind == "ebias":
+            m, x, feat = rec["m"], rec["x"], rec["feat"]
+            O = m.out_channels
+            ref = R.conv_fwd(_f(x), _w_rounded(m.weight, plan.dtype), 1) + m.bias.detach().float()
+            rep.add("ebias", "feat", rec, feat.torch()[..., :O].float(), ref, 1e-3, f"{x.H}x{x.W} {x.C}->{O}")
+        elif kind == "epool":
+            buf, c = rec["buf"], rec["c"]
+            t = buf.torch()
+            cur = t[..., :c].float().permute(0, 3, 1, 2)
+            for i in range(1, 4):
+                cur = F.max_pool2d(cur, 5, 1, 2)
+                assert torch.equal(t[..., i * c:(i + 1) * c].float(), cur.permute(0, 2, 3, 1)), f"SPPF pool {i}"
+        elif kind == "decode":
+            head, feats, y = rec["head"], rec["feats"], rec["y"]
+            assert all(f.data_ptr() == g.data_ptr() for f, g in zip(feats, plan.feats[rec["task"]])), "check the plan's home outputs (fresh_outputs(False))"
+            ref = decode_ref(feats, head.nc, [float(s) for s in head.stride])
+            got = y.float()
+            tol = 1e-3 if y.dtype == torch.float32 else 2.0 ** -9  # (a 16-bit `y` rounds once: fp16 2^-11, bf16 2^-8 of the value)
+            # boxes against the image scale, class probabilities absolute
+            rep.add("decode", "box", rec, got[:, :4], ref[:, :4], tol if y.dtype != torch.bfloat16 else 2.0 ** -7, rec["task"])
+            assert float((got[:, 4:] - ref[:, 4:]).abs().max()) <= (1e-3 if y.dtype != torch.bfloat16 else 2.0 ** -8), f"class probabilities of {rec['task']}"
+    return n
