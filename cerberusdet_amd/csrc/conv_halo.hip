@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "halo_common.h"
+#include "bn_fold.h"
 
 #include <type_traits>
 
@@ -35,6 +36,7 @@ struct HaloArgs {
     const uint16_t* res;
     void* y;
     float* stats;
+    const BnFold* fold;  // train form: the partial sums are reduced and finalized inside this launch (bn_fold.h); null: the caller runs bn_finalize
     int H, W, Cd;
     int M;  // N*H*W
     int src_ld, src_coff, dst_ld, dst_coff, res_ld, res_coff;
@@ -607,9 +609,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 sv += stl[(m * 2 + 0) * HC + t];
                 qv += stl[(m * 2 + 1) * HC + t];
             }
-            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
-            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+            if (a.fold != nullptr) {  // write-through (sc1) stores: the workgroup that draws the last ticket reads them from any XCD
+                const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(a.stats);
+                bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 0) * a.Cd + c0 + t) * 4), sv);
+                bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 1) * a.Cd + c0 + t) * 4), qv);
+            } else {
+                a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+                a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+            }
         }
+        if (a.fold != nullptr) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cb, reinterpret_cast<volatile int*>(smem));
     }
 #ifdef CDET_PROFILING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -866,7 +875,7 @@ namespace cdet {
 // csrc/conv_pair.hip: 1x1 layers with an even number of 160-cout blocks -- two blocks share the staged pixel tile
 bool pair_plan_ok(const cdet_conv_desc* d);
 int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
-                float* stats, hipStream_t s, const CatSrcs* cat = nullptr);
+                float* stats, hipStream_t s, const CatSrcs* cat = nullptr, const BnFold* fold = nullptr);
 
 // host-side check + fill of a virtual-Concat source list against the convolution's descriptor
 static int cat_fill(const cdet_conv_desc* d, const cdet_cat_src* srcs, int n, CatSrcs* c) {
@@ -946,7 +955,7 @@ extern "C" int cdet_pack_weight_tiled(const float* w_oihw, void* w_fwd, void* w_
 }
 
 static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
-                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat);
+                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat, const BnFold* fold);
 
 extern "C" int cdet_conv2d_tiled_cat_ok(const cdet_conv_desc* d, const cdet_cat_src* srcs, int32_t n_src) {
     if (!d) return 0;
@@ -970,11 +979,27 @@ extern "C" int cdet_conv2d_tiled_cat(const cdet_conv_desc* d, const cdet_cat_src
 
 extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                                  const void* residual, void* y, float* stats, void* stream) {
-    return conv2d_tiled_impl(d, x, w_tiled, scale, bias, residual, y, stats, stream, nullptr);
+    return conv2d_tiled_impl(d, x, w_tiled, scale, bias, residual, y, stats, stream, nullptr, nullptr);
+}
+
+// The train form with the BatchNorm statistics finished inside the launch (bn_fold.h). rows / column blocks of the launch: see cdet_bn_fold_ok.
+extern "C" int cdet_conv2d_tiled_bn(const cdet_conv_desc* d, const void* x, const void* w_tiled, void* y, float* stats, const cdet_bn_fold* fold_dev,
+                                    void* stream) {
+    CDET_CHECK_ARG(stats, "cdet_conv2d_tiled_bn: the partial-sum rows are needed with or without the fold");
+    CDET_CHECK_ARG(!fold_dev || cdet_conv2d_tiled_bn_ok(d), "cdet_conv2d_tiled_bn: this launch has more partial rows / column blocks than the fold takes");
+    return conv2d_tiled_impl(d, x, w_tiled, nullptr, nullptr, nullptr, y, stats, stream, nullptr, fold_dev);
+}
+
+extern "C" int cdet_conv2d_tiled_bn_ok(const cdet_conv_desc* d) {
+    if (!d || !cdet_conv2d_tiled_ok(d) || d->out_dtype == CDET_F32) return 0;
+    const HaloPlan pl = halo_plan(d);
+    if (!pl.ok) return 0;
+    const int rows = cdet_conv2d_tiled_stat_blocks(d);
+    return rows <= BNF_CL * BNF_MAX_CL && div_up(d->Cd, pl.nf * 32) <= BNF_MAX_CB;
 }
 
 static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
-                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat) {
+                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat, const BnFold* fold = nullptr) {
     CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_tiled: null pointer");
     const HaloPlan pl = halo_plan(d);
     CDET_CHECK_ARG(pl.ok, "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs/Cd/ld/coff %% 8 == 0, 16-bit in, out = the same "
@@ -984,14 +1009,14 @@ static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void*
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_tiled: the data gradient is a FWD call on the DGRAD operand of cdet_pack_weights_tiled");
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_tiled: residual ld/coff must be multiples of 8");
     if (!f32out && pl.nf == 5 && pl.ng == 2 && pair_plan_ok(d)) {
-        const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream, cat);
+        const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream, cat, fold);
         CDET_LAUNCH_CHECK();
         return rc;
     }
     const int rb = pl.nf * 32;
     HaloArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_tiled; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
-    a.y = y; a.stats = stats;
+    a.y = y; a.stats = stats; a.fold = stats ? fold : nullptr;
     a.H = d->Hs; a.W = d->Ws; a.Cd = d->Cd;
     a.M = d->N * d->Hs * d->Ws;
     a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "halo_common.h"
+#include "bn_fold.h"
 
 namespace cdet {
 
@@ -24,6 +25,7 @@ struct PairArgs {
     const uint16_t* res;
     void* y;
     float* stats;
+    const BnFold* fold;  // see conv_halo.hip
     int Cd, M;
     int src_ld, src_coff, dst_ld, dst_coff, res_ld, res_coff;
     int nchunk, Cs, n_pblk, n_pair, act;
@@ -260,8 +262,14 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
                     sv += stl[((cbh * 4 + m) * 2 + 0) * HC + c];
                     qv += stl[((cbh * 4 + m) * 2 + 1) * HC + c];
                 }
-                a.stats[((int64_t)pblk * 2 + 0) * a.Cd + co] = sv;
-                a.stats[((int64_t)pblk * 2 + 1) * a.Cd + co] = qv;
+                if (a.fold != nullptr) {
+                    const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(a.stats);
+                    bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 0) * a.Cd + co) * 4), sv);
+                    bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 1) * a.Cd + co) * 4), qv);
+                } else {
+                    a.stats[((int64_t)pblk * 2 + 0) * a.Cd + co] = sv;
+                    a.stats[((int64_t)pblk * 2 + 1) * a.Cd + co] = qv;
+                }
             }
         }
     }
@@ -348,6 +356,10 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+    // train form with the statistics finished in this launch (bn_fold.h): the workgroup's row share (both cout blocks: 2 HC columns) went out with
+    // write-through stores above; tickets at the very end, when the staging LDS is free
+    if (EPI == HEPI_RAW && a.stats != nullptr && a.fold != nullptr)
+        bn_fold_finish<true>(a.fold, a.stats, pblk, pair * 2 * HC, 2 * HC, pair, reinterpret_cast<volatile int*>(smem));
 }
 
 template <int DT, int EPI, bool CAT = false>
@@ -377,10 +389,10 @@ bool pair_plan_ok(const cdet_conv_desc* d) {
 }
 
 int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
-                float* stats, hipStream_t s, const CatSrcs* cat) {
+                float* stats, hipStream_t s, const CatSrcs* cat, const BnFold* fold) {
     PairArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_tiled; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
-    a.y = y; a.stats = stats;
+    a.y = y; a.stats = stats; a.fold = stats ? fold : nullptr;
     a.Cd = d->Cd;
     a.M = d->N * d->Hs * d->Ws;
     a.src_ld = d->src_ld; a.src_coff = d->src_coff; a.dst_ld = d->dst_ld; a.dst_coff = d->dst_coff;

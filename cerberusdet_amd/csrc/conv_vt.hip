@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "halo_common.h"
+#include "bn_fold.h"
 
 namespace cdet {
 
@@ -32,6 +33,7 @@ struct VtArgs {
     const uint16_t* res;
     void* y;
     float* stats;
+    const BnFold* fold;  // see conv_halo.hip
     int Hs, Ws;  // source image size (forward: the input; class: dY)
     int Hp, Wp;  // the tile space: forward = output pixels, class = dY pixels = pixels of one parity plane of dX
     int Hd, Wd;  // destination image size (forward: = Hp, Wp; class: dX = 2 Hp x 2 Wp)
@@ -420,8 +422,14 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
                 sv += stl[(m * 2 + 0) * HC + t];
                 qv += stl[(m * 2 + 1) * HC + t];
             }
-            a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
-            a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+            if (a.fold != nullptr) {
+                const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(a.stats);
+                bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 0) * a.Cd + c0 + t) * 4), sv);
+                bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 1) * a.Cd + c0 + t) * 4), qv);
+            } else {
+                a.stats[((int64_t)pblk * 2 + 0) * a.Cd + c0 + t] = sv;
+                a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
+            }
         }
     }
 
@@ -520,6 +528,9 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+    // train form with the statistics finished in this launch (bn_fold.h); tickets at the very end, when the staging LDS is free
+    if (FWD && EPI == HEPI_RAW && a.stats != nullptr && a.fold != nullptr)
+        bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem));
 }
 
 // XCD-aware remap (bijective): consecutive logical ids run on ONE XCD
@@ -660,7 +671,7 @@ static void vt_fill(VtArgs& a, const cdet_conv_desc* d, const VtPlan& pl, bool d
                     const float* bias, const void* residual, void* y, float* stats) {
     const int rb = pl.nf * 32;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.scale = scale; a.bias = bias; a.res = (const uint16_t*)residual;
-    a.y = y; a.stats = stats;
+    a.y = y; a.stats = stats; a.fold = nullptr;
     a.Hs = d->Hs; a.Ws = d->Ws; a.Hd = d->Hd; a.Wd = d->Wd;
     a.Hp = dgrad ? d->Hs : d->Hd; a.Wp = dgrad ? d->Ws : d->Wd;
     a.Cd = d->Cd;
@@ -682,6 +693,11 @@ static void vt_fill(VtArgs& a, const cdet_conv_desc* d, const VtPlan& pl, bool d
 
 extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                                     const void* residual, void* y, float* stats, void* stream) {
+    return s2_tiled_impl(d, x, w_tiled, scale, bias, residual, y, stats, stream, nullptr);
+}
+
+static int s2_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual,
+                         void* y, float* stats, void* stream, const BnFold* fold) {
     CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_s2_tiled: null pointer");
     CDET_CHECK_ARG(d->mode == CDET_CONV_FWD, "cdet_conv2d_s2_tiled: forward descriptor expected");
     const VtPlan pl = vt_plan(d, false);
@@ -690,6 +706,7 @@ extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, cons
     CDET_CHECK_ARG(!residual || (d->res_ld % 8 == 0 && d->res_coff % 8 == 0), "cdet_conv2d_s2_tiled: residual ld/coff must be multiples of 8");
     VtArgs a;
     vt_fill(a, d, pl, false, x, w_tiled, scale, bias, residual, y, stats);
+    a.fold = stats ? fold : nullptr;
     CDET_CHECK_ARG(!(d->out_dtype == CDET_F32 && stats), "cdet_conv2d_s2_tiled: BatchNorm partial sums go with the 16-bit raw output");
     const int full = d->out_dtype == CDET_F32 ? HEPI_F32 : ((scale || bias || residual || d->act != CDET_ACT_NONE) ? HEPI_FULL : HEPI_RAW);
     const int nblocks = a.n_pblk * a.n_cblk;
@@ -698,6 +715,23 @@ extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, cons
     else dispatch_vt<CDET_F16, VT_S2FWD>(a, pl.nf, full, pl.patch, pl.lds, nblocks, s);
     CDET_LAUNCH_CHECK();
     return 0;
+}
+
+static int s2_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual,
+                         void* y, float* stats, void* stream, const BnFold* fold);
+
+extern "C" int cdet_conv2d_s2_tiled_bn_ok(const cdet_conv_desc* d) {
+    if (!d || !cdet_conv2d_s2_tiled_ok(d) || d->out_dtype == CDET_F32 || d->mode != CDET_CONV_FWD) return 0;
+    const VtPlan pl = vt_plan(d, false);
+    return pl.ok && cdet_conv2d_s2_tiled_stat_blocks(d) <= BNF_CL * BNF_MAX_CL && div_up(d->Cd, pl.nf * 32) <= BNF_MAX_CB;
+}
+
+// train form with the BatchNorm statistics finished inside the launch (bn_fold.h)
+extern "C" int cdet_conv2d_s2_tiled_bn(const cdet_conv_desc* d, const void* x, const void* w_tiled, void* y, float* stats, const cdet_bn_fold* fold_dev,
+                                       void* stream) {
+    CDET_CHECK_ARG(stats, "cdet_conv2d_s2_tiled_bn: the partial-sum rows are needed with or without the fold");
+    CDET_CHECK_ARG(!fold_dev || cdet_conv2d_s2_tiled_bn_ok(d), "cdet_conv2d_s2_tiled_bn: this launch has more partial rows / column blocks than the fold takes");
+    return s2_tiled_impl(d, x, w_tiled, nullptr, nullptr, nullptr, y, stats, stream, fold_dev);
 }
 
 extern "C" int cdet_conv2d_s2_tiled_dgrad(const cdet_conv_desc* d, const void* dy, const void* w_dgrad_tiled, const float* scale, const float* bias,

@@ -64,7 +64,7 @@ struct NmsArgs {
     int n_classes;
     Cand* cand;             // [N][max_cand]
     unsigned long long* keys;  // [N][cap2]
-    int cap2;
+    int cap2, sel_cap;      // per image: cap2 keys + sel_cap keys of the max_nms selection (validation settings)
     int* count;             // [N]
     int* seg_count;         // [N][n_seg]: candidates per anchor segment (filter pass 1 -> the slot base of pass 2)
     int n_seg, seg_len;     // anchors are split into n_seg runs of seg_len (a multiple of 256)
@@ -165,40 +165,170 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const NmsArgs a) {
 
 // key = (~ord(conf) << 32) | pos : ascending sort == conf descending, original position ascending
 constexpr int SORT_LDS_MAX = 4096;
+
+__device__ __forceinline__ unsigned long long cand_key(const Cand* cand, int i) {
+    return (((unsigned long long)(~f2ord(cand[i].conf))) << 32) | (unsigned long long)i;
+}
+
+// Bitonic sort (ascending) of p2 = 2^k keys, LDS-resident while the partners of a compare-exchange sit in the same 4096-key chunk: all stages of the
+// sizes <= 4096 run chunk by chunk in ONE pass through LDS; for a larger size only its strides >= 4096 go through global memory (L2), the rest of the
+// size again chunk by chunk. 32768 keys: 6 global passes + 4 LDS phases instead of 120 global passes. 1024 threads.
+__device__ void bitonic_sort_hybrid(unsigned long long* __restrict__ k, int p2, unsigned long long* __restrict__ sk) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int chunk = p2 < SORT_LDS_MAX ? p2 : SORT_LDS_MAX;
+    for (int size_lo = 2; size_lo <= p2;) {
+        // global strides of this size (none while size <= chunk)
+        int size_hi = size_lo;  // the LDS phase below covers sizes size_lo .. size_hi
+        if (size_lo <= chunk) size_hi = chunk;
+        else {
+            for (int stride = size_lo >> 1; stride >= chunk; stride >>= 1) {
+                for (int i = tid; i < (p2 >> 1); i += nt) {
+                    const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size_lo) == 0);
+                    const unsigned long long x = k[lo], y = k[hi];
+                    if ((x > y) == up) {
+                        k[lo] = y;
+                        k[hi] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int c0 = 0; c0 < p2; c0 += chunk) {
+            for (int i = tid; i < chunk; i += nt) sk[i] = k[c0 + i];
+            __syncthreads();
+            for (int size = size_lo; size <= size_hi; size <<= 1) {
+                for (int stride = min(size >> 1, chunk >> 1); stride > 0; stride >>= 1) {
+                    for (int i = tid; i < (chunk >> 1); i += nt) {
+                        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                        const int hi = lo + stride;
+                        const bool up = (((c0 + lo) & size) == 0);
+                        const unsigned long long x = sk[lo], y = sk[hi];
+                        if ((x > y) == up) {
+                            sk[lo] = y;
+                            sk[hi] = x;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < chunk; i += nt) k[c0 + i] = sk[i];
+            __syncthreads();
+        }
+        size_lo = size_hi << 1;
+    }
+}
+
+// The K-th smallest (0-based rank K - 1) of cnt distinct 64-bit keys: MSB-first radix select, 8-bit digits, one 256-bin histogram per wave (a level's
+// keys mostly share their high digits -- confidences of one exponent range -- so a single LDS histogram would serialise all 16 waves on a few bins).
+__device__ unsigned long long radix_select_kth(const unsigned long long* __restrict__ k, int cnt, int K, unsigned* __restrict__ hist /* [16][256] */,
+                                               unsigned* __restrict__ bins /* [256] */, unsigned long long* __restrict__ sh_pref, int* __restrict__ sh_rank) {
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6;
+    if (tid == 0) {
+        *sh_pref = 0ull;
+        *sh_rank = K - 1;
+    }
+    __syncthreads();
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 16 * 256; i += nt) hist[i] = 0u;
+        __syncthreads();
+        const unsigned long long pref = *sh_pref;
+        const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        for (int i = tid; i < cnt; i += nt) {
+            const unsigned long long key = k[i];
+            if ((key & himask) == pref) atomicAdd(&hist[wave * 256 + (int)((key >> shift) & 0xffull)], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned t = 0;
+            for (int w = 0; w < 16; ++w) t += hist[w * 256 + tid];
+            bins[tid] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int r = *sh_rank, b = 0;
+            while (b < 255 && r >= (int)bins[b]) {
+                r -= (int)bins[b];
+                ++b;
+            }
+            *sh_rank = r;
+            *sh_pref = pref | ((unsigned long long)b << shift);
+        }
+        __syncthreads();
+    }
+    return *sh_pref;
+}
+
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const NmsArgs a) {
     __shared__ unsigned long long sk[SORT_LDS_MAX];
+    __shared__ unsigned hist[16 * 256], bins[256];
+    __shared__ unsigned long long sh_pref;
+    __shared__ int sh_rank, sh_slot;
     const int n = blockIdx.x;
     const int cnt = a.count[n];
     const Cand* cand = a.cand + (int64_t)n * a.max_cand;
-    unsigned long long* keys = a.keys + (int64_t)n * a.cap2;
-    int p2 = 1;
-    while (p2 < cnt) p2 <<= 1;
+    unsigned long long* keys = a.keys + (int64_t)n * (a.cap2 + a.sel_cap);
     if (cnt <= 1) {
         if (threadIdx.x == 0 && cnt == 1) keys[0] = 0ull;
         return;
     }
-    const bool in_lds = p2 <= SORT_LDS_MAX;
-    unsigned long long* k = in_lds ? sk : keys;
-    for (int i = threadIdx.x; i < p2; i += blockDim.x)
-        k[i] = i < cnt ? (((unsigned long long)(~f2ord(cand[i].conf))) << 32) | (unsigned long long)i : ~0ull;
-    __syncthreads();
-    for (int size = 2; size <= p2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = threadIdx.x; i < (p2 >> 1); i += blockDim.x) {
-                const int lo = ((i / stride) * (stride << 1)) + (i % stride);
-                const int hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const unsigned long long x = k[lo], y = k[hi];
-                if ((x > y) == up) {
-                    k[lo] = y;
-                    k[hi] = x;
+    int p2 = 1;
+    while (p2 < cnt) p2 <<= 1;
+    if (p2 <= SORT_LDS_MAX) {  // the inference regime: a few hundred candidates per image, one pass through LDS
+        for (int i = threadIdx.x; i < p2; i += blockDim.x) sk[i] = i < cnt ? cand_key(cand, i) : ~0ull;
+        __syncthreads();
+        for (int size = 2; size <= p2; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = threadIdx.x; i < (p2 >> 1); i += blockDim.x) {
+                    const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long x = sk[lo], y = sk[hi];
+                    if ((x > y) == up) {
+                        sk[lo] = y;
+                        sk[hi] = x;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
-    }
-    if (in_lds)
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[i] = sk[i];
+        return;
+    }
+    // validation settings (conf 0.001, multi_label: up to A x nc candidates per image). The reference keeps the max_nms = 30000 best before the
+    // suppression (x[x[:, 4].argsort(descending=True)[:max_nms]], general.py:416,459): only those are sorted here -- selected first (the keys are
+    // distinct, so the set of the K smallest is unique and the result equals the first K of the full sort), then sorted.
+    const int K = cnt < a.max_nms ? cnt : a.max_nms;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[i] = cand_key(cand, i);
+    __syncthreads();
+    if (K == cnt) {
+        for (int i = cnt + threadIdx.x; i < p2; i += blockDim.x) keys[i] = ~0ull;
+        __syncthreads();
+        bitonic_sort_hybrid(keys, p2, sk);
+        return;
+    }
+    const unsigned long long kth = radix_select_kth(keys, cnt, K, hist, bins, &sh_pref, &sh_rank);
+    unsigned long long* sel = keys + a.cap2;
+    int pk = 1;
+    while (pk < K) pk <<= 1;
+    if (threadIdx.x == 0) sh_slot = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < cnt; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const unsigned long long key = i < cnt ? keys[i] : ~0ull;
+        const bool take = i < cnt && key <= kth;
+        const unsigned long long m = __ballot(take);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&sh_slot, __popcll(m));
+        base = __shfl(base, 0);
+        if (take) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+    }
+    for (int i = K + threadIdx.x; i < pk; i += blockDim.x) sel[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort_hybrid(sel, pk, sk);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) keys[i] = sel[i];
 }
 
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2, float by2,
@@ -228,7 +358,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(const NmsArgs a) {
     int cnt = a.count[n];
     if (cnt > a.max_nms) cnt = a.max_nms;  // general.py:459
     const Cand* cand = a.cand + (int64_t)n * a.max_cand;
-    const unsigned long long* keys = a.keys + (int64_t)n * a.cap2;
+    const unsigned long long* keys = a.keys + (int64_t)n * (a.cap2 + a.sel_cap);
     float* rows = a.out_rows + (int64_t)n * a.max_det * 6;
     const float thr = a.iou_thres;
     int nkept = 0;
@@ -478,10 +608,16 @@ using namespace cdet;
 
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
+// keys of the max_nms selection (only when an image can hold more candidates than max_nms and more than the LDS sort takes)
+static int nms_sel_cap(const cdet_nms_desc* d) {
+    const int max_nms = d->max_nms > 0 ? d->max_nms : 30000;
+    return (d->max_cand > max_nms && d->max_cand > SORT_LDS_MAX) ? next_pow2(max_nms) : 0;
+}
+
 extern "C" int64_t cdet_nms_ws_bytes(const cdet_nms_desc* d) {
     if (!d) return -1;
     const int cap2 = next_pow2(d->max_cand);
-    return align256((int64_t)d->N * d->max_cand * sizeof(Cand)) + align256((int64_t)d->N * cap2 * 8) + align256((int64_t)d->N * 4) +
+    return align256((int64_t)d->N * d->max_cand * sizeof(Cand)) + align256((int64_t)d->N * (cap2 + nms_sel_cap(d)) * 8) + align256((int64_t)d->N * 4) +
            align256((int64_t)d->N * NMS_SEG_MAX * 4);
 }
 
@@ -499,9 +635,10 @@ extern "C" int cdet_nms_batched_idx(const cdet_nms_desc* d, const void* pred, fl
     a.max_det = d->max_det; a.max_nms = d->max_nms > 0 ? d->max_nms : 30000; a.max_cand = d->max_cand;
     a.classes = d->classes; a.n_classes = d->classes ? d->n_classes : 0;
     a.cap2 = next_pow2(d->max_cand);
+    a.sel_cap = nms_sel_cap(d);
     char* p = (char*)ws;
     a.cand = (Cand*)p; p += align256((int64_t)d->N * d->max_cand * sizeof(Cand));
-    a.keys = (unsigned long long*)p; p += align256((int64_t)d->N * a.cap2 * 8);
+    a.keys = (unsigned long long*)p; p += align256((int64_t)d->N * (a.cap2 + a.sel_cap) * 8);
     a.count = (int*)p; p += align256((int64_t)d->N * 4);
     a.seg_count = (int*)p;
     // enough segments to put a few workgroups on every CU, each a whole number of 256-anchor rounds
