@@ -214,13 +214,13 @@ def kernel_breakdown(trainer, batches, n_max):
         ms = e0.elapsed_time(e1)
         flops = 0.0
         key = name
-        if name in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad",
-                    "cdet_conv2d_s2_tiled", "cdet_conv2d_s2_tiled_dgrad"):
+        if name in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_bn", "cdet_conv2d_tiled_dgrad",
+                    "cdet_conv2d_s2_tiled", "cdet_conv2d_s2_tiled_bn", "cdet_conv2d_s2_tiled_dgrad"):
             d = args[0]._obj  # ctypes.byref(desc) keeps the descriptor
             if name == "cdet_conv2d_wgrad_grouped":  # args[2] layers of this geometry in one launch
                 key = "cdet_conv2d_wgrad"
                 flops = args[2] * 2.0 * d.N * d.Hd * d.Wd * d.Cd * d.Cs * d.kh * d.kw
-            elif name == "cdet_conv2d_s2_tiled":  # stride-2 forward on the parity-plane kernel (csrc/conv_vt.hip)
+            elif name in ("cdet_conv2d_s2_tiled", "cdet_conv2d_s2_tiled_bn"):  # stride-2 forward on the parity-plane kernel (csrc/conv_vt.hip)
                 key = "cdet_conv2d_s2_tiled[fwd]"
                 flops = 2.0 * d.N * d.Hd * d.Wd * d.Cd * d.Cs * d.kh * d.kw
             elif name == "cdet_conv2d_s2_tiled_dgrad":  # its data gradient: 4 class launches; FLOPs of the forward conv it differentiates

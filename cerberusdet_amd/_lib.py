@@ -24,6 +24,21 @@ class ConvDesc(C.Structure):
         "src_ld", "src_coff", "dst_ld", "dst_coff", "res_ld", "res_coff", "accumulate")]
 
 
+class BnFold(C.Structure):
+    """cdet_bn_fold (include/cerberus_hip.h): lives in DEVICE memory, read by the producing kernels at their very end."""
+    _fields_ = [("tickets", vp), ("cl_sums", vp), ("totals", vp), ("mean", vp), ("invstd", vp), ("running_mean", vp), ("running_var", vp),
+                ("dgamma", vp), ("dbeta", vp), ("inv_count", C.c_double), ("unbias", C.c_double), ("eps", f32), ("momentum", f32),
+                ("accumulate", i32), ("nrows", i32), ("C", i32), ("ncl", i32)]
+
+
+class BnRunningItem(C.Structure):
+    _fields_ = [("totals", vp), ("running_mean", vp), ("running_var", vp), ("inv_count", C.c_double), ("unbias", C.c_double),
+                ("momentum", f32), ("C", i32)]
+
+
+BN_FOLD_TICKET_WORDS = 8 * (1 + 128)
+
+
 class LossDesc(C.Structure):
     _fields_ = [("N", i32), ("nc", i32), ("n_max", i32), ("hw", i32 * 6), ("stride", f32 * 3), ("gain_box", f32),
                 ("gain_cls", f32), ("gain_dfl", f32), ("grad_scale", f32), ("dtype", i32), ("grad_dtype", i32),
@@ -120,6 +135,13 @@ _SIGS = {
     "cdet_letterbox_batch": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "cdet_mosaic_augment_batch": (i32, [vp, i32, vp, i32, vp]),
     "cdet_bn_finalize": (i32, [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp]),
+    "cdet_bn_fold_cl_doubles": (i64, [i32, i32]),
+    "cdet_conv2d_tiled_bn_ok": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_tiled_bn": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "cdet_conv2d_s2_tiled_bn_ok": (i32, [C.POINTER(ConvDesc)]),
+    "cdet_conv2d_s2_tiled_bn": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "cdet_bn_running_update": (i32, [vp, i32, i32, vp]),
+    "cdet_bn_silu_bwd_reduce_fold": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp]),
     "cdet_bn_silu_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, i32, vp]),
     "cdet_bn_bwd_blocks": (i32, [i64]),
     "cdet_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

@@ -47,16 +47,41 @@ __device__ __forceinline__ void bnf_std(__amdgpu_buffer_rsrc_t r, unsigned byte_
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bnf_u2, v), r, (int)byte_off, 0, 16);
 }
 
-// Sum of n (<= BNF_CL) values `stride` bytes apart, ascending, in double: all loads are issued before the first add.
+// Sum of n (<= BNF_CL) values `stride` bytes apart, ascending, in double: loads in two batches of 16 (all of a batch issued before its first add).
 __device__ __forceinline__ double bnf_sum_rows_f(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned stride, int n) {
-    float v[BNF_CL];
-#pragma unroll
-    for (int i = 0; i < BNF_CL; ++i) v[i] = i < n ? bnf_ldf(r, off + (unsigned)i * stride) : 0.f;
     double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < BNF_CL; ++i)
-        if (i < n) acc += (double)v[i];
+    for (int h = 0; h < BNF_CL; h += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = h + i < n ? bnf_ldf(r, off + (unsigned)(h + i) * stride) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (h + i < n) acc += (double)v[i];
+    }
     return acc;
+}
+
+// mean / invstd / running statistics of one channel from its fp32 totals [sum, sumsq] -- ONE definition for bn_finalize_kernel, the in-launch
+// fold and the batched running-statistics update. Every multiply-add is an EXPLICIT fma whose other operands are plain products: nothing is left
+// for the compiler's contraction to decide (measured: with `a * b + c * d` the same source rounded differently inside conv_halo_kernel and inside
+// bn_finalize_kernel, `#pragma clang fp contract(off)` notwithstanding) -- the call sites must agree to the bit.
+__device__ __forceinline__ void bn_stats_from_totals(float sf, float qf, double inv_count, double unbias, float eps, float momentum, float* mean,
+                                                     float* invstd, float* running_mean, float* running_var) {
+    const double m = (double)sf * inv_count;
+    const double mm = m * m;
+    double var = fma((double)qf, inv_count, -mm);
+    if (var < 0.0) var = 0.0;
+    if (mean != nullptr) *mean = (float)m;
+    if (invstd != nullptr) *invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+        const float keep = 1.f - momentum;
+        const float km = keep * *running_mean;
+        *running_mean = fmaf(momentum, (float)m, km);
+        const float kv = keep * *running_var;
+        const double vu = var * unbias;
+        *running_var = fmaf(momentum, (float)vu, kv);
+    }
 }
 
 // Called by ALL threads of the workgroup (uniformly) after the workgroup's share of its partial row has been stored with bnf_stf.
@@ -107,16 +132,16 @@ __device__ __forceinline__ void bn_fold_finish(const BnFold* __restrict__ fp, co
         const int col = c0 + j;
         if (col >= C) continue;
         double s = 0.0, q = 0.0;
-        for (int k0 = 0; k0 < ncl; k0 += 16) {
-            double vs[16], vq[16];
+        for (int k0 = 0; k0 < ncl; k0 += 8) {
+            double vs[8], vq[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const bool in = k0 + i < ncl;
                 vs[i] = in ? bnf_ldd(rc, (unsigned)((((int64_t)(k0 + i) * 2 + 0) * C + col) * 8)) : 0.0;
                 vq[i] = in ? bnf_ldd(rc, (unsigned)((((int64_t)(k0 + i) * 2 + 1) * C + col) * 8)) : 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < 8; ++i)
                 if (k0 + i < ncl) {
                     s += vs[i];
                     q += vq[i];
@@ -128,17 +153,9 @@ __device__ __forceinline__ void bn_fold_finish(const BnFold* __restrict__ fp, co
             fp->totals[C + col] = qf;
         }
         if (FWD) {
-            const double sd = (double)sf, qd = (double)qf;
-            const double m = sd * fp->inv_count;
-            double var = qd * fp->inv_count - m * m;
-            if (var < 0.0) var = 0.0;
-            fp->mean[col] = (float)m;
-            fp->invstd[col] = (float)(1.0 / sqrt(var + (double)fp->eps));
-            if (fp->running_mean != nullptr) {
-                const float momentum = fp->momentum;
-                fp->running_mean[col] = (1.f - momentum) * fp->running_mean[col] + momentum * (float)m;
-                fp->running_var[col] = (1.f - momentum) * fp->running_var[col] + momentum * (float)(var * fp->unbias);
-            }
+            bn_stats_from_totals(sf, qf, fp->inv_count, fp->unbias, fp->eps, fp->momentum, fp->mean + col, fp->invstd + col,
+                                 fp->running_mean != nullptr ? fp->running_mean + col : nullptr,
+                                 fp->running_mean != nullptr ? fp->running_var + col : nullptr);
         } else {
             if (fp->dbeta != nullptr) fp->dbeta[col] = (fp->accumulate ? fp->dbeta[col] : 0.f) + sf;
             if (fp->dgamma != nullptr) fp->dgamma[col] = (fp->accumulate ? fp->dgamma[col] : 0.f) + qf;

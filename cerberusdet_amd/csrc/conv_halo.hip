@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
                 a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
             }
         }
-        if (a.fold != nullptr) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cb, reinterpret_cast<volatile int*>(smem));
+        if (a.fold != nullptr) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem));
     }
 #ifdef CDET_PROFILING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -974,7 +974,7 @@ extern "C" int cdet_conv2d_tiled_cat(const cdet_conv_desc* d, const cdet_cat_src
     CDET_CHECK_ARG(d->out_dtype == d->dtype, "cdet_conv2d_tiled_cat: 16-bit in == out");
     cdet_conv_desc dd = *d;
     dd.src_ld = (d->Cs + 7) / 8 * 8; dd.src_coff = 0;
-    return conv2d_tiled_impl(&dd, srcs[0].x, w_tiled, scale, bias, residual, y, nullptr, stream, &c);
+    return conv2d_tiled_impl(&dd, srcs[0].x, w_tiled, scale, bias, residual, y, nullptr, stream, &c, nullptr);
 }
 
 extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
@@ -999,7 +999,7 @@ extern "C" int cdet_conv2d_tiled_bn_ok(const cdet_conv_desc* d) {
 }
 
 static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
-                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat, const BnFold* fold = nullptr) {
+                             const void* residual, void* y, float* stats, void* stream, const CatSrcs* cat, const BnFold* fold) {
     CDET_CHECK_ARG(d && x && w_tiled && y, "cdet_conv2d_tiled: null pointer");
     const HaloPlan pl = halo_plan(d);
     CDET_CHECK_ARG(pl.ok, "cdet_conv2d_tiled: unsupported geometry (need stride 1, k in {1,3}, Cs/Cd/ld/coff %% 8 == 0, 16-bit in, out = the same "

@@ -691,6 +691,9 @@ static void vt_fill(VtArgs& a, const cdet_conv_desc* d, const VtPlan& pl, bool d
     a.accum = d->accumulate ? 1 : 0;
 }
 
+static int s2_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual,
+                         void* y, float* stats, void* stream, const BnFold* fold);
+
 extern "C" int cdet_conv2d_s2_tiled(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias,
                                     const void* residual, void* y, float* stats, void* stream) {
     return s2_tiled_impl(d, x, w_tiled, scale, bias, residual, y, stats, stream, nullptr);
@@ -716,9 +719,6 @@ static int s2_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_t
     CDET_LAUNCH_CHECK();
     return 0;
 }
-
-static int s2_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual,
-                         void* y, float* stats, void* stream, const BnFold* fold);
 
 extern "C" int cdet_conv2d_s2_tiled_bn_ok(const cdet_conv_desc* d) {
     if (!d || !cdet_conv2d_s2_tiled_ok(d) || d->out_dtype == CDET_F32 || d->mode != CDET_CONV_FWD) return 0;

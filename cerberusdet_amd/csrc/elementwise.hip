@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bn_fold.h"
 
 #include <type_traits>
 
@@ -76,12 +77,40 @@ __device__ __forceinline__ ColMap col_map(int CV) {
 // handful of workgroups each, i.e. their LATENCY is on the critical path: 1024 threads (64 groups) instead of 256 cut the serial
 // loop 4x (measured: skipping them entirely saves 7.1 ms of a 99 ms iteration).
 constexpr int BN_RED_THREADS = 1024;
+// Round 5: for launches of at most BNF_CL * BNF_MAX_CL = 4096 partial rows the sums follow the fixed TREE of bn_fold.h -- clusters of 32 consecutive
+// rows added ascending in double, then the cluster sums added ascending in double -- which is the order the producers use when they reduce their
+// own partials in-launch: the two forms give the same bits. (Longer lists -- the round-1 generic kernel's rows -- keep the strided two-chain order.)
 __device__ __forceinline__ bool bn_reduce_partials(const float* __restrict__ part, int nblk, int C, int c, double& s, double& q) {
     constexpr int NG = BN_RED_THREADS / 16;
-    __shared__ double sh[2][NG][16];
+    __shared__ double sh[2][BNF_MAX_CL][16];
+    static_assert(BNF_MAX_CL >= NG, "the strided form keeps one LDS row per thread group");
     const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
     s = 0.0;
     q = 0.0;
+    const int ncl = (nblk + BNF_CL - 1) / BNF_CL;
+    if (ncl <= BNF_MAX_CL) {
+        for (int cl = g; cl < ncl; cl += NG) {
+            double a = 0.0, b = 0.0;
+            if (c < C) {
+                const int r0 = cl * BNF_CL, n = min(BNF_CL, nblk - r0);
+                const float* p0 = part + ((int64_t)r0 * 2) * C + c;
+#pragma unroll 8
+                for (int i = 0; i < n; ++i) {  // ascending, one double chain per quantity (the loads run ahead of the adds)
+                    a += (double)p0[(int64_t)i * 2 * C];
+                    b += (double)p0[(int64_t)i * 2 * C + C];
+                }
+            }
+            sh[0][cl][cx] = a;
+            sh[1][cl][cx] = b;
+        }
+        __syncthreads();
+        if (g != 0 || c >= C) return false;
+        for (int k = 0; k < ncl; ++k) {
+            s += sh[0][k][cx];
+            q += sh[1][k][cx];
+        }
+        return true;
+    }
     if (c < C) {
         float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
         int b = g, it = 0;
@@ -132,6 +161,14 @@ __device__ __forceinline__ bool bn_reduce_partials(const float* __restrict__ par
     return true;
 }
 
+// deferred running-statistics updates of many layers, one workgroup (256 threads) per item: the arithmetic of bn_finalize_kernel on fp32 totals
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const cdet_bn_running_item* __restrict__ items) {
+    const cdet_bn_running_item it = items[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256)
+        bn_stats_from_totals(it.totals[c], it.totals[it.C + c], it.inv_count, it.unbias, 0.f, it.momentum, nullptr, nullptr, it.running_mean + c,
+                             it.running_var + c);
+}
+
 __global__ __launch_bounds__(BN_RED_THREADS) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int C, double inv_count,
                                                                      double unbias, float eps, float momentum, float* running_mean,
                                                                      float* running_var, float* mean, float* invstd) {
@@ -142,17 +179,8 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_finalize_kernel(const float
     // (bn_bwd_sums_kernel -> all-reduce -> this kernel with nblk = 1), so the per-GPU list and the synchronised one derive mean / invstd from the
     // same numbers -- bit-identical at world 1, and exactly "twice the sums over twice the count" when two ranks hold the same shard
     // (tests/test_gpu_distributed.py).
-    s = (double)(float)s;
-    q = (double)(float)q;
-    const double m = s * inv_count;
-    double var = q * inv_count - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
-    }
+    bn_stats_from_totals((float)s, (float)q, inv_count, unbias, eps, momentum, mean + c, invstd + c, running_mean ? running_mean + c : nullptr,
+                         running_mean ? running_var + c : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,7 +511,8 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce2_kernel(const uint16_t
                                                                   const uint16_t* __restrict__ z, int z_ld, int z_coff,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                  float* __restrict__ part, int64_t M, int C, int CV) {
+                                                                  float* __restrict__ part, int64_t M, int C, int CV,
+                                                                  const BnFold* __restrict__ fold) {
     extern __shared__ float shm[];  // [rows_per_pass][2][C]
     const ColMap cm = col_map(CV);
     const int c = cm.cv * 8;
@@ -534,11 +563,22 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce2_kernel(const uint16_t
         }
     }
     __syncthreads();
+    if (fold == nullptr) {
+        for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
+            float acc = 0.f;
+            for (int r = 0; r < cm.rows_per_pass; ++r) acc += shm[r * 2 * C + j];
+            part[(int64_t)blockIdx.x * 2 * C + j] = acc;
+        }
+        return;
+    }
+    // the partial rows are reduced in this launch (bn_fold.h): write-through row, ticket, the last arrivers add up in the fixed tree order
+    const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(part);
     for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
         float acc = 0.f;
         for (int r = 0; r < cm.rows_per_pass; ++r) acc += shm[r * 2 * C + j];
-        part[(int64_t)blockIdx.x * 2 * C + j] = acc;
+        bnf_stf(rs_, (unsigned)(((int64_t)blockIdx.x * 2 * C + j) * 4), acc);
     }
+    bn_fold_finish<false>(fold, part, (int)blockIdx.x, 0, C, 0, reinterpret_cast<volatile int*>(shm));
 }
 
 template <int DT, bool ALSO>
@@ -1055,9 +1095,39 @@ extern "C" int cdet_bn_bwd_blocks(int64_t M) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+static int bn_silu_bwd_reduce_impl(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, float* part, int64_t M, int32_t C, int32_t dtype,
+                                   const cdet_bn_fold* fold, void* stream);
+
 extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
                                        const float* mean, const float* invstd, const float* gamma, const float* beta, float* part, int64_t M,
                                        int32_t C, int32_t dtype, void* stream) {
+    return bn_silu_bwd_reduce_impl(dy, dy_ld, dy_coff, z, z_ld, z_coff, mean, invstd, gamma, beta, part, M, C, dtype, nullptr, stream);
+}
+
+extern "C" int cdet_bn_silu_bwd_reduce_fold(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                            const float* mean, const float* invstd, const float* gamma, const float* beta, float* part, int64_t M,
+                                            int32_t C, int32_t dtype, const cdet_bn_fold* fold_dev, void* stream) {
+    CDET_CHECK_ARG(fold_dev, "cdet_bn_silu_bwd_reduce_fold: null descriptor");
+    CDET_CHECK_ARG(bn_v2() && bn_small(M, dy_ld) && bn_small(M, z_ld), "cdet_bn_silu_bwd_reduce_fold: tensors of 2 GiB and more take the two-launch form");
+    return bn_silu_bwd_reduce_impl(dy, dy_ld, dy_coff, z, z_ld, z_coff, mean, invstd, gamma, beta, part, M, C, dtype, fold_dev, stream);
+}
+
+extern "C" int64_t cdet_bn_fold_cl_doubles(int32_t nrows, int32_t C) {
+    if (nrows <= 0 || C <= 0 || nrows > BNF_CL * BNF_MAX_CL) return -1;
+    return (int64_t)((nrows + BNF_CL - 1) / BNF_CL) * 2 * C;
+}
+
+extern "C" int cdet_bn_running_update(const cdet_bn_running_item* items_dev, int32_t n_items, int32_t max_C, void* stream) {
+    CDET_CHECK_ARG(items_dev && n_items > 0 && max_C > 0, "cdet_bn_running_update: bad arguments");
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(n_items), dim3(256), 0, (hipStream_t)stream, items_dev);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+static int bn_silu_bwd_reduce_impl(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, float* part, int64_t M, int32_t C, int32_t dtype,
+                                   const cdet_bn_fold* fold, void* stream) {
     if (int e = check16("cdet_bn_silu_bwd_reduce", dtype, C, dy_ld, dy_coff, z_ld, z_coff)) return e;
     CDET_CHECK_ARG(C / 8 <= 256, "cdet_bn_silu_bwd_reduce: C too large");
     const int CV = C / 8, rpp = 256 / CV;
@@ -1066,7 +1136,7 @@ extern "C" int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy
     if (bn_v2() && bn_small(M, dy_ld) && bn_small(M, z_ld)) {
         DISPATCH16(dtype, hipLaunchKernelGGL((bn_silu_bwd_reduce2_kernel<DT>), dim3(cdet_bn_bwd_blocks(M)), dim3(256), shm, (hipStream_t)stream,
                                              (const uint16_t*)dy, dy_ld, dy_coff, (const uint16_t*)z, z_ld, z_coff, mean, invstd, gamma, beta, part,
-                                             M, C, CV));
+                                             M, C, CV, fold));
         CDET_LAUNCH_CHECK();
         return 0;
     }

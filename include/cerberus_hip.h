@@ -276,6 +276,50 @@ int cdet_mosaic_augment_batch(const cdet_aug_sample* samples, int32_t B, void* o
 /* Reduce the conv kernel's partial sums -> mean, invstd (biased var), update running stats (unbiased var). */
 int cdet_bn_finalize(const float* stats, int32_t nblk, int32_t C, int64_t count, float eps, float momentum,
                      float* running_mean, float* running_var, float* mean, float* invstd, void* stream);
+/* Round 5 -- the reduction of the partial sums INSIDE the launch that produces them (csrc/bn_fold.h): the per-layer cdet_bn_finalize launch (and the
+ * bn_bwd_sums launch inside cdet_bn_silu_bwd_apply) of the reference's nn.BatchNorm2d in train mode (models/common.py:57-62) disappear from the
+ * per-GPU training plans. The producers -- cdet_conv2d_tiled_bn, cdet_conv2d_s2_tiled_bn (raw 16-bit convolution output + partial rows), and
+ * cdet_bn_silu_bwd_reduce_fold -- take a DEVICE-resident descriptor: every workgroup stores its share of a partial row (write-through), draws a
+ * ticket; the last arriver of each cluster of 32 rows adds the cluster's rows (ascending, double), the last arriver over the clusters adds the
+ * cluster sums (ascending, double), rounds the totals to fp32 and finishes exactly as cdet_bn_finalize / cdet_bn_bwd_sums do. The order of every
+ * addition is fixed by row numbers, and cdet_bn_finalize / cdet_bn_bwd_sums use the same tree (for <= 4096 rows): results are bit-identical with
+ * and without the fold. fold_dev == NULL: the partial rows only (the caller runs cdet_bn_finalize). SyncBatchNorm plans keep the separate
+ * kernels (the exchange sits between them).
+ *   tickets   CDET_BN_FOLD_TICKET_WORDS 32-bit words, zeroed ONCE by the caller (the last arrivers reset them); one set per stream of launches
+ *   cl_sums   cdet_bn_fold_cl_doubles(rows, C) doubles of scratch
+ *   totals    optional [2][C] fp32: the rounded totals ([sum, sumsq] forward -- what a deferred running-statistics update or SyncBatchNorm
+ *             reads; [sum dact, sum dact xhat] backward = the `sums` vector cdet_bn_silu_bwd_apply(nblk = 0) takes)
+ *   forward   mean, invstd (out), running_mean / running_var (in/out, may be NULL), inv_count = 1 / count, unbias = count / (count - 1), eps, momentum
+ *   backward  dgamma, dbeta (+= when accumulate), the rest unused
+ *   nrows     partial rows of the launch; C channels; ncl = ceil(nrows / 32) */
+typedef struct {
+    uint32_t* tickets;
+    double* cl_sums;
+    float* totals;
+    float *mean, *invstd, *running_mean, *running_var;
+    float *dgamma, *dbeta;
+    double inv_count, unbias;
+    float eps, momentum;
+    int32_t accumulate, nrows, C, ncl;
+} cdet_bn_fold;
+#define CDET_BN_FOLD_TICKET_WORDS (8 * (1 + 128))
+int64_t cdet_bn_fold_cl_doubles(int32_t nrows, int32_t C);
+int cdet_conv2d_tiled_bn_ok(const cdet_conv_desc* d);      /* 1: the launch's rows (<= 4096) and 160-cout blocks (<= 8) fit the fold */
+int cdet_conv2d_tiled_bn(const cdet_conv_desc* d, const void* x, const void* w_tiled, void* y, float* stats, const cdet_bn_fold* fold_dev,
+                         void* stream);
+int cdet_conv2d_s2_tiled_bn_ok(const cdet_conv_desc* d);
+int cdet_conv2d_s2_tiled_bn(const cdet_conv_desc* d, const void* x, const void* w_tiled, void* y, float* stats, const cdet_bn_fold* fold_dev,
+                            void* stream);
+/* Running-statistics updates of many layers from their fp32 totals in ONE launch (the later task's deferred updates of a shared block, see
+ * engine.Plan.deferred_stats): per item exactly cdet_bn_finalize(totals, nblk = 1, ...)'s running_mean / running_var arithmetic. */
+typedef struct {
+    const float* totals;           /* [2][C] */
+    float *running_mean, *running_var;
+    double inv_count, unbias;
+    float momentum;
+    int32_t C;
+} cdet_bn_running_item;
+int cdet_bn_running_update(const cdet_bn_running_item* items_dev, int32_t n_items, int32_t max_C, void* stream);
 /* y = silu(gamma*(z-mean)*invstd + beta) (+ residual); z,y [M, C] with strides. */
 int cdet_bn_silu_fwd(const void* z, int32_t z_ld, int32_t z_coff, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, const void* residual, int32_t res_ld, int32_t res_coff,
@@ -286,6 +330,11 @@ int cdet_bn_bwd_blocks(int64_t M);
 int cdet_bn_silu_bwd_reduce(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
                             const float* mean, const float* invstd, const float* gamma, const float* beta,
                             float* part, int64_t M, int32_t C, int32_t dtype, void* stream);
+/* The same pass with the reduction of its partial rows folded in (cdet_bn_fold above, backward form): fold_dev->totals receives the sums
+ * [2C] that cdet_bn_silu_bwd_apply takes with nblk = 0, dgamma / dbeta are written by the last arriver. */
+int cdet_bn_silu_bwd_reduce_fold(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 float* part, int64_t M, int32_t C, int32_t dtype, const cdet_bn_fold* fold_dev, void* stream);
 /* pass 2: reduce partials -> dgamma(+)=, dbeta(+)=; dz = gamma*invstd*(dact - mean(dact) - xhat*mean(dact*xhat)).
  * `part` must hold (nblk*2*C + 2*C) floats: the reduced sums are stored behind the partials. */
 int cdet_bn_silu_bwd_apply(const void* dy, int32_t dy_ld, int32_t dy_coff, const void* z, int32_t z_ld, int32_t z_coff,

@@ -34,8 +34,8 @@ def main():
     groups = OrderedDict()
     for fn, args in calls:
         name = getattr(fn, "__name__", "")
-        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad",
-                        "cdet_conv2d_s2_tiled", "cdet_conv2d_s2_tiled_dgrad"):
+        if name not in ("cdet_conv2d", "cdet_conv2d_wgrad", "cdet_conv2d_wgrad_grouped", "cdet_conv2d_tiled", "cdet_conv2d_tiled_bn", "cdet_conv2d_tiled_dgrad",
+                        "cdet_conv2d_s2_tiled", "cdet_conv2d_s2_tiled_bn", "cdet_conv2d_s2_tiled_dgrad"):
             continue
         d = args[0]._obj
         if name == "cdet_conv2d_wgrad_grouped":  # n = layers; the timed call is the whole group (ms and TF/s are per group launch)
