@@ -72,7 +72,7 @@ def test_half_width_train_plan_every_launch_vs_fp32_layer(which):
     if which == "both":  # a backbone tap that both tasks' necks concatenate is copied, not placed (overwrite / accumulate bookkeeping)
         assert "copy" in kinds
     names = {getattr(fn, "__name__", "") for _, cs in plan.bwd_groups for fn, _ in cs} | {getattr(fn, "__name__", "") for fn, _ in plan.fwd}
-    assert {"cdet_conv2d_tiled_bn", "cdet_conv2d_tiled_dgrad", "cdet_conv2d", "cdet_conv2d_wgrad"} <= names  # (_bn: statistics finished in the launch)
+    assert {"cdet_conv2d_tiled", "cdet_conv2d_tiled_dgrad", "cdet_conv2d", "cdet_conv2d_wgrad"} <= names
     rep, n = _run(plan, img, tasks, ncs)
     print(f"[teacher/half-width/{which}] {n} backward units, {len(rep.rows)} tensors: {rep.summary()}")
     assert n >= 60
