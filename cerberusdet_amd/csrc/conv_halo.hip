@@ -75,9 +75,18 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // of 256 consecutive pixels (halo 256 + 2W + 2 rows) -- half the halo on the 80-wide maps, and the only form that fits for 160-wide.
 // ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no epilogue
 // stores, 16 = no K loop
+// NG = 4 (round 5): the 512-pixel tile. ONE workgroup per CU, one wave per SIMD with all 512 registers of a lane: a wave owns 128 pixels x 160 couts =
+// 20 accumulator tiles (16 of them in AccVGPRs). Per k16 it reads (128 + 160) x 32 B of fragments for 20 MFMAs -- 461 B per MFMA against the 717 B of
+// the 64 x 160 wave tile -- and the workgroup's weight ring serves twice the pixels: LDS reads per FLOP -36 %, weight LDS-DMA per FLOP -50 %, one
+// barrier per 40 MFMAs instead of per 20. (Measured on the 256-pixel form, profiling build, 40 x 40 320 -> 320: the K loop takes 98 us, its MFMAs alone
+// 55, everything but the MFMAs alone 48 -- the two do not overlap; tools/conv_tiled_bench.py with CDET_HALO_ABLATE.)
 template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false, bool CAT = false>
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const HaloArgs a) {
     static_assert(!CAT || (NT == 1 && !PATCH && !OMAP), "a virtual-Concat source is a 1x1 convolution's");
+    static_assert(NG != 4 || (NT == 9 && !PATCH && !OMAP && !CAT && NSW == 6), "the 512-pixel tile: 3x3, linear halo, six-stage weight ring");
+    static_assert(NSW == 2 || NSW == 3 || (NSW == 6 && NT == 9), "weight ring depths");
+    constexpr int XPS = NG == 4 ? 2 : 1;  // pixel DMA pieces a wave issues per K step (taps 0..6 of a chunk fetch the next chunk's halo)
+    constexpr int MAXXPK = MAXXP * XPS;   // pieces per wave per chunk: XH <= 448 (896) rows
     constexpr int HPB = 128 * NG;         // pixels per block: a wave owns NG 32-pixel fragments (NG = 1: half tiles for layers whose
                                           // 256-pixel tiles would leave most CUs idle, e.g. the 20 x 20 maps at batch 32)
     static_assert(NG == 2 || !PATCH, "the 16 x 16 patch form is a 256-pixel tile");
@@ -136,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     // ---- X DMA pieces of this wave: piece id 4*i + wave covers halo rows 16*id .. 16*id+15, 4 lanes (64 B) per row --------------
     const int nxp_total = a.XH >> 4;
     const int nxpw = (nxp_total - wave + 3) >> 2;  // wave-uniform
-    unsigned xvoff[MAXXP];
+    unsigned xvoff[MAXXPK];
 #pragma unroll
-    for (int i = 0; i < MAXXP; ++i) {
+    for (int i = 0; i < MAXXPK; ++i) {
         const int hrow = 16 * (4 * i + wave) + (lane >> 2);
         int g;
         bool ok;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
 
     // ---- prologue: chunk 0 of X (1x1: chunks 0 and 1), weight tiles of steps 0 .. NSW-1 -------------------------------------------
 #pragma unroll
-    for (int i = 0; i < MAXXP; ++i)
+    for (int i = 0; i < MAXXPK; ++i)
         if (i < nxpw) dma_x(i, 0, 0);
 #pragma unroll
     for (int j = 0; j < NWP; ++j) dma_w1(0, 0, j);
@@ -294,12 +303,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         for (int i = 0; i < NXP1; ++i) dma_x(i, 1, 1);
     }
 #pragma unroll
-    for (int j = 0; j < NWP; ++j) dma_w1(1, 1, j);
-    if (NSW == 3) {
+    for (int sg = 1; sg < NSW; ++sg) {
 #pragma unroll
-        for (int j = 0; j < NWP; ++j) dma_w1(2, 2, j);
+        for (int j = 0; j < NWP; ++j) dma_w1(sg, sg, j);
     }
-    wait_vm((NT == 1 ? NXP1 : 0) + (NSW - 1) * NWP);  // tile 0 and chunk 0 have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NT == 1 ? NXP1 : 0) + (NSW - 1) * NWP) : "memory");  // tile 0 and chunk 0 have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -351,20 +359,27 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
     // `chunk` is the step's channel chunk, `st` its index.
     auto step = [&](int st, int chunk, int u, auto HK) {
         constexpr bool halfk = decltype(HK)::value;  // the step's second k16 half holds zero channels only: no reads, no MFMAs for it
-        const int sc = NSW == 3 ? u % 3 : (st & 1);           // ring stage of this step's tile (compile-time for NSW == 3)
-        const int sn = NSW == 3 ? (u + 1) % 3 : ((st + 1) & 1);
+        // ring stage of this step's tile: compile-time for NSW == 3 (nine taps = three turns of the ring); NSW == 6 (the 512-pixel tile): st % 6 =
+        // (3 chunk + u) % 6 -- one of two compile-time constants, selected by the chunk's parity (a scalar select)
+        const int sc = NSW == 3 ? u % 3 : (NSW == 6 ? ((chunk & 1) ? (u + 3) % 6 : u % 6) : (st & 1));
+        const int sn = NSW == 3 ? (u + 1) % 3 : (NSW == 6 ? ((chunk & 1) ? (u + 4) % 6 : (u + 1) % 6) : ((st + 1) & 1));
         const unsigned char* ws = wbase + sc * WTILE;
         const unsigned char* wsn = wbase + sn * WTILE;
         const int tapn = NT == 9 ? (u + 1) % 9 : 0;
         const int chunkn = NT == 9 ? chunk + (u == 8 ? 1 : 0) : chunk + 1;
         const int xbn = NT == 9 ? (chunkn & 1) : (u + 1) % 3;  // pixel buffer of step st+1
-        const bool xa = NT == 9 && u < MAXXP && u < nxpw;      // a pixel piece of the next chunk is issued in phase A (wave-uniform)
+        // pixel pieces of the next chunk issued in this step's phase A (wave-uniform): pieces XPS u .. XPS u + XPS - 1 at taps u = 0..6
+        const int na = (NT == 9 && u < MAXXP) ? min(max(nxpw - XPS * u, 0), XPS) : 0;
+        const bool xa = na > 0;
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase A: MFMAs of (st, k16 #0); the fragment reads of (st, k16 #1), the address arithmetic of step st+1 and the pixel
         //      pieces of the next chunk (3x3: one per step; 1x1: the whole chunk st+2 into the third buffer) in their shadow
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (!(ABL & 4)) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
+            if (!(ABL & 4)) {
+                if (NG == 4 && i < 16) mfma32a<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);  // (tiles 0..15 of the 512-pixel form: AccVGPRs)
+                else mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
+            }
             // two fragment reads per MFMA slot: they are all in flight after the first half of the phase, so the lgkmcnt(0) at its
             // end waits for LDS latency that the second half has already covered (one read per slot left ~140 clocks per step exposed)
             if (!halfk && 2 * i < NR) frag(ws, bo_cur, 1, 2 * i, a1, b1);
@@ -373,7 +388,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             if (!(ABL & 1)) {
                 if (NT == 9) {
                     if (i == NM - 2 && u < MAXXP) {
-                        if (xa) dma_x(u, chunk + 1, (chunk + 1) & 1);
+                        if (xa) dma_x(XPS * u, chunk + 1, (chunk + 1) & 1);
+                    }
+                    if (XPS == 2 && i == NM - 3 && u < MAXXP) {
+                        if (na > 1) dma_x(XPS * u + 1, chunk + 1, (chunk + 1) & 1);
                     }
                 } else if (i < NXP1) {
                     dma_x(i, chunk + 2, (u + 2) % 3);
@@ -393,10 +411,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
             // vmcnt retires in order: what must have landed is the weight tile of step st+1 (issued two phase-Bs ago); everything
             // issued after it may stay in flight -- the newest weight tile and the pixel pieces of this and the previous phase A
             // (pixel pieces are only issued at taps 0..6, so at tap 8, when phase B first reads the next chunk, none is left)
-            const bool xp = u >= 1 && u - 1 < MAXXP && u - 1 < nxpw;  // wave-uniform; xa implies xp for u >= 1
-            if (xa && xp) wait_vm_lgkm0<(NSW - 2) * NWP + 2>();
-            else if (xa || xp) wait_vm_lgkm0<(NSW - 2) * NWP + 1>();
-            else wait_vm_lgkm0<(NSW - 2) * NWP>();
+            const int np = (u >= 1 && u - 1 < MAXXP) ? min(max(nxpw - XPS * (u - 1), 0), XPS) : 0;  // pieces of the previous step's phase A
+            switch (na + np) {  // wave-uniform
+                case 0: wait_vm_lgkm0<(NSW - 2) * NWP>(); break;
+                case 1: wait_vm_lgkm0<(NSW - 2) * NWP + 1>(); break;
+                case 2: wait_vm_lgkm0<(NSW - 2) * NWP + 2>(); break;
+                case 3: wait_vm_lgkm0<(NSW - 2) * NWP + 3>(); break;
+                default: wait_vm_lgkm0<(NSW - 2) * NWP + 4>(); break;
+            }
         } else {
             wait_vm_lgkm0<(NSW - 2) * NWP + NXP1>();
         }
@@ -413,7 +435,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloArgs a) {
         //      (st+1, k16 #0) in their shadow
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (!(ABL & 4) && !halfk) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+            if (!(ABL & 4) && !halfk) {
+                if (NG == 4 && i < 16) mfma32a<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+                else mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+            }
             if (!(ABL & 1)) {
                 if (i == 0) dma_w1(st + NSW, sc, 0);
                 if (i == (NM >= 10 ? 3 : (NM >= 6 ? 2 : 1))) dma_w1(st + NSW, sc, 1);
@@ -743,9 +768,11 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
     // half tiles (128 pixels, one 32-pixel fragment per wave) when 256-pixel tiles would not even give every CU one workgroup
     pl.ng = (div_up(M, HP) * div_up(d->Cd, rb) < 256 && M > 128) ? 1 : 2;
-    if (const char* e = getenv("CDET_HALO_NG")) {  // CDET_HALO_NG=1|2 pins the tile size (tests cover both forms on the same shapes; A/B timing)
+    if (const char* e = getenv("CDET_HALO_NG")) {  // CDET_HALO_NG=1|2|4 pins the tile size (tests cover the forms on the same shapes; A/B timing)
         const int force = atoi(e);
         if (force == 1 || force == 2) pl.ng = force;
+        // the 512-pixel tile (one workgroup per CU): 3x3, 160-cout blocks, 16-bit output, linear halo (maps up to 95 wide)
+        if (force == 4 && d->kh == 3 && rb == 160 && d->out_dtype != CDET_F32 && d->Ws <= 95) pl.ng = 4;
     }
     pl.hp = 128 * pl.ng;
     if (d->kh == 1) {
@@ -754,13 +781,13 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     } else {
         const int lin = (pl.hp + 2 * (d->Ws + 1) + 15) / 16 * 16;
         const int pat = (PATCH_HPW * PATCH_HPW + 15) / 16 * 16;  // 336
-        pl.patch = d->Hs % PATCH_W == 0 && d->Ws % PATCH_W == 0 && pat < (HP + 2 * (d->Ws + 1) + 15) / 16 * 16;
+        pl.patch = pl.ng != 4 && d->Hs % PATCH_W == 0 && d->Ws % PATCH_W == 0 && pat < (HP + 2 * (d->Ws + 1) + 15) / 16 * 16;
         if (pl.patch) {  // 16 x 16 patches are 256-pixel tiles
             pl.ng = 2;
             pl.hp = HP;
         }
         pl.XH = pl.patch ? pat : (pl.ng == 2 ? (HP + 2 * (d->Ws + 1) + 15) / 16 * 16 : lin);
-        if (pl.XH > 16 * 4 * MAXXP) return pl;
+        if (pl.XH > 16 * 4 * MAXXP * (pl.ng == 4 ? 2 : 1)) return pl;
     }
     if (M >= (1ll << 31) - HP) return pl;
     if (M * d->src_ld * 2 >= 0xC0000000ll) return pl;
@@ -769,7 +796,9 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     pl.nxb = d->kh == 1 ? 3 : 2;
     // ring depth: three stages when two workgroups still fit a CU (80 KiB each); the patch, 1x1 and half-tile forms always do
     const size_t base = (size_t)HZERO + (size_t)pl.nxb * pl.XH * HROW;
-    pl.nsw = base + 3 * (size_t)rb * HROW <= 80 * 1024 ? 3 : 2;
+    // (the 512-pixel tile has the CU's LDS to itself: a six-stage ring keeps five weight tiles in flight -- the LDS-DMA stream of a workgroup is
+    //  latency-bound, (stages - 1) x 10 KB per ~2 us)
+    pl.nsw = pl.ng == 4 ? 6 : (base + 3 * (size_t)rb * HROW <= 80 * 1024 ? 3 : 2);
     if ((pl.patch || d->kh == 1 || pl.ng == 1) && pl.nsw != 3) return pl;
     pl.lds = base + (size_t)pl.nsw * rb * HROW;
     const size_t epi = (size_t)HZERO + HEPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16);  // the epilogue's store staging
@@ -844,7 +873,9 @@ static void dispatch_halo_cat(const HaloArgs& a, const HaloPlan& pl, int nblocks
 
 template <int DT, int NF, int EPI>
 static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nblocks, hipStream_t s) {
-    if (pl.ng == 1) {
+    if (pl.ng == 4) {
+        if constexpr (NF == 5 && EPI != HEPI_F32) launch_halo<DT, 9, 5, EPI, 6, false, 4>(a, pl.lds, nblocks, s);
+    } else if (pl.ng == 1) {
         if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
         else launch_halo<DT, 9, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
     } else if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 2>(a, pl.lds, nblocks, s);

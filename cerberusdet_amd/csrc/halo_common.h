@@ -47,6 +47,14 @@ __device__ __forceinline__ void mfma32(const u32x4& a, const u32x4& b, f32x16& c
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
+// the same MFMA with the accumulator in AccVGPRs (the 512-pixel tile form, conv_halo.hip NG = 4: 20 accumulator tiles = 320 registers per lane, of
+// which 16 tiles live in the wave's 256 AccVGPRs and 4 in ArchVGPRs; one wave per SIMD owns all 512 registers of a lane)
+template <int DT>
+__device__ __forceinline__ void mfma32a(const u32x4& a, const u32x4& b, f32x16& c) {
+    if (DT == CDET_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 template <int AUX = 0>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned char* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, AUX);
