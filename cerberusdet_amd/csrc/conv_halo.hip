@@ -659,7 +659,13 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
 //                     plain forward convolution of dY with this operand
 // One workgroup transposes a [32 o][32 i][taps] tile through LDS (the master is read once, in runs of 32*taps floats).
 // ------------------------------------------------------------------------------------------------------------------------------------
+// (CDET_RB160_AS_96, experiment builds only: 160-row operands as two 96-row blocks -- the 174-179-VGPR instantiation instead of the 251-VGPR one, so that
+//  a BatchNorm wave of the other task's pass fits beside two convolution workgroups on a SIMD; profiles/r05_bn_beside_conv.txt)
+#ifdef CDET_RB160_AS_96
+static __host__ __device__ __forceinline__ int row_block(int rows) { return (rows <= 96 || rows == 160) ? 96 : 160; }
+#else
 static __host__ __device__ __forceinline__ int row_block(int rows) { return rows <= 96 ? 96 : 160; }
+#endif
 
 __device__ __forceinline__ int64_t tiled_elem(int row, int chunk, int tap, int k, int nchunk, int taps, int rb) {
     const int cb = row / rb, r = row - cb * rb;

@@ -568,7 +568,11 @@ struct VtPlan {
     size_t lds;
 };
 
+#ifdef CDET_RB160_AS_96
+static int vt_row_block(int rows) { return (rows <= 96 || rows == 160) ? 96 : 160; }  // (experiment builds only: see conv_halo.hip::row_block)
+#else
 static int vt_row_block(int rows) { return rows <= 96 ? 96 : 160; }
+#endif
 
 // d describes the FORWARD stride-2 convolution (Hs x Ws x Cs -> Hd x Wd x Cd) for mode 0, or the data gradient (CDET_CONV_DGRAD
 // convention of cdet_conv2d: source = dY [Hs x Ws x Cs], destination = dX [Hd x Wd x Cd] = 2 Hs x 2 Ws) for the class launches
