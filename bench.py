@@ -663,13 +663,16 @@ def main():
         torch.cuda.synchronize()
 
     items = None
+    # defer_tail: the optimizer's update of the unshared blocks (necks + heads) runs on a side stream under the next iteration's trunk -- the training
+    # loop's form (cerberusdet_amd/train.py). Every update is inside the timed region: sync() = barrier + device-wide synchronize, tail included.
     for i in range(args.warmup):
-        items = trainer.train_step(data[i % n_distinct], n_max=n_max)
+        items = trainer.train_step(data[i % n_distinct], n_max=n_max, defer_tail=True)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max)
+        items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max, defer_tail=True)
     sync()
+    trainer.join_tail()
     dt = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)

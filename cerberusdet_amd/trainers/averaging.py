@@ -219,6 +219,15 @@ class Averaging:
             for k, v in msd.items():
                 if v.dtype.is_floating_point and k in ema_sd:
                     self.slots_meta.append(dict(p=v, g=None, mom=None, ema=ema_sd[k], group=-1, div=1, key=k))
+        # The optimizer's TAIL: the slots of the blocks no other task shares (necks + heads: ~70 % of the parameters) sit behind the shared trunk's in the
+        # table, so that the update can run as two launches -- the trunk's on the current stream, the rest on a side stream under the NEXT
+        # iteration's trunk kernels (train_step(defer_tail=True)); every pass waits for the tail in front of its first block outside the trunk.
+        self._early_blocks = frozenset(self._shared_blocks)
+        self.slots_meta.sort(key=lambda m: 0 if int(m["key"].split(".")[1]) in self._early_blocks else 1)  # (stable: block order inside each half)
+        self.n_head_slots = sum(1 for m in self.slots_meta if int(m["key"].split(".")[1]) in self._early_blocks)
+        self._tail_stream = None
+        self._tail_event = None
+        self._tail_pending = False
         self.n_slots = len(self.slots_meta)
         self._slots_host = (L.ParamSlot * self.n_slots)()
         self._slots_dev = torch.empty(C.sizeof(self._slots_host), dtype=torch.uint8, device=device)
@@ -242,6 +251,7 @@ class Averaging:
 
     # ---------------------------------------------------------------------------------------------------- step pieces
     def forward_backward(self, task: str, batch: dict, n_max: Optional[int] = None, active_tasks=None):
+        self.join_tail()
         g = self._pass_steps(task, batch, n_max, active_tasks, None)
         try:
             while True:
@@ -332,7 +342,15 @@ class Averaging:
         for t in active:
             img = batches[t]["img"]
             plan = self.model.get_plan(t, img.shape, img.dtype, training=True)
-            plan.refresh_weights()  # all re-packs on the current stream, before the fork
+            # the shared trunk's operands are packed here, on the current stream, before the fork (by the first plan that finds them stale);
+            # every pass packs its own branch itself in front of its first block outside the trunk, on its OWN stream, behind the optimizer's
+            # tail (engine.Plan.iter_forward) -- under the trunk kernels of the iteration
+            plan.early_blocks = self._early_blocks
+            plan.tail_event = self._tail_event if self._tail_pending else None
+            if self._early_blocks:
+                plan.refresh_weights("early")
+            else:
+                plan.refresh_weights()
             plan.attach_grads()
             plans.append(plan)
         # Block-interleaved enqueue: every round lets each task enqueue its next block on its own stream. The GPU-side order is set by
@@ -343,7 +361,7 @@ class Averaging:
         fired: set = set()
         from ..engine import lane_stream
         if self._fold_stream is None:
-            self._fold_stream = lane_stream(self.device, 2 * len(self.task_ids))  # (behind the task streams and the eval side lanes)
+            self._fold_stream = lane_stream(self.device, len(self.task_ids) + 1)  # (the lane behind the task streams; eval plans use it as a side lane, never at the same time)
         self._unit_count = {}
         self._in_streams = True
         try:
@@ -387,10 +405,18 @@ class Averaging:
         self.reducer.skip_blocks = {i for i, b in enumerate(self.model.blocks)
                                     if any(True for _ in b.parameters()) and not any(p.requires_grad for p in b.parameters())}
 
-    def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None, idle_blocks=()):
+    def join_tail(self):
+        """Order the current stream behind the optimizer's deferred tail (train_step(defer_tail=True)). Call before anything reads weights, momentum
+        or EMA of the blocks outside the shared trunk on the current stream: validation, checkpoints, state_dict(), tests."""
+        if self._tail_pending:
+            torch.cuda.current_stream().wait_event(self._tail_event)
+            self._tail_pending = False
+
+    def optimizer_step(self, lrs, momentum, n_serving: Optional[Dict[int, int]] = None, idle_blocks=(), defer_tail: bool = False):
         """idle_blocks: blocks none of whose serving tasks ran this iteration (--skip-batches). The reference's zero_grad() leaves
         their gradients None (torch >= 2.0 default set_to_none), so torch's SGD skips them entirely -- no weight decay, no momentum
         coasting, no momentum-buffer initialisation; here their slots become EMA-only for this step and are not marked stepped."""
+        self.join_tail()  # (a previous deferred tail still owns its slots)
         self.reducer.wait()
         idle = set(idle_blocks)
         live = [m["g"] is not None and m["p"].requires_grad and int(m["key"].split(".")[1]) not in idle for m in self.slots_meta]
@@ -414,13 +440,31 @@ class Averaging:
             self._slot_key = key
         st = torch.cuda.current_stream().cuda_stream
         L.check(self.lib.cdet_grad_sqnorm(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), st), "cdet_grad_sqnorm")
+        n_head = self.n_head_slots if (defer_tail and 0 < self.n_head_slots < self.n_slots) else self.n_slots
+        if n_head < self.n_slots:
+            from ..engine import lane_stream
+            if self._tail_stream is None:
+                self._tail_stream = lane_stream(self.device, len(self.task_ids) + 2)
+                self._tail_event = torch.cuda.Event()
+                self._norm_event = torch.cuda.Event()
+            self._norm_event.record(torch.cuda.current_stream())  # the tail forks HERE: behind the reduced gradients and the clipping norm
         d = 0.0
         if self.ema:
             self.ema.updates += 1
             d = self.ema.decay(self.ema.updates)
         lr_arr = (C.c_float * len(lrs))(*[float(v) for v in lrs])
-        L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs),
+        L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), n_head, self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs),
                                            float(momentum), float(d), st), "cdet_sgd_ema_step")
+        if n_head < self.n_slots:
+            # the tail: the same kernel over the slots of the unshared blocks, on a side stream behind the clipping norm -- it runs under the next
+            # iteration's trunk (HBM-bound update beside MFMA-bound convolutions); same arithmetic per slot, same results
+            ts = self._tail_stream
+            ts.wait_event(self._norm_event)
+            L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr() + n_head * C.sizeof(L.ParamSlot), self.n_slots - n_head,
+                                               self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs), float(momentum), float(d), ts.cuda_stream),
+                    "cdet_sgd_ema_step")
+            self._tail_event.record(ts)
+            self._tail_pending = True
         if fresh:
             for m, a in zip(self.slots_meta, live):
                 if a:
@@ -428,7 +472,7 @@ class Averaging:
         self.model.mark_weights_changed()
         self.steps += 1
 
-    def train_step(self, batches: Dict[str, dict], ni: Optional[int] = None, n_max: Optional[int] = None):
+    def train_step(self, batches: Dict[str, dict], ni: Optional[int] = None, n_max: Optional[int] = None, defer_tail: bool = False):
         """batches: {task: {"img": [N,3,H,W] uint8|float on device, "batch_idx", "cls", "bboxes"}}; tasks missing from the dict
         are skipped this iteration (the reference's --skip-batches). Returns {task: loss items tensor[5]}."""
         ni = self.steps if ni is None else ni
@@ -444,13 +488,19 @@ class Averaging:
         if self.task_streams and len(active) > 1:
             self._run_tasks_on_streams(active, batches, n_max, out)
         else:
+            self.join_tail()
             for t in active:
                 out[t] = self.forward_backward(t, batches[t], n_max=n_max, active_tasks=active)
         n_serving, idle = None, ()
         if len(active) != len(self.task_ids):
             n_serving = {i: max(len([t for t in ts if t in active]), 1) for i, ts in self.serving.items()}
             idle = [i for i, ts in self.serving.items() if ts and not any(t in active for t in ts)]
-        self.optimizer_step(lrs, mom, n_serving, idle)
+        # defer_tail (training loops; the caller joins with join_tail() before it reads weights outside a train_step): the update of the unshared
+        # blocks overlaps the next iteration's trunk. Only with the task streams -- the sequential schedule packs everything up front.
+        defer = bool(defer_tail) and self.task_streams and len(self.task_ids) > 1 and len(active) == len(self.task_ids)
+        self.optimizer_step(lrs, mom, n_serving, idle, defer_tail=defer)
+        if self._tail_pending and not defer:
+            self.join_tail()
         return out
 
     def check_targets(self):
@@ -467,6 +517,10 @@ class Averaging:
 
     # ---------------------------------------------------------------------------------------------------- resume
     def state_dict(self):
+        self.join_tail()
+        return self._state_dict()
+
+    def _state_dict(self):
         """Everything `--resume` needs besides the model weights (reference utils/models_manager.py:262-308 saves optimizer, EMA +
         updates, epoch, best fitness): momentum buffers and their first-step flags per parameter, EMA weights and update count,
         iteration counters."""

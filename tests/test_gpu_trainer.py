@@ -156,18 +156,22 @@ def test_task_streams_bit_identical_to_sequential_schedule(which, monkeypatch):
     """train_step with one HIP stream per task pass must give bit-identical weights, BN running statistics, EMA and loss items to the
     sequential schedule of the reference (trainers/averaging.py:132-194) -- in the decoupled form (per-task gradient buckets on the shared
     blocks folded in task order, the later tasks' running-statistics updates behind each block: the passes wait for each other nowhere else)
-    and in the chained form (CDET_TASK_DECOUPLE=0: one shared gradient buffer, a per-block event chain), four runs, one result."""
+    and in the chained form (CDET_TASK_DECOUPLE=0: one shared gradient buffer, a per-block event chain), four runs, one result. Round 5: a fifth
+    run defers the optimizer's tail (train_step(defer_tail=True): necks + heads updated on a side stream under the next iteration's trunk, every
+    pass re-packing its own branch behind it) and a sixth interleaves a momentum / EMA read (state_dict joins the tail) -- the same bits again."""
     from cerberusdet_amd.trainers import Averaging
 
     arrays, meta = load_golden("trainer")
     _, mmeta = load_golden(which)  # tiny3: three tasks, blocks shared by all of them and by two of them
     tasks, ncs = mmeta["tasks"], mmeta["nc"]
     res = []
-    for streams, decouple in ((False, "0"), (True, "0"), (False, "1"), (True, "1")):
+    for streams, decouple, defer in ((False, "0", False), (True, "0", False), (False, "1", False), (True, "1", False), (True, "1", True), (True, "1", "read")):
         monkeypatch.setenv("CDET_TASK_DECOUPLE", decouple)
         m = _model(meta, mmeta)
         tr = Averaging(torch.device(DEV), m, meta["hyp"], tasks, epochs=100, nb=1000, task_streams=streams)
         assert tr.task_streams == streams and bool(m._alt_pairs) == (decouple == "1")
+        if defer:
+            assert 0 < tr.n_head_slots < tr.n_slots and tr._early_blocks  # the shared trunk's slots lead the table
         if decouple == "1":  # every later task of a shared block owns a bucket; its plans wait for nothing but their statistics updates
             assert len(m._alt_pairs) == sum(len(ts) - 1 for bi, ts in tr.serving.items() if len(ts) > 1 and any(True for _ in m.blocks[bi].parameters()))
         items = []
@@ -177,8 +181,14 @@ def test_task_streams_bit_identical_to_sequential_schedule(which, monkeypatch):
                 img = torch.from_numpy(synth.det_image(500 + 10 * it + ti, 4, 128)).to(DEV)
                 b = synth.make_batch(4, 3, ncs[ti], 600 + 10 * it + ti)
                 batches[t] = dict(img=img, **{k: torch.from_numpy(v).to(DEV) for k, v in b.items()})
-            out = tr.train_step(batches, ni=2000 + it)  # past warm-up: every group has lr > 0
+            out = tr.train_step(batches, ni=2000 + it, defer_tail=bool(defer))  # past warm-up: every group has lr > 0
             items.append({t: v.clone() for t, v in out.items()})
+            if defer:
+                assert tr._tail_pending  # the tail is in flight behind this call
+            if defer == "read":
+                mom = tr.state_dict()["momentum"]  # (joins the tail on the current stream before it copies)
+                assert not tr._tail_pending and len(mom) > 100
+        tr.join_tail()
         torch.cuda.synchronize()
         res.append((items, {k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in tr.ema.ema.state_dict().items()}))
     ia, sa, ea = res[0]
