@@ -663,14 +663,16 @@ def main():
         torch.cuda.synchronize()
 
     items = None
-    # defer_tail: the optimizer's update of the unshared blocks (necks + heads) runs on a side stream under the next iteration's trunk -- the training
-    # loop's form (cerberusdet_amd/train.py). Every update is inside the timed region: sync() = barrier + device-wide synchronize, tail included.
+    # CDET_DEFER_TAIL=1 (A/B timing; measured 0.3 ms SLOWER, profiles/r05_optimizer_tail.txt, hence off): the optimizer's update of the unshared
+    # blocks (necks + heads) on a side stream under the next iteration's trunk. Every update stays inside the timed region either way: sync() =
+    # barrier + device-wide synchronize.
+    defer = os.environ.get("CDET_DEFER_TAIL", "0") == "1"
     for i in range(args.warmup):
-        items = trainer.train_step(data[i % n_distinct], n_max=n_max, defer_tail=True)
+        items = trainer.train_step(data[i % n_distinct], n_max=n_max, defer_tail=defer)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max, defer_tail=True)
+        items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max, defer_tail=defer)
     sync()
     trainer.join_tail()
     dt = time.perf_counter() - t0

@@ -230,8 +230,8 @@ def train(hyp, opt, device, train_dataset=None, val_dataset=None):
                     iters[t] = iter(train_dataset[t])
                     batches[t] = next(iters[t])
                 batches[t] = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batches[t].items()}
-            items.update(trainer.train_step(batches, ni=i + nb * epoch, defer_tail=True))  # (the update of necks + heads overlaps the next trunk)
-        trainer.join_tail()
+            items.update(trainer.train_step(batches, ni=i + nb * epoch, defer_tail=os.environ.get("CDET_DEFER_TAIL", "0") == "1"))
+        trainer.join_tail()  # (no-op unless the optimizer's tail was deferred: measured slower, off by default -- trainers/averaging.py)
         torch.cuda.synchronize()
         trainer.check_targets()
         results = {t: [float(v) for v in items[t].tolist()] for t in tasks if t in items}

@@ -222,7 +222,7 @@ class Averaging:
         # The optimizer's TAIL: the slots of the blocks no other task shares (necks + heads: ~70 % of the parameters) sit behind the shared trunk's in the
         # table, so that the update can run as two launches -- the trunk's on the current stream, the rest on a side stream under the NEXT
         # iteration's trunk kernels (train_step(defer_tail=True)); every pass waits for the tail in front of its first block outside the trunk.
-        self._early_blocks = frozenset(self._shared_blocks)
+        self._early_blocks = frozenset(self._shared_blocks) if os.environ.get("CDET_LATE_PACK", "1") != "0" else frozenset()
         self.slots_meta.sort(key=lambda m: 0 if int(m["key"].split(".")[1]) in self._early_blocks else 1)  # (stable: block order inside each half)
         self.n_head_slots = sum(1 for m in self.slots_meta if int(m["key"].split(".")[1]) in self._early_blocks)
         self._tail_stream = None
