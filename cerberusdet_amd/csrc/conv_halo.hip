@@ -85,11 +85,17 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
     static_assert(!CAT || (NT == 1 && !PATCH && !OMAP), "a virtual-Concat source is a 1x1 convolution's");
     static_assert(NG != 4 || (NT == 9 && !PATCH && !OMAP && !CAT && NSW == 6), "the 512-pixel tile: 3x3, linear halo, six-stage weight ring");
     static_assert(NSW == 2 || NSW == 3 || (NSW == 6 && NT == 9), "weight ring depths");
-    constexpr int XPS = NG == 4 ? 2 : 1;  // pixel DMA pieces a wave issues per K step (taps 0..6 of a chunk fetch the next chunk's halo)
+    constexpr int XPS = NG >= 3 ? 2 : 1;  // pixel DMA pieces a wave issues per K step (taps 0..6 of a chunk fetch the next chunk's halo)
     constexpr int MAXXPK = MAXXP * XPS;   // pieces per wave per chunk: XH <= 448 (896) rows
     constexpr int HPB = 128 * NG;         // pixels per block: a wave owns NG 32-pixel fragments (NG = 1: half tiles for layers whose
                                           // 256-pixel tiles would leave most CUs idle, e.g. the 20 x 20 maps at batch 32)
-    static_assert(NG == 2 || !PATCH, "the 16 x 16 patch form is a 256-pixel tile");
+    static_assert(NG == 2 || (NG == 3 && NF == 3) || !PATCH, "patch forms: 16 x 16 (256 pixels), or 24 rows x 16 columns (384 pixels) for the 96-cout tile");
+    constexpr int PH = HPB / PATCH_W;     // patch rows: 16, or 24 in the NG = 3 form (round 5): the 80-channel layers of the 160 x 160 stage stream
+                                          // 162 KB of weights per workgroup for 65 KB of pixels -- a 384-pixel patch (9 accumulator tiles per wave
+                                          // = 144 registers, still two workgroups per CU) takes a third off the weight LDS-DMA per pixel, a fifth
+                                          // off the fragment reads per MFMA, and puts 18 instead of 12 MFMAs behind every barrier. A map whose
+                                          // height is not a multiple of 24 gets a last patch row that hangs over the bottom edge (160 = 6 x 24 +
+                                          // 16: 5 % idle rows; they read zeros and are never stored)
     constexpr int HC = NF * 32;           // couts per block
     constexpr int WTILE = HC * HROW;      // bytes per (cblk, chunk, tap) weight tile: 10240 / 6144
     constexpr int WQ = WTILE / 4;         // bytes of the tile each wave copies: 2 (1) full 1-KiB pieces + one half piece (lanes 0-31)
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
     if (PATCH) {
         pn = pblk / a.tiles_per_img;
         const int r = pblk - pn * a.tiles_per_img;
-        py0 = (r / a.tiles_x) * PATCH_W;
+        py0 = (r / a.tiles_x) * PH;
         px0 = (r % a.tiles_x) * PATCH_W;
     }
     unsigned char* const xbase = smem + HZERO;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
         if (PATCH) {
             const int hy = hrow / PATCH_HPW, hx = hrow - hy * PATCH_HPW;
             const int y = py0 - 1 + hy, x = px0 - 1 + hx;
-            ok = hy < PATCH_HPW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)W;  // outside the image: zeros = the padding
+            ok = hy < PH + 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)W;  // outside the image: zeros = the padding
             g = (pn * a.H + y) * W + x;
         } else {
             g = p0 - halo0 + hrow;
@@ -253,7 +259,9 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
             const int iy = i / PATCH_W, ix = i % PATCH_W;
             pixh[g] = iy * PATCH_HPW + ix + halo0;
             pout[g] = (pn * a.H + py0 + iy) * W + px0 + ix;
-            m = 0x1ffu;  // every halo row is the right neighbour or the zero padding
+            // every halo row is the right neighbour or the zero padding; a pixel of a patch row that hangs over the bottom edge (NG = 3) takes the
+            // zero row for all taps -- its window would reach the image's last row, and its accumulator must stay 0 for the BatchNorm partial sums
+            m = (py0 + iy < a.H) ? 0x1ffu : 0u;
         } else {
             pixh[g] = i + halo0;
             const int p = p0 + i;
@@ -531,7 +539,8 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int p = pout[g];
-        const bool pok = OMAP ? (p0 + wave * (32 * NG) + g * 32 + l31) < a.M : p < a.M;
+        const bool pok = OMAP ? (p0 + wave * (32 * NG) + g * 32 + l31) < a.M
+                              : (p < a.M && (!PATCH || py0 + (wave * (32 * NG) + g * 32 + l31) / PATCH_W < a.H));  // (a 24-row patch may hang over the bottom edge)
         const int64_t rb = (int64_t)p * a.res_ld + a.res_coff;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
                 if (PATCH) po = (pn * a.H + py0 + i / PATCH_W) * W + px0 + i % PATCH_W;
                 else po = p0 + i;
                 const int co = c0 + 8 * c;
-                bool in = po < a.M;
+                bool in = po < a.M && (!PATCH || py0 + i / PATCH_W < a.H);
                 if (OMAP && in) {
                     const int n_ = po / (a.H * W), r_ = po - n_ * (a.H * W);
                     const int y_ = r_ / W, x_ = r_ - y_ * W;
@@ -793,7 +802,18 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
             pl.hp = HP;
         }
         pl.XH = pl.patch ? pat : (pl.ng == 2 ? (HP + 2 * (d->Ws + 1) + 15) / 16 * 16 : lin);
-        if (pl.XH > 16 * 4 * MAXXP * (pl.ng == 4 ? 2 : 1)) return pl;
+        // CDET_HALO_NG=3 (round-5 experiment, opt-in): the 96-cout tile on tall maps as 24-row x 16-column patches (384 pixels) when at most 6 % of
+        // the patch rows hang over the bottom edge (160 = 6 x 24 + 16: 5 %). Measured on 160 x 160 80 -> 80: 0.1381 against 0.1372 ms -- a third less
+        // weight LDS-DMA, a fifth fewer fragment reads and barriers per MFMA buy NOTHING there (profiles/r05_halo_ng4.txt, section 3)
+        if (pl.patch && pl.nf == 3 && d->out_dtype != CDET_F32 && getenv("CDET_HALO_NG") && atoi(getenv("CDET_HALO_NG")) == 3) {
+            const int rows3 = div_up(d->Hs, 24) * 24;
+            if ((rows3 - d->Hs) * 100 <= 6 * d->Hs) {
+                pl.ng = 3;
+                pl.hp = 384;
+                pl.XH = (26 * PATCH_HPW + 15) / 16 * 16;  // 480
+            }
+        }
+        if (pl.XH > 16 * 4 * MAXXP * (pl.ng >= 3 ? 2 : 1)) return pl;
     }
     if (M >= (1ll << 31) - HP) return pl;
     if (M * d->src_ld * 2 >= 0xC0000000ll) return pl;
@@ -881,6 +901,8 @@ template <int DT, int NF, int EPI>
 static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nblocks, hipStream_t s) {
     if (pl.ng == 4) {
         if constexpr (NF == 5 && EPI != HEPI_F32) launch_halo<DT, 9, 5, EPI, 6, false, 4>(a, pl.lds, nblocks, s);
+    } else if (pl.ng == 3) {
+        if constexpr (NF == 3 && EPI != HEPI_F32) launch_halo<DT, 9, 3, EPI, 3, true, 3>(a, pl.lds, nblocks, s);
     } else if (pl.ng == 1) {
         if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
         else launch_halo<DT, 9, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
@@ -958,10 +980,13 @@ extern "C" int cdet_debug_halo_timeline(void* buf) {
 
 extern "C" int cdet_conv2d_tiled_ok(const cdet_conv_desc* d) { return d && halo_plan(d).ok ? 1 : 0; }
 
-extern "C" int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d) {
-    const HaloPlan pl = halo_plan(d);
+// pixel tiles of a launch (= BatchNorm partial rows): M / tile, or per image ceil(H / patch rows) x (W / 16) patches in the patch forms
+static int halo_pixel_tiles(const cdet_conv_desc* d, const HaloPlan& pl) {
+    if (pl.ok && pl.patch) return d->N * div_up(d->Hs, pl.hp / PATCH_W) * (d->Ws / PATCH_W);
     return div_up((int64_t)d->N * d->Hd * d->Wd, pl.ok ? pl.hp : HP);
 }
+
+extern "C" int cdet_conv2d_tiled_stat_blocks(const cdet_conv_desc* d) { return halo_pixel_tiles(d, halo_plan(d)); }
 
 extern "C" int64_t cdet_tiled_weight_elems(int32_t rows, int32_t red, int32_t kh, int32_t kw) {
     const int rb = row_block(rows);
@@ -1061,12 +1086,12 @@ static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void*
     a.nchunk = div_up(d->Cs, 32);
     a.halfk = (d->kh == 3 && d->Cs % 32 != 0 && d->Cs % 32 <= 16 && tune_env("CDET_HALO_HALFK", 1)) ? 1 : 0;
     a.Cs = d->Cs;
-    a.n_pblk = div_up(a.M, pl.hp);
+    a.n_pblk = halo_pixel_tiles(d, pl);
     a.n_cblk = div_up(d->Cd, rb);
     a.act = d->act;
     a.XH = pl.XH;
     a.tiles_x = d->Ws / PATCH_W;
-    a.tiles_per_img = (d->Hs / PATCH_W) * (d->Ws / PATCH_W);
+    a.tiles_per_img = div_up(d->Hs, pl.hp / PATCH_W) * (d->Ws / PATCH_W);
     a.x_bytes = (unsigned)((int64_t)a.M * d->src_ld * 2);
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * d->kh * d->kw * rb * HROW);
     a.wts = 1; a.wt0 = 0; a.Hd = d->Hd; a.Wd = d->Wd; a.cp = a.cq = 0;

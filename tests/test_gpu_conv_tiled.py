@@ -53,12 +53,14 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("ng", [0, 1, 2, 4])
+@pytest.mark.parametrize("ng", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", CASES)
 def test_tiled_conv_fwd_epilogue_stats(case, ng, monkeypatch):
     """ng: 0 = the library's own choice of tile (half tiles when 256-pixel tiles would under-fill the chip), 1 / 2 = pinned; 4 = the round-5
     experiment: 512-pixel tiles, one workgroup per CU, 16 of 20 accumulator tiles in AccVGPRs, six-stage weight ring (3x3, 160-cout blocks,
-    maps up to 95 wide; other geometries keep the library's choice) -- correct, measured slower, opt-in only (profiles/r05_halo_ng4.txt)."""
+    maps up to 95 wide; other geometries keep the library's choice) -- correct, measured slower, opt-in only (profiles/r05_halo_ng4.txt); 3 = the
+    other round-5 experiment: 24-row x 16-column patches (384 pixels) for the 96-cout tile on maps whose last patch row hangs over the bottom edge
+    by at most 6 % (the 160 x 160 case here) -- correct, no faster, opt-in."""
     ops = _ops()
     from cerberusdet_amd import _lib as L
 
