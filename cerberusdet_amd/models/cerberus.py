@@ -519,7 +519,7 @@ class CerberusDet(nn.Module):
         self._plans[key] = plan  # (re-inserted last: dict order = recency)
         return plan
 
-    def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False, zero_copy=False):
+    def forward(self, input_tensor, task_ids=None, retain_tensors=False, retain_all=False, zero_copy=False, contiguous_maps=False):
         """Same contract as the reference (cerberus.py:804-882): a `str` task -> that head's output, otherwise a dict.
         train mode -> list of 3 raw maps [N, 64+nc, h, w]; eval mode -> (y [N, 4+nc, A], maps).
         Like the reference, every call returns FRESH tensors. Eval mode: the head projections and the decode kernel write straight
@@ -553,7 +553,11 @@ class CerberusDet(nn.Module):
             for t in tasks:
                 nc = self.get_head(t).nc
                 srcs = [f.clone() for f in plan.feats[t]] if (self.training and not zero_copy) else plan.feats[t]  # flat copies
+                # NCHW-shaped VIEWS of the padded NHWC fp32 maps (values and shapes as the reference's Detect.forward returns them,
+                # models/yolo.py:87-100; `.view()` needs contiguous memory: contiguous_maps=True pays one transposing copy per map for it)
                 maps = [f[..., :64 + nc].permute(0, 3, 1, 2) for f in srcs]
+                if contiguous_maps:
+                    maps = [m.contiguous() for m in maps]
                 outs[t] = maps if self.training else (plan.y[t], maps)
         return outs[task_ids] if isinstance(task_ids, str) else outs
 

@@ -161,6 +161,12 @@ def test_default_forward_returns_fresh_tensors_without_a_copy():
                 for f, g in zip(got[t][1], want1[t][1]):
                     assert f.shape == g.shape and torch.equal(f, g)
             assert torch.equal(b[t][0], z2[t][0]) and not torch.equal(b[t][0], a[t][0])
+        # the reference's maps are contiguous NCHW tensors (torch.cat results, models/yolo.py:87-100): `.view()` works on them. Here they are
+        # NCHW-shaped views of padded NHWC buffers unless contiguous_maps=True asks for the copy
+        d = m(x1, contiguous_maps=True)
+        for t in meta["tasks"]:
+            for f, g in zip(d[t][1], want1[t][1]):
+                assert f.is_contiguous() and torch.equal(f, g) and f.view(f.shape[0], -1).shape[1] == g[0].numel()
     m.train()
     with torch.no_grad():
         t1 = m(x1)
