@@ -81,12 +81,20 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // barrier per 40 MFMAs instead of per 20. (Measured on the 256-pixel form, profiling build, 40 x 40 320 -> 320: the K loop takes 98 us, its MFMAs alone
 // 55, everything but the MFMAs alone 48 -- the two do not overlap; tools/conv_tiled_bench.py with CDET_HALO_ABLATE.)
 template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false, bool CAT = false>
-__global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) void conv_halo_kernel(const HaloArgs a) {
+    // TRI (round 5, CDET_HALO_WG3=1): THREE workgroups per CU for the 96-cout patch form (the 80-channel layers of the 160 x 160 stage, where a
+    // workgroup's life is a chain of latencies -- tile fetch, 27 short K steps, statistics, store -- and two resident workgroups leave the MFMA pipe idle
+    // 65 % of the time). 160 KB / 3 in the LDS allocation granule of gfx950 (1280 B) = 42 granules = 53 760 B: two 18 x 18-row pixel buffers without
+    // padding (2 x 20 736 B; the 21st DMA piece of a buffer is four rows = lanes 0-15 only), a two-stage weight ring (2 x 6 144 B), and NO zero row -- a
+    // patch's halo rows are all real neighbours or DMA-filled padding, no tap is ever redirected. <= 168 registers per lane (launch bounds).
+    constexpr bool TRI = PATCH && NSW == 2;
+    static_assert(!TRI || (NF == 3 && NG == 2 && NT == 9 && !OMAP && !CAT), "three workgroups per CU: the 96-cout 16 x 16 patch form only");
+    constexpr int HZ = TRI ? 0 : HZERO;  // bytes in front of the pixel buffers
     static_assert(!CAT || (NT == 1 && !PATCH && !OMAP), "a virtual-Concat source is a 1x1 convolution's");
     static_assert(NG != 4 || (NT == 9 && !PATCH && !OMAP && !CAT && NSW == 6), "the 512-pixel tile: 3x3, linear halo, six-stage weight ring");
     static_assert(NSW == 2 || NSW == 3 || (NSW == 6 && NT == 9), "weight ring depths");
     constexpr int XPS = NG >= 3 ? 2 : 1;  // pixel DMA pieces a wave issues per K step (taps 0..6 of a chunk fetch the next chunk's halo)
-    constexpr int MAXXPK = MAXXP * XPS;   // pieces per wave per chunk: XH <= 448 (896) rows
+    constexpr int MAXXPK = TRI ? 6 : MAXXP * XPS;   // pieces per wave per chunk: XH <= 448 (896) rows; TRI: 21 pieces over four waves
     constexpr int HPB = 128 * NG;         // pixels per block: a wave owns NG 32-pixel fragments (NG = 1: half tiles for layers whose
                                           // 256-pixel tiles would leave most CUs idle, e.g. the 20 x 20 maps at batch 32)
     static_assert(NG == 2 || (NG == 3 && NF == 3) || !PATCH, "patch forms: 16 x 16 (256 pixels), or 24 rows x 16 columns (384 pixels) for the 96-cout tile");
@@ -135,11 +143,11 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
         py0 = (r / a.tiles_x) * PH;
         px0 = (r % a.tiles_x) * PATCH_W;
     }
-    unsigned char* const xbase = smem + HZERO;
+    unsigned char* const xbase = smem + HZ;
     constexpr int NXB = NT == 1 ? 3 : 2;  // pixel buffers
-    unsigned char* const wbase = smem + HZERO + NXB * XHB;
+    unsigned char* const wbase = smem + HZ + NXB * XHB;
 
-    if (t < 16) reinterpret_cast<uint32_t*>(smem)[t] = 0u;  // zero row (visible after the first barrier)
+    if (!TRI && t < 16) reinterpret_cast<uint32_t*>(smem)[t] = 0u;  // zero row (visible after the first barrier)
 #ifdef CDET_PROFILING
     if (g_halo_dbg != nullptr && t == 0) {
         g_halo_dbg[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
     CDET_HALO_STAMP(2);
 
     // ---- X DMA pieces of this wave: piece id 4*i + wave covers halo rows 16*id .. 16*id+15, 4 lanes (64 B) per row --------------
-    const int nxp_total = a.XH >> 4;
+    const int nxp_total = (a.XH + 15) >> 4;  // (TRI: 324 rows = 20 pieces + 4 rows)
     const int nxpw = (nxp_total - wave + 3) >> 2;  // wave-uniform
     unsigned xvoff[MAXXPK];
 #pragma unroll
@@ -242,7 +250,11 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
         // last partial chunk (Cs % 32 != 0, the 80-channel layers): the lanes whose 8-channel slot lies beyond Cs fetch zeros -- what
         // sits there in memory is a neighbouring channel slice (possibly never written), and 0-weight x NaN would still be NaN
         if (partial && chunk * 32 + 8 * xls >= a.Cs) v = HSENT;
-        dma16<CDET_HALO_X_AUX>(rs, v, 0u, dst);
+        if (TRI && 4 * i + wave == 20) {  // the buffer's last four rows: the rest of the piece would land in the next buffer / the weight ring
+            if (lane < 16) dma16<CDET_HALO_X_AUX>(rs, v, 0u, dst);
+        } else {
+            dma16<CDET_HALO_X_AUX>(rs, v, 0u, dst);
+        }
     };
 
     // ---- fragment read offsets -------------------------------------------------------------------------------------------------
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
         for (int g = 0; g < NG; ++g) {
             const int hrow = p_[g] + (NT == 9 ? dy_ * tp + dx_ : 0);
             const int off = hrow * HROW + ((h ^ ((hrow >> 2) & 3)) << 4);
-            const bool ok = (vmask[g] >> tap_) & 1u;
+            const bool ok = TRI || ((vmask[g] >> tap_) & 1u);  // (TRI: a 16 x 16 patch of a map whose sides are multiples of 16 -- every tap is real)
             bo[g] = ok ? off + xoff : 0;  // invalid tap / pixel: the zero row
         }
     };
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
 #endif
     int bo_cur[NG], bo_nxt[NG];
     u32x4 a0[NF], b0[NG], a1[NF], b1[NG];
-    b_offsets(HZERO, 0, bo_cur);
+    b_offsets(HZ, 0, bo_cur);
 #pragma unroll
     for (int i = 0; i < NR; ++i) frag(wbase, bo_cur, 0, i, a0, b0);
 
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
             // end waits for LDS latency that the second half has already covered (one read per slot left ~140 clocks per step exposed)
             if (!halfk && 2 * i < NR) frag(ws, bo_cur, 1, 2 * i, a1, b1);
             if (!halfk && 2 * i + 1 < NR) frag(ws, bo_cur, 1, 2 * i + 1, a1, b1);
-            if (i == NM - 1) b_offsets(HZERO + xbn * XHB, tapn, bo_nxt);
+            if (i == NM - 1) b_offsets(HZ + xbn * XHB, tapn, bo_nxt);
             if (!(ABL & 1)) {
                 if (NT == 9) {
                     if (i == NM - 2 && u < MAXXP) {
@@ -419,7 +431,10 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : 2) void conv_halo_kernel(const H
             // vmcnt retires in order: what must have landed is the weight tile of step st+1 (issued two phase-Bs ago); everything
             // issued after it may stay in flight -- the newest weight tile and the pixel pieces of this and the previous phase A
             // (pixel pieces are only issued at taps 0..6, so at tap 8, when phase B first reads the next chunk, none is left)
-            const int np = (u >= 1 && u - 1 < MAXXP) ? min(max(nxpw - XPS * (u - 1), 0), XPS) : 0;  // pieces of the previous step's phase A
+            // (a TWO-stage ring issues tile st+1 one phase B ago, i.e. BEHIND the previous phase A's pixel pieces: only this phase's may stay in flight.
+            //  Until round 5 the two-stage form waited with the three-stage count -- up to one weight piece of tile st+1 could still be in flight at
+            //  the barrier; never observed at two workgroups per CU, but it showed as wrong results as soon as three shared one)
+            const int np = (NSW != 2 && u >= 1 && u - 1 < MAXXP) ? min(max(nxpw - XPS * (u - 1), 0), XPS) : 0;  // pieces of the previous step's phase A
             switch (na + np) {  // wave-uniform
                 case 0: wait_vm_lgkm0<(NSW - 2) * NWP>(); break;
                 case 1: wait_vm_lgkm0<(NSW - 2) * NWP + 1>(); break;
@@ -764,6 +779,7 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const cdet_pack
 struct HaloPlan {
     bool ok, patch;
     int nf, ng, hp, XH, nsw, nxb;
+    bool tri;
     size_t lds;
 };
 
@@ -814,6 +830,16 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
             }
         }
         if (pl.XH > 16 * 4 * MAXXP * (pl.ng >= 3 ? 2 : 1)) return pl;
+        // three workgroups per CU for the 96-cout 16 x 16 patch form (see TRI in the kernel) when the grid holds at least three full rounds of them
+        // (160 x 160 80 -> 80 at batch 32: 3 200 workgroups, 0.142 -> 0.131 ms; 80 x 80 80 -> 80 with 800 loses 6 % and keeps two).
+        // CDET_HALO_WG3=1 forces the form (tests), 0 disables it
+        const char* w3 = getenv("CDET_HALO_WG3");
+        const int w3v = w3 ? atoi(w3) : -1;
+        const int64_t tiles = (int64_t)d->N * (d->Hs / PATCH_W) * (d->Ws / PATCH_W) * div_up(d->Cd, rb);
+        if (pl.patch && pl.ng == 2 && pl.nf == 3 && d->out_dtype != CDET_F32 && (w3v == 1 || (w3v < 0 && tiles >= 3 * 768))) {
+            pl.tri = true;
+            pl.XH = PATCH_HPW * PATCH_HPW;  // 324
+        }
     }
     if (M >= (1ll << 31) - HP) return pl;
     if (M * d->src_ld * 2 >= 0xC0000000ll) return pl;
@@ -825,10 +851,12 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     // (the 512-pixel tile has the CU's LDS to itself: a six-stage ring keeps five weight tiles in flight -- the LDS-DMA stream of a workgroup is
     //  latency-bound, (stages - 1) x 10 KB per ~2 us)
     pl.nsw = pl.ng == 4 ? 6 : (base + 3 * (size_t)rb * HROW <= 80 * 1024 ? 3 : 2);
-    if ((pl.patch || d->kh == 1 || pl.ng == 1) && pl.nsw != 3) return pl;
-    pl.lds = base + (size_t)pl.nsw * rb * HROW;
+    if (pl.tri) pl.nsw = 2;
+    if ((pl.patch || d->kh == 1 || pl.ng == 1) && pl.nsw != 3 && !pl.tri) return pl;
+    pl.lds = base + (size_t)pl.nsw * rb * HROW - (pl.tri ? HZERO : 0);
     const size_t epi = (size_t)HZERO + HEPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16);  // the epilogue's store staging
     if (pl.lds < epi) pl.lds = epi;
+    if (pl.tri && pl.lds != 42 * 1280) return HaloPlan{};
     pl.ok = true;
     return pl;
 }
@@ -907,7 +935,9 @@ static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nbl
         if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
         else launch_halo<DT, 9, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
     } else if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 2>(a, pl.lds, nblocks, s);
-    else if (pl.patch) launch_halo<DT, 9, NF, EPI, 3, true, 2>(a, pl.lds, nblocks, s);
+    else if (pl.tri) {
+        if constexpr (NF == 3 && EPI != HEPI_F32) launch_halo<DT, 9, 3, EPI, 2, true, 2>(a, pl.lds, nblocks, s);
+    } else if (pl.patch) launch_halo<DT, 9, NF, EPI, 3, true, 2>(a, pl.lds, nblocks, s);
     else if (pl.nsw == 3) launch_halo<DT, 9, NF, EPI, 3, false, 2>(a, pl.lds, nblocks, s);
     else launch_halo<DT, 9, NF, EPI, 2, false, 2>(a, pl.lds, nblocks, s);
 }
