@@ -83,7 +83,10 @@ class PendingPrediction:
 
 class CerberusDetInference:
     def __init__(self, weights, device: str = "", conf_thres: float = 0.25, iou_thres: float = 0.45, iou_thres_between_tasks: float = 0.8,
-                 half: bool = False, img_size: int = 640):
+                 half: bool = False, img_size: int = 640, full_precision: bool = False):
+        """Same arguments as the reference (cerberusdet_inference.py:24-28) plus `full_precision`: the reference's half=False runs the model in
+        fp32; here half=False means bf16 storage (the engine's default) unless full_precision=True selects the fp32-accurate path
+        (models/cerberus.py::full_precision, cerberusdet_amd/precise.py: boxes within 1e-3 of the fp32 reference, ~8x the time)."""
         self.conf_thres, self.iou_thres, self.iou_thres_between_tasks = conf_thres, iou_thres, iou_thres_between_tasks
         if device and torch.device(device).type != "cuda":
             # the reference would run on the CPU here (cerberusdet_inference.py:30-36, select_device); this engine has no CPU path
@@ -94,7 +97,11 @@ class CerberusDetInference:
         self.device = torch.device(device if device else "cuda:0")
         self.half = half
         self.model: CerberusDet = attempt_load(weights, map_location=self.device)
-        if self.half:
+        if full_precision:
+            if half:
+                raise ValueError("CerberusDetInference: half=True and full_precision=True contradict each other")
+            self.model.full_precision()
+        elif self.half:
             self.model.half()
         self.model.eval()
         self.stride = int(self.model.stride.max())

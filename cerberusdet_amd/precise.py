@@ -1,0 +1,345 @@
+"""The fp32-ACCURATE eval forward of a CerberusDet model on the MI355X (round 5) -- `model.full_precision()`.
+
+The reference evaluates a model with fp32 parameters in fp32 (cerberusdet/models/cerberus.py:804-882 on a `.float()` model; `CerberusDetInference`
+with half=False, cerberusdet_inference.py:26-40), and BASELINE.json states the tolerance against it: boxes within 1e-3 relative. The compiled
+16-bit plans (engine.Plan) store activations in bf16 / fp16 and match that reference statistically. This module is the same
+forward at the reference's OWN precision, still on the product's kernels:
+
+  * an fp32 map is carried as its fp32 value plus three bf16 terms, t = hi + mid + lo (exact to 2^-24 |t|); so is every weight;
+  * a convolution is the six term pairs whose product lies above 2^-24, accumulated in fp32 by `cdet_conv2d_tiled` / `cdet_conv2d_s2_tiled`
+    (conv_halo_kernel / conv_vt_kernel, fp32 destination, accumulate form) -- the 3-channel stem, which those refuse, on `cdet_conv2d`;
+  * folded BatchNorm + SiLU + the Bottleneck shortcut (`cdet_epilogue_f32`), the SPPF pools (`cdet_maxpool_f32`), Concat / nn.Upsample
+    (`cdet_split3` into a channel slice, optionally through the nearest 2x upsample) run in fp32 and emit value and terms at once; the Detect
+    decode is the plans' own fp32 kernel (`cdet_detect_decode`).
+
+No arithmetic on activations happens in torch; torch allocates the buffers. Weights are split by the same `cdet_split3` kernel and packed by
+`cdet_pack_weight_tiled` (exact: every term is a bf16 value); the folded BatchNorm scale / bias are computed in float64 on the device.
+
+Eval only: a `full_precision()` model refuses train mode (gradients at this precision are covered by the test harness `tests/hiprec.py`, which
+drives the same kernels through torch autograd). Cost: 6 MFMA launches + 1 elementwise pass per convolution and fp32 maps -- roughly 8x the
+time of the bf16 plan; it exists for parity, not for throughput.
+
+Walk order and graph semantics follow `CerberusDet.execution_plan` / `_inputs` exactly as engine.Plan._build does (reference
+cerberus.py:804-882, models/yolo.py:87-100, models/common.py:51-68, 107-117, 174-191, 230-245, 288-295).
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .models.common import C2f, Concat, Conv, SPPF, Upsample
+from .ops import View, conv_desc, detect_decode, dt, pack_weight, pack_weight_tiled, ptr, stream
+
+# operand-term pairs whose product is above 2^-24 relative: hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi
+_PAIRS = [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)]
+
+
+def _up8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+class Map:
+    """An fp32 NHWC map [N, H, W, ld] with its three bf16 term buffers of the same geometry; a channel slice [coff, coff + C) of it."""
+
+    __slots__ = ("f", "s", "coff", "C", "ctot")
+
+    def __init__(self, f: Optional[torch.Tensor], s: Optional[List[torch.Tensor]], coff: int, Cn: int, ctot: int):
+        self.f, self.s, self.coff, self.C, self.ctot = f, s, coff, Cn, ctot  # ctot: real channels of the buffer (ld = ctot rounded up to 8)
+
+    @staticmethod
+    def new(N, H, W, Cn, dev, terms=True, value=True) -> "Map":
+        ld = _up8(Cn)
+        f = torch.zeros((N, H, W, ld), dtype=torch.float32, device=dev) if value else None  # (zeros: the pad channels are read by the convolutions)
+        s = [torch.zeros((N, H, W, ld), dtype=torch.bfloat16, device=dev) for _ in range(3)] if terms else None
+        return Map(f, s, 0, Cn, Cn)
+
+    def _any(self):
+        return self.f if self.f is not None else self.s[0]
+
+    N = property(lambda m: m._any().shape[0])
+    H = property(lambda m: m._any().shape[1])
+    W = property(lambda m: m._any().shape[2])
+    ld = property(lambda m: m._any().shape[3])
+    M = property(lambda m: m.N * m.H * m.W)
+
+    def slice(self, c0: int, c: int) -> "Map":
+        return Map(self.f, self.s, self.coff + c0, c, self.ctot)
+
+    def term(self, i: int) -> View:
+        """Term i as a convolution source: a slice that ends the buffer's real channels is widened over the (zero) pad channels behind it, so
+        that its channel count is a multiple of 8 like every interior slice's."""
+        return View(self.s[i], self.coff, self.C if self.coff + self.C < self.ctot else self.ld - self.coff)
+
+    def tptr(self, i):
+        return self.s[i].data_ptr() if self.s is not None else None
+
+    def fptr(self):
+        return self.f.data_ptr() if self.f is not None else None
+
+
+class PrecisePlan:
+    """Launch list of one (tasks, shape) configuration: compiled once, replayed per forward; packed weight terms refreshed when parameters change."""
+
+    def __init__(self, model, tasks: Sequence[str], N: int, H: int, W: int, img_dtype: torch.dtype, device):
+        self.lib = L.load()
+        self.model, self.tasks, self.N, self.H, self.W, self.img_dtype, self.device = model, list(tasks), N, H, W, img_dtype, device
+        self.steps: List = []           # closures, in launch order
+        self.packs: List = []           # closures that (re)build packed weight terms / folded scale and bias
+        self.counts = {"tiled": 0, "s2_tiled": 0, "generic": 0, "epilogue": 0, "split": 0, "pool": 0}  # launches per forward, by entry point
+        self._scratch: Optional[torch.Tensor] = None
+        self._scratch_elems = 0
+        self._late: List = []
+        self.feats: Dict[str, List[torch.Tensor]] = {}
+        self.y: Dict[str, torch.Tensor] = {}
+        self._img: List[Optional[torch.Tensor]] = [None]
+        self._packed_at = None
+        self._build()
+        self._scratch = torch.empty(self._scratch_elems, dtype=torch.float32, device=device)
+        for bind in self._late:
+            bind()
+
+    # ------------------------------------------------------------------------------------------------ launches
+    def _split(self, src_ptr_fn, src_dtype, src_ld, src_coff, nchw, up, dst: Map, want_value=True):
+        lib, args = self.lib, (src_dtype, src_ld, src_coff, int(nchw), int(up))
+        N, H, W, Cn = dst.N, dst.H, dst.W, dst.C
+
+        def run():
+            L.check(lib.cdet_split3(src_ptr_fn(), *args, dst.fptr() if want_value else None, dst.tptr(0), dst.tptr(1), dst.tptr(2), dst.ld, dst.coff,
+                                    N, H, W, Cn, stream()), "cdet_split3")
+        self.steps.append(run)
+        self.counts["split"] += 1
+
+    def _epilogue(self, zc: int, scale, bias, act, res: Optional[Map], y: Map):
+        """y = act(z * scale + bias) + res over the first y.C channels of the scratch accumulator (row length zc)."""
+        lib = self.lib
+        slot = {}
+        self._late.append(lambda: slot.__setitem__("z", self._scratch.data_ptr()))
+
+        def run():
+            L.check(lib.cdet_epilogue_f32(slot["z"], zc, 0, scale() if scale else None, bias() if bias else None, act,
+                                          res.fptr() if res else None, res.ld if res else 0, res.coff if res else 0, y.fptr(), y.tptr(0), y.tptr(1), y.tptr(2),
+                                          y.ld, y.coff, y.M, y.C, stream()), "cdet_epilogue_f32")
+        self.steps.append(run)
+        self.counts["epilogue"] += 1
+
+    def _conv_raw(self, x: Map, weight: torch.nn.Parameter, k: int, s: int, Ho: int, Wo: int) -> int:
+        """scratch[:, :Op] = conv(x, weight) in fp32 (six bf16 term-pair launches). Returns Op (row length of the accumulator)."""
+        lib, dev = self.lib, self.device
+        O, Ci = weight.shape[0], weight.shape[1]
+        assert Ci == x.C, (Ci, x.C)
+        Op, Cp = _up8(O), _up8(Ci)
+        self._scratch_elems = max(self._scratch_elems, x.N * Ho * Wo * Op)
+        xv = x.term(0)
+        assert xv.C % 8 == 0 and x.coff % 8 == 0, f"full_precision: channel slice [{x.coff}, {x.coff + x.C}) is not a multiple of 8 wide"
+        zv = _GeomView(x.N, Ho, Wo, Op, torch.float32)
+        d0 = conv_desc(xv, zv, k, s)
+        d0.accumulate = 1
+        if s == 1 and lib.cdet_conv2d_tiled_ok(C.byref(d0)):
+            path, fn = "tiled", lib.cdet_conv2d_tiled
+        elif s == 2 and k == 3 and lib.cdet_conv2d_s2_tiled_ok(C.byref(d0)):
+            path, fn = "s2_tiled", lib.cdet_conv2d_s2_tiled
+        else:
+            path, fn = "generic", lib.cdet_conv2d
+        # weight terms: padded fp32 OIHW -> cdet_split3 (as a [1, 1, numel] map) -> three packed operands
+        wpad = torch.zeros((Op, xv.C, k, k), dtype=torch.float32, device=dev)
+        terms = [torch.zeros(wpad.numel(), dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        packed: List[Optional[torch.Tensor]] = [None, None, None]
+
+        def pack():
+            wpad[:O, :Ci].copy_(weight.detach().float())
+            n = wpad.numel()
+            L.check(lib.cdet_split3(wpad.data_ptr(), L.F32, n, 0, 0, 0, None, terms[0].data_ptr(), terms[1].data_ptr(), terms[2].data_ptr(), n, 0,
+                                    1, 1, 1, n, stream()), "cdet_split3")
+            for i in range(3):
+                w32 = terms[i].float().view_as(wpad)  # (exact widening of bf16 values; the packers take fp32 OIHW)
+                packed[i] = pack_weight(w32, torch.bfloat16) if path == "generic" else pack_weight_tiled(w32, torch.bfloat16)[0]
+        self.packs.append(pack)
+        descs = []
+        for n_ in range(len(_PAIRS)):
+            d = conv_desc(xv, zv, k, s)
+            d.accumulate = 1 if n_ > 0 else 0
+            descs.append(d)
+        slot = {}
+        self._late.append(lambda: slot.__setitem__("z", self._scratch.data_ptr()))
+
+        def run():
+            st = stream()
+            for n_, (i, j) in enumerate(_PAIRS):
+                L.check(fn(C.byref(descs[n_]), x.s[i].data_ptr(), packed[j].data_ptr(), None, None, None, slot["z"], None, st), "precise convolution")
+        self.steps.append(run)
+        self.counts[path] += len(_PAIRS)
+        return Op
+
+    def _conv_unit(self, m: Conv, x: Map, y: Map, res: Optional[Map] = None):
+        """SiLU(BN(conv(x))) (+ res) -> y (models/common.py:51-68; BatchNorm folded as in fuseforward, or the fused module's own bias)."""
+        Ho, Wo = (x.H + 2 * (m.k // 2) - m.k) // m.s + 1, (x.W + 2 * (m.k // 2) - m.k) // m.s + 1
+        assert (Ho, Wo, m.c2) == (y.H, y.W, y.C), ((Ho, Wo, m.c2), (y.H, y.W, y.C))
+        Op = self._conv_raw(x, m.conv.weight, m.k, m.s, Ho, Wo)
+        scale = torch.empty(m.c2, dtype=torch.float32, device=self.device)
+        bias = torch.empty(m.c2, dtype=torch.float32, device=self.device)
+
+        def pack():
+            if getattr(m, "fused", False):
+                scale.fill_(1.0)
+                bias.copy_(m.conv.bias.detach().float())
+            else:
+                bn = m.bn
+                sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
+                scale.copy_(sc.float())
+                bias.copy_((bn.bias.detach().double() - bn.running_mean.double() * sc).float())
+        self.packs.append(pack)
+        self._epilogue(Op, lambda: scale.data_ptr(), lambda: bias.data_ptr(), L.ACT_SILU, res, y)
+
+    # ------------------------------------------------------------------------------------------------ layers
+    def _new(self, H, W, Cn, terms=True, value=True) -> Map:
+        return Map.new(self.N, H, W, Cn, self.device, terms, value)
+
+    def _copy_into(self, src: Map, dst: Map, up=False):
+        """dst slice <- src (value and terms), optionally through the nearest 2x upsample."""
+        assert dst.C == src.C
+        self._split(lambda: src.f.data_ptr(), L.F32, src.ld, src.coff, False, up, dst, want_value=dst.f is not None)
+
+    def _layer(self, m, xs: List[Map]) -> Map:
+        if isinstance(m, Conv):
+            x = xs[0]
+            y = self._new((x.H + 2 * (m.k // 2) - m.k) // m.s + 1, (x.W + 2 * (m.k // 2) - m.k) // m.s + 1, m.c2)
+            self._conv_unit(m, x, y)
+            return y
+        if isinstance(m, C2f):
+            x, c = xs[0], m.c
+            cat = self._new(x.H, x.W, (2 + len(m.m)) * c)
+            self._conv_unit(m.cv1, x, cat.slice(0, 2 * c))
+            cur = cat.slice(c, c)
+            for i, b in enumerate(m.m):
+                t = self._new(x.H, x.W, b.cv1.c2)
+                self._conv_unit(b.cv1, cur, t)
+                dst = cat.slice((2 + i) * c, c)
+                self._conv_unit(b.cv2, t, dst, res=cur if b.add else None)
+                cur = dst
+            y = self._new(x.H, x.W, m.cv2.c2)
+            self._conv_unit(m.cv2, cat, y)
+            return y
+        if isinstance(m, SPPF):
+            x, c_ = xs[0], m.cv1.c2
+            cat = self._new(x.H, x.W, 4 * c_)
+            self._conv_unit(m.cv1, x, cat.slice(0, c_))
+            lib = self.lib
+            for i in range(3):
+                a, b = cat.slice(i * c_, c_), cat.slice((i + 1) * c_, c_)
+
+                def run(a=a, b=b):
+                    L.check(lib.cdet_maxpool_f32(a.fptr(), a.ld, a.coff, b.fptr(), b.tptr(0), b.tptr(1), b.tptr(2), b.ld, b.coff, b.N, b.H, b.W, b.C, m.k,
+                                                 stream()), "cdet_maxpool_f32")
+                self.steps.append(run)
+                self.counts["pool"] += 1
+            y = self._new(x.H, x.W, m.cv2.c2)
+            self._conv_unit(m.cv2, cat, y)
+            return y
+        if isinstance(m, Upsample):
+            return _Up(xs[0])
+        if isinstance(m, Concat):
+            srcs = [(v.src, True) if isinstance(v, _Up) else (v, False) for v in xs]
+            H, W = (srcs[0][0].H * 2, srcs[0][0].W * 2) if srcs[0][1] else (srcs[0][0].H, srcs[0][0].W)
+            cat = self._new(H, W, sum(v.C for v, _ in srcs))
+            off = 0
+            for v, up in srcs:
+                self._copy_into(v, cat.slice(off, v.C), up)
+                off += v.C
+            return cat
+        raise NotImplementedError(f"full_precision: layer {type(m).__name__}")
+
+    def _real(self, v) -> Map:
+        if isinstance(v, _Up):  # an Upsample that is not consumed by a Concat
+            y = self._new(v.src.H * 2, v.src.W * 2, v.src.C)
+            self._copy_into(v.src, y, up=True)
+            return y
+        return v
+
+    def _detect(self, head, task: str, xs: List[Map]):
+        nc = head.nc
+        ncp = _up8(nc)
+        feats = []
+        for lvl, xl in enumerate(xs):
+            xl = self._real(xl)
+            fb = Map(torch.zeros((self.N, xl.H, xl.W, 64 + ncp), dtype=torch.float32, device=self.device), None, 0, 64 + nc, 64 + nc)
+            for br, off, cn in ((head.cv2[lvl], 0, 64), (head.cv3[lvl], 64, nc)):
+                t1 = self._new(xl.H, xl.W, br[0].c2)
+                self._conv_unit(br[0], xl, t1)
+                t2 = self._new(xl.H, xl.W, br[1].c2)
+                self._conv_unit(br[1], t1, t2)
+                proj: nn.Conv2d = br[2]
+                Op = self._conv_raw(t2, proj.weight, 1, 1, xl.H, xl.W)
+                pb = torch.empty(cn, dtype=torch.float32, device=self.device)
+                self.packs.append(lambda pb=pb, proj=proj: pb.copy_(proj.bias.detach().float()))
+                self._epilogue(Op, None, lambda pb=pb: pb.data_ptr(), L.ACT_NONE, None, fb.slice(off, cn))
+            feats.append(fb.f)
+        self.feats[task] = feats
+        strides = [float(s) for s in head.stride]
+
+        def run():
+            self.y[task] = detect_decode(feats, nc, strides)
+        self.steps.append(run)
+
+    # ------------------------------------------------------------------------------------------------ graph walk
+    def _build(self):
+        model = self.model
+        order, _ = model.execution_plan(self.tasks)
+        img = self._new(self.H, self.W, 3)  # three image channels in an 8-channel row (pad channels stay zero)
+        self._split(lambda: self._img[0].data_ptr(), dt(self.img_dtype), 0, 0, True, False, img)
+        outs: Dict[int, object] = {}
+        for idx in order:
+            blk = model.blocks[idx]
+            if idx == 0:
+                ys, cur = [], img
+                for li, lay in enumerate(blk.model):
+                    f = lay.f
+                    xin = [cur] if (li == 0 or f == -1) else ([ys[f]] if isinstance(f, int) else [cur if j == -1 else ys[j] for j in f])
+                    if not isinstance(lay, Concat):
+                        xin = [self._real(v) for v in xin]
+                    cur = self._layer(lay, xin)
+                    ys.append(cur)
+                outs[0] = ys
+                continue
+            xs = [outs[0][j] if kind == "bb" else outs[j] for kind, j in model._inputs[idx]]
+            if idx in model.heads.values():
+                self._detect(blk, model.controllers[idx].task_id, xs)
+            else:
+                outs[idx] = self._layer(blk, xs if isinstance(blk, Concat) else [self._real(v) for v in xs])
+
+    # ------------------------------------------------------------------------------------------------ run
+    def _versions(self):
+        return (self.model._weights_version, sum(int(p._version) for p in self.model.parameters()),
+                sum(int(b._version) for b in self.model.buffers()))
+
+    def release(self):
+        """(plan-cache eviction hook, as engine.Plan.release: nothing is registered on the modules here)"""
+        self.steps, self.packs = [], []
+
+    def run(self, img: torch.Tensor):
+        assert tuple(img.shape) == (self.N, 3, self.H, self.W) and img.dtype == self.img_dtype and img.is_contiguous()
+        ver = self._versions()
+        if ver != self._packed_at:
+            with torch.no_grad():
+                for p in self.packs:
+                    p()
+            self._packed_at = ver
+        self._img[0] = img
+        for step in self.steps:
+            step()
+        self._img[0] = None
+
+
+class _Up:
+    """nn.Upsample(None, 2, 'nearest') of a map, not materialised until something other than a Concat needs it."""
+
+    def __init__(self, src: Map):
+        self.src = src
+
+
+class _GeomView:
+    """Geometry of the fp32 accumulator for conv_desc (the pointer is bound at launch)."""
+
+    def __init__(self, N, H, W, Cn, dtype):
+        self.N, self.H, self.W, self.C, self.ld, self.coff, self.dtype = N, H, W, Cn, Cn, 0, dtype

@@ -374,6 +374,24 @@ int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, int32_t H, in
 /* backward through the three chained pools: dbuf[:, coff:coff+C] += routed gradients of slices 1..3 */
 int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C,
                        int32_t dtype, void* stream);
+/* ---- fp32-accurate eval path (csrc/precise.hip, cerberusdet_amd/precise.py; round 5) --------------------------------------------------
+ * The reference evaluates an fp32 model in fp32 (cerberusdet/models/cerberus.py:804-882 on a `.float()` model). Here an fp32 map is carried as
+ * three bf16 terms t = hi + mid + lo (exact to 2^-24 |t|) beside its fp32 value; a convolution is the six term pairs above 2^-24 accumulated in
+ * fp32 by cdet_conv2d_tiled / cdet_conv2d_s2_tiled (fp32 destination, accumulate), and the three kernels below do everything between two
+ * convolutions in fp32. All maps NHWC [N, H, W, ld] with a channel slice [coff, coff + C); a map's three term buffers share its geometry.
+ *
+ * cdet_split3: dst pixel (n, y, x) <- src pixel (n, y >> upsample, x >> upsample): copy / Concat slice / nn.Upsample(None, 2, 'nearest')
+ * (models/common.py:288-295 and the neck rows of the model YAML) / the NCHW input image (src_nchw = 1: src is [N, C, H, W]). src_dtype F32 / BF16 / F16;
+ * dst_f32 may be null (only the terms are wanted). */
+int cdet_split3(const void* src, int32_t src_dtype, int32_t src_ld, int32_t src_coff, int32_t src_nchw, int32_t upsample, float* dst_f32, void* dst_hi,
+                void* dst_mid, void* dst_lo, int32_t dst_ld, int32_t dst_coff, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* y = act(z * scale[c] + bias[c]) + res, fp32 throughout (scale / bias / res may be null): folded BatchNorm + SiLU + Bottleneck shortcut of
+ * models/common.py:51-68, 107-117, or the bias of the head's projections (models/yolo.py:82-84). Writes y and / or its three terms. */
+int cdet_epilogue_f32(const float* z, int32_t z_ld, int32_t z_coff, const float* scale, const float* bias, int32_t act, const float* res, int32_t res_ld,
+                      int32_t res_coff, float* y, void* y_hi, void* y_mid, void* y_lo, int32_t y_ld, int32_t y_coff, int64_t M, int32_t C, void* stream);
+/* nn.MaxPool2d(k, 1, k / 2) on an fp32 map (SPPF, models/common.py:174-191). */
+int cdet_maxpool_f32(const float* x, int32_t x_ld, int32_t x_coff, float* y, void* y_hi, void* y_mid, void* y_lo, int32_t y_ld, int32_t y_coff, int32_t N,
+                     int32_t H, int32_t W, int32_t C, int32_t k, void* stream);
 /* out[c] (=|+=) sum_r src[r, coff + c], c < C_out <= C: bias gradient of the head's biased 1x1 projections (yolo.py:82-84).
  * `part`: fp32 scratch of cdet_bn_bwd_blocks(M) * C elements. */
 int cdet_colsum(const void* src, int32_t ld, int32_t coff, int64_t M, int32_t C, int32_t C_out, int32_t dtype, float* out,
