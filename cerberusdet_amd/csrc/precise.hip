@@ -91,6 +91,55 @@ __global__ void pool_f32_kernel(const float* __restrict__ x, int x_ld, int x_cof
     }
 }
 
+// Train-form BatchNorm of an fp32 map (nn.BatchNorm2d in train mode, reference models/common.py:57-62): batch statistics in double, two launches with a
+// fixed summation order -- partial sums of BNS_NB row groups, then one thread per channel adds them ascending and writes the folded scale / bias the
+// epilogue applies (scale = gamma / sqrt(var + eps), bias = beta - mean * scale) and the running statistics (momentum form, unbiased variance).
+constexpr int BNS_NB = 128;
+
+__global__ void bn_stats_f32_partial_kernel(const float* __restrict__ z, int z_ld, int z_coff, int64_t M, int C, double* __restrict__ ws) {
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int64_t p = (int64_t)blockIdx.y * 4 + r; p < M; p += (int64_t)BNS_NB * 4) {
+            const double v = (double)z[p * z_ld + z_coff + c];
+            s += v;
+            q += v * v;
+        }
+    }
+    red[0][r][threadIdx.x & 63] = s;
+    red[1][r][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = ((red[0][0][l] + red[0][1][l]) + red[0][2][l]) + red[0][3][l];
+        ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = ((red[1][0][l] + red[1][1][l]) + red[1][2][l]) + red[1][3][l];
+    }
+}
+
+__global__ void bn_stats_f32_final_kernel(const double* __restrict__ ws, int64_t M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          double eps, double momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                          float* __restrict__ scale, float* __restrict__ bias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < BNS_NB; ++b) {
+        s += ws[((int64_t)b * 2 + 0) * C + c];
+        q += ws[((int64_t)b * 2 + 1) * C + c];
+    }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)gamma[c] / sqrt(var + eps);
+    scale[c] = (float)sc;
+    bias[c] = (float)((double)beta[c] - mean * sc);
+    if (running_mean != nullptr) {
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
 static inline int grid_for(int64_t total) {
     const int64_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -136,6 +185,22 @@ extern "C" int cdet_maxpool_f32(const float* x, int x_ld, int x_coff, float* y, 
     CDET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k >= 1 && (k & 1) && x_coff + C <= x_ld && y_coff + C <= y_ld, "cdet_maxpool_f32: bad geometry");
     hipLaunchKernelGGL(pool_f32_kernel, dim3(grid_for((int64_t)N * H * W * C)), dim3(256), 0, stream, x, x_ld, x_coff, y, (uint16_t*)y_hi, (uint16_t*)y_mid,
                        (uint16_t*)y_lo, y_ld, y_coff, N, H, W, C, k);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t cdet_bn_train_f32_ws_doubles(int C) { return (int64_t)BNS_NB * 2 * C; }
+
+extern "C" int cdet_bn_train_f32(const float* z, int z_ld, int z_coff, int64_t M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, double* ws, float* scale, float* bias, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CDET_CHECK_ARG(z != nullptr && gamma != nullptr && beta != nullptr && ws != nullptr && scale != nullptr && bias != nullptr, "cdet_bn_train_f32: null pointer");
+    CDET_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "cdet_bn_train_f32: running mean and variance come together");
+    CDET_CHECK_ARG(M > 0 && C > 0 && z_coff >= 0 && z_coff + C <= z_ld, "cdet_bn_train_f32: bad geometry");
+    hipLaunchKernelGGL(bn_stats_f32_partial_kernel, dim3((C + 63) / 64, BNS_NB), dim3(256), 0, stream, z, z_ld, z_coff, M, C, ws);
+    CDET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_f32_final_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, ws, M, C, gamma, beta, (double)eps, (double)momentum, running_mean,
+                       running_var, scale, bias);
     CDET_LAUNCH_CHECK();
     return 0;
 }

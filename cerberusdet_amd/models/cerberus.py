@@ -486,7 +486,8 @@ class CerberusDet(nn.Module):
     def full_precision(self):
         """Evaluate at the reference's own precision -- what `model.float()` on fp32 inputs gives there (cerberus.py:804-882): every convolution as
         six bf16 term-pair launches of the product's MFMA kernels accumulated in fp32, everything between them in fp32 (cerberusdet_amd/precise.py).
-        Boxes / maps agree with the fp32 reference to <= 1e-3 (BASELINE.json's tolerance); roughly 8x the time of the bf16 plan. Eval only."""
+        Boxes / maps agree with the fp32 reference to <= 1e-3 (BASELINE.json's tolerance); roughly 8x the time of the bf16 plan. Forward only: eval
+        mode, or train mode (batch-statistics BatchNorm, running statistics updated) under torch.no_grad() -- there is no full-precision backward."""
         if self.compute_dtype != torch.float32:
             self.compute_dtype = torch.float32
             self._plans = {}
@@ -577,29 +578,30 @@ class CerberusDet(nn.Module):
         """Eval forward of a full_precision() model (cerberusdet_amd/precise.py). Every call returns fresh `y`; the maps are views of the plan's."""
         from ..precise import PrecisePlan
 
-        if self.training:
-            raise NotImplementedError("full_precision() is an eval-mode path (fp32-accurate gradients: tests/hiprec.py); call model.eval() or "
-                                      "model.bfloat16() / model.half() for training")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("full_precision() has no backward (fp32-accurate gradients: tests/hiprec.py over the same kernels): run the "
+                                      "train-mode forward under torch.no_grad(), or call model.bfloat16() / model.half() for training")
         dev = next(super().parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             raise TypeError(f"full_precision(): image dtype {x.dtype} (expected a floating-point image scaled to [0, 1] like the reference's)")
-        key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision")
+        key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision", self.training)
         plan = self._plans.pop(key, None)
         if plan is None:
             cap = int(os.environ.get("CDET_MAX_EVAL_PLANS", "6"))
             evals = [k for k in self._plans if k[3] is False]
             for k in evals[:max(len(evals) - cap + 1, 0)]:
                 self._plans.pop(k).release()
-            plan = PrecisePlan(self, tasks, x.shape[0], x.shape[2], x.shape[3], x.dtype, dev)
+            plan = PrecisePlan(self, tasks, x.shape[0], x.shape[2], x.shape[3], x.dtype, dev, training=self.training)
         self._plans[key] = plan
         with torch.no_grad():
             plan.run(x)
         outs = {}
         for t in tasks:
             nc = self.get_head(t).nc
-            outs[t] = (plan.y[t], [f[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]])
+            maps = [f[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
+            outs[t] = maps if self.training else (plan.y[t], maps)
         return outs[task_ids] if isinstance(task_ids, str) else outs
 
     # ------------------------------------------------------------------------------------------------------ freezing

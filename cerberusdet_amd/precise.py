@@ -82,12 +82,16 @@ class Map:
 class PrecisePlan:
     """Launch list of one (tasks, shape) configuration: compiled once, replayed per forward; packed weight terms refreshed when parameters change."""
 
-    def __init__(self, model, tasks: Sequence[str], N: int, H: int, W: int, img_dtype: torch.dtype, device):
+    def __init__(self, model, tasks: Sequence[str], N: int, H: int, W: int, img_dtype: torch.dtype, device, training: bool = False):
         self.lib = L.load()
         self.model, self.tasks, self.N, self.H, self.W, self.img_dtype, self.device = model, list(tasks), N, H, W, img_dtype, device
+        self.training = training        # train-form BatchNorm (batch statistics, running statistics updated); forward only
+        self.bns: List[nn.BatchNorm2d] = []
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_doubles = 0
         self.steps: List = []           # closures, in launch order
         self.packs: List = []           # closures that (re)build packed weight terms / folded scale and bias
-        self.counts = {"tiled": 0, "s2_tiled": 0, "generic": 0, "epilogue": 0, "split": 0, "pool": 0}  # launches per forward, by entry point
+        self.counts = {"tiled": 0, "s2_tiled": 0, "generic": 0, "epilogue": 0, "split": 0, "pool": 0, "bn": 0}  # launches per forward, by entry point
         self._scratch: Optional[torch.Tensor] = None
         self._scratch_elems = 0
         self._late: List = []
@@ -97,6 +101,7 @@ class PrecisePlan:
         self._packed_at = None
         self._build()
         self._scratch = torch.empty(self._scratch_elems, dtype=torch.float32, device=device)
+        self._ws = torch.empty(max(self._ws_doubles, 1), dtype=torch.float64, device=device)
         for bind in self._late:
             bind()
 
@@ -179,17 +184,37 @@ class PrecisePlan:
         Op = self._conv_raw(x, m.conv.weight, m.k, m.s, Ho, Wo)
         scale = torch.empty(m.c2, dtype=torch.float32, device=self.device)
         bias = torch.empty(m.c2, dtype=torch.float32, device=self.device)
-
-        def pack():
+        if self.training:
+            # train-form BatchNorm: statistics of THIS batch from the fp32 accumulator (cdet_bn_train_f32), running statistics updated unless the
+            # module is frozen (reference cerberus.py:885-905: track_running_stats False, batch statistics still used)
             if getattr(m, "fused", False):
-                scale.fill_(1.0)
-                bias.copy_(m.conv.bias.detach().float())
-            else:
-                bn = m.bn
-                sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
-                scale.copy_(sc.float())
-                bias.copy_((bn.bias.detach().double() - bn.running_mean.double() * sc).float())
-        self.packs.append(pack)
+                raise RuntimeError("training needs un-fused Conv modules (BatchNorm present)")
+            bn, lib, M = m.bn, self.lib, self.N * Ho * Wo
+            self.bns.append(bn)
+            self._ws_doubles = max(self._ws_doubles, int(lib.cdet_bn_train_f32_ws_doubles(m.c2)))
+            slot = {}
+            self._late.append(lambda: slot.update(z=self._scratch.data_ptr(), ws=self._ws.data_ptr()))
+
+            def run():
+                upd = bool(bn.track_running_stats and bn.training)
+                L.check(lib.cdet_bn_train_f32(slot["z"], Op, 0, M, m.c2, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
+                                              bn.running_mean.data_ptr() if upd else None, bn.running_var.data_ptr() if upd else None, slot["ws"],
+                                              scale.data_ptr(), bias.data_ptr(), stream()), "cdet_bn_train_f32")
+                if upd:
+                    bn._nbt_pending = getattr(bn, "_nbt_pending", 0) + 1   # num_batches_tracked (host counter, flushed by the model like the plans')
+            self.steps.append(run)
+            self.counts["bn"] += 1
+        else:
+            def pack():
+                if getattr(m, "fused", False):
+                    scale.fill_(1.0)
+                    bias.copy_(m.conv.bias.detach().float())
+                else:
+                    bn = m.bn
+                    sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
+                    scale.copy_(sc.float())
+                    bias.copy_((bn.bias.detach().double() - bn.running_mean.double() * sc).float())
+            self.packs.append(pack)
         self._epilogue(Op, lambda: scale.data_ptr(), lambda: bias.data_ptr(), L.ACT_SILU, res, y)
 
     # ------------------------------------------------------------------------------------------------ layers
@@ -280,7 +305,8 @@ class PrecisePlan:
 
         def run():
             self.y[task] = detect_decode(feats, nc, strides)
-        self.steps.append(run)
+        if not self.training:  # (train mode returns the raw maps only, models/yolo.py:87-89)
+            self.steps.append(run)
 
     # ------------------------------------------------------------------------------------------------ graph walk
     def _build(self):
@@ -310,8 +336,9 @@ class PrecisePlan:
 
     # ------------------------------------------------------------------------------------------------ run
     def _versions(self):
+        # (train form: the running statistics are written by every forward and read by none of the packs)
         return (self.model._weights_version, sum(int(p._version) for p in self.model.parameters()),
-                sum(int(b._version) for b in self.model.buffers()))
+                0 if self.training else sum(int(b._version) for b in self.model.buffers()))
 
     def release(self):
         """(plan-cache eviction hook, as engine.Plan.release: nothing is registered on the modules here)"""

@@ -389,6 +389,12 @@ int cdet_split3(const void* src, int32_t src_dtype, int32_t src_ld, int32_t src_
  * models/common.py:51-68, 107-117, or the bias of the head's projections (models/yolo.py:82-84). Writes y and / or its three terms. */
 int cdet_epilogue_f32(const float* z, int32_t z_ld, int32_t z_coff, const float* scale, const float* bias, int32_t act, const float* res, int32_t res_ld,
                       int32_t res_coff, float* y, void* y_hi, void* y_mid, void* y_lo, int32_t y_ld, int32_t y_coff, int64_t M, int32_t C, void* stream);
+/* Train-form nn.BatchNorm2d of an fp32 map (models/common.py:57-62 in model.train()): batch statistics in double (fixed summation order) ->
+ * scale[c] = gamma / sqrt(var + eps), bias[c] = beta - mean * scale for cdet_epilogue_f32, and the running statistics (momentum form, unbiased
+ * variance; both null: untouched, as for a frozen block). ws: cdet_bn_train_f32_ws_doubles(C) doubles of scratch. */
+int64_t cdet_bn_train_f32_ws_doubles(int32_t C);
+int cdet_bn_train_f32(const float* z, int32_t z_ld, int32_t z_coff, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, double* ws, float* scale, float* bias, void* stream);
 /* nn.MaxPool2d(k, 1, k / 2) on an fp32 map (SPPF, models/common.py:174-191). */
 int cdet_maxpool_f32(const float* x, int32_t x_ld, int32_t x_coff, float* y, void* y_hi, void* y_mid, void* y_lo, int32_t y_ld, int32_t y_coff, int32_t N,
                      int32_t H, int32_t W, int32_t C, int32_t k, void* stream);
