@@ -160,7 +160,11 @@ _SIGS = {
     "cdet_split3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_epilogue_f32": (i32, [vp, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "cdet_bn_train_f32_ws_doubles": (i64, [i32]),
-    "cdet_bn_train_f32": (i32, [vp, i32, i32, i64, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]),
+    "cdet_bn_train_f32": (i32, [vp, i32, i32, i64, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cdet_bn_silu_bwd_f32": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "cdet_colsum_f32": (i32, [vp, i32, i32, i64, i32, vp, vp, vp]),
+    "cdet_add_f32": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "cdet_maxpool_bwd_f32": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_maxpool_f32": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "cdet_detect_decode": (i32, [vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i32, i32, i32, vp, i32, vp]),
     "cdet_pad_targets": (i32, [vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp]),

@@ -486,8 +486,9 @@ class CerberusDet(nn.Module):
     def full_precision(self):
         """Evaluate at the reference's own precision -- what `model.float()` on fp32 inputs gives there (cerberus.py:804-882): every convolution as
         six bf16 term-pair launches of the product's MFMA kernels accumulated in fp32, everything between them in fp32 (cerberusdet_amd/precise.py).
-        Boxes / maps agree with the fp32 reference to <= 1e-3 (BASELINE.json's tolerance); roughly 8x the time of the bf16 plan. Forward only: eval
-        mode, or train mode (batch-statistics BatchNorm, running statistics updated) under torch.no_grad() -- there is no full-precision backward."""
+        Boxes / maps agree with the fp32 reference to <= 1e-3 (BASELINE.json's tolerance); roughly 8x the time of the bf16 plan. Eval mode, or train mode
+        (batch-statistics BatchNorm, running statistics updated) with a backward at the same precision through autograd: `model(x, task)` ->
+        `loss.backward()` accumulates into the parameters' fp32 `.grad`. The trainer (trainers/averaging.py) keeps to the 16-bit plans."""
         if self.compute_dtype != torch.float32:
             self.compute_dtype = torch.float32
             self._plans = {}
@@ -578,9 +579,6 @@ class CerberusDet(nn.Module):
         """Eval forward of a full_precision() model (cerberusdet_amd/precise.py). Every call returns fresh `y`; the maps are views of the plan's."""
         from ..precise import PrecisePlan
 
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("full_precision() has no backward (fp32-accurate gradients: tests/hiprec.py over the same kernels): run the "
-                                      "train-mode forward under torch.no_grad(), or call model.bfloat16() / model.half() for training")
         dev = next(super().parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
@@ -595,6 +593,11 @@ class CerberusDet(nn.Module):
                 self._plans.pop(k).release()
             plan = PrecisePlan(self, tasks, x.shape[0], x.shape[2], x.shape[3], x.dtype, dev, training=self.training)
         self._plans[key] = plan
+        if self.training and torch.is_grad_enabled():
+            from ..precise import run_with_autograd
+
+            outs = run_with_autograd(plan, x)
+            return outs[task_ids] if isinstance(task_ids, str) else outs
         with torch.no_grad():
             plan.run(x)
         outs = {}

@@ -394,7 +394,24 @@ int cdet_epilogue_f32(const float* z, int32_t z_ld, int32_t z_coff, const float*
  * variance; both null: untouched, as for a frozen block). ws: cdet_bn_train_f32_ws_doubles(C) doubles of scratch. */
 int64_t cdet_bn_train_f32_ws_doubles(int32_t C);
 int cdet_bn_train_f32(const float* z, int32_t z_ld, int32_t z_coff, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
-                     float* running_mean, float* running_var, double* ws, float* scale, float* bias, void* stream);
+                      float* running_mean, float* running_var, double* ws, float* scale, float* bias, float* mean, float* invstd, void* stream);
+/* Backward of y = SiLU(gamma * zhat + beta) with zhat = (z - mean) * invstd (the autograd of models/common.py:57-68 in train mode), all fp32, sums in
+ * double with a fixed order: dgamma[c] += sum da * zhat, dbeta[c] += sum da (either may be null), dz = scale * (da - mean(da) - zhat * mean(da * zhat))
+ * written as value and / or three terms (row length dz_ld, channel 0 first). z: the convolution's fp32 accumulator [M][z_ld]; scale / bias / mean /
+ * invstd: what cdet_bn_train_f32 wrote in the forward; ws as there. */
+int cdet_bn_silu_bwd_f32(const float* dy, int32_t dy_ld, int32_t dy_coff, const float* z, int32_t z_ld, const float* scale, const float* bias, const float* mean,
+                         const float* invstd, int64_t M, int32_t C, double* ws, float* dgamma, float* dbeta, float* dz, void* dz_hi, void* dz_mid,
+                         void* dz_lo, int32_t dz_ld, void* stream);
+/* dst (=|+=) src on fp32 channel slices; downsum = 1: dst pixel (y, x) takes the sum of src pixels (2y..2y+1, 2x..2x+1) of a 2H x 2W source (backward of
+ * nn.Upsample(None, 2, 'nearest')). N, H, W: destination geometry. Gradient fan-in of shortcuts / Concat slices / Upsample. */
+int cdet_add_f32(const float* src, int32_t src_ld, int32_t src_coff, float* dst, int32_t dst_ld, int32_t dst_coff, int32_t N, int32_t H, int32_t W, int32_t C,
+                 int32_t downsum, int32_t accumulate, void* stream);
+/* out[c] += sum over M pixels of src[:, coff + c] (double, fixed order): bias gradient of the head's projections (models/yolo.py:82-84). ws: as
+ * cdet_bn_train_f32. */
+int cdet_colsum_f32(const float* src, int32_t ld, int32_t coff, int64_t M, int32_t C, double* ws, float* out, void* stream);
+/* Backward of cdet_maxpool_f32: dx += dy routed to the FIRST maximum of every window (row-major scan, like nn.MaxPool2d). */
+int cdet_maxpool_bwd_f32(const float* x, int32_t x_ld, int32_t x_coff, const float* dy, int32_t dy_ld, int32_t dy_coff, float* dx, int32_t dx_ld,
+                         int32_t dx_coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, void* stream);
 /* nn.MaxPool2d(k, 1, k / 2) on an fp32 map (SPPF, models/common.py:174-191). */
 int cdet_maxpool_f32(const float* x, int32_t x_ld, int32_t x_coff, float* y, void* y_hi, void* y_mid, void* y_lo, int32_t y_ld, int32_t y_coff, int32_t N,
                      int32_t H, int32_t W, int32_t C, int32_t k, void* stream);
