@@ -507,6 +507,9 @@ class CerberusDet(nn.Module):
 
         training = self.training if training is None else training
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
+        if self.compute_dtype == torch.float32:
+            raise NotImplementedError("compiled plans (trainers.Averaging, val.run, CerberusDetInference streams) store activations in 16 bits: a "
+                                      "full_precision() model runs through model(x) only -- call model.bfloat16() / model.half() first")
         frozen = ()
         if training:  # blocks whose parameters are all frozen (freeze_shared_layers): train-form forward with batch statistics, running
             # statistics untouched, no backward (engine.Plan.frozen)
