@@ -303,12 +303,29 @@ def north_star_forward(model, device, bs=32, imgsz=640, reps=40):
         finite = all(bool(torch.isfinite(y).all()) and all(bool(torch.isfinite(f).all()) for f in maps) for y, maps in fresh.values())
         same = all(torch.equal(fresh[t][0], home[t][0]) and all(torch.equal(a, b) for a, b in zip(fresh[t][1], home[t][1])) for t in fresh)
         checksum = {t: round(float(y.double().sum()), 3) for t, (y, _) in fresh.items()}
+        # ... and against the SAME forward at the reference's precision (model.full_precision(), cerberusdet_amd/precise.py: the reference's fp32 numbers
+        # to ~1e-6, tests/test_gpu_full_precision.py) on the batch's first two images: what 16-bit storage costs on the timed workload
+        vs_full = None
+        if os.environ.get("CDET_BENCH_FULL_PRECISION", "1") != "0":
+            keep = {t: (y[:2].float().clone(), [f[:2].float().clone() for f in maps]) for t, (y, maps) in fresh.items()}
+            model.full_precision()
+            full = model(x[:2].contiguous())
+            torch.cuda.synchronize()
+            vs_full = {
+                "images": 2,
+                "head_maps_rel_l2_max": float("%.3e" % max(float((a - b).norm() / b.norm()) for t in full for a, b in zip(keep[t][1], full[t][1]))),
+                "boxes_max_abs_px": float("%.3e" % max(float((keep[t][0][:, :4] - full[t][0][:, :4]).abs().max()) for t in full)),
+                "class_prob_max_abs": float("%.3e" % max(float((keep[t][0][:, 4:] - full[t][0][:, 4:]).abs().max()) for t in full)),
+                "note": "random-init weights after the timed training steps: the head maps are dominated by their biases (models/yolo.py bias_init)",
+            }
+            del full
+            model.bfloat16()  # (switching the compute dtype drops the cached plans, the full-precision one with its fp32 maps included)
     tf = bs * 381.31e9 * (imgsz / 640) ** 2 / (ms * 1e-3) / 1e12
     model.train()
     return {"ms": round(ms, 3), "tflops": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "images_per_sec": round(bs / ms * 1e3, 1),
             "config": f"YOLOv8x 2-task all-heads forward + decode, eval form (BN folded), bf16, batch {bs} @{imgsz}; default model(x) call (fresh output tensors)",
             "ms_with_fresh_output_tensors": round(ms, 3), "ms_zero_copy": round(ms_zc, 3),
-            "outputs_finite": finite, "fresh_equals_zero_copy": same, "y_checksum": checksum,
+            "outputs_finite": finite, "fresh_equals_zero_copy": same, "y_checksum": checksum, "bf16_vs_full_precision": vs_full,
             "gflop_per_image": 381.31, "timing": f"HIP events around {reps} back-to-back forwards on the launch stream after {n_w} warm-up forwards (>= 1 s)"}
 
 
