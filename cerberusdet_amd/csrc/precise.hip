@@ -45,7 +45,9 @@ __global__ void split3_kernel(const void* __restrict__ src, int src_dtype, int s
         const int y = (int)(q % H), n = (int)(q / H);
         const int ys = y >> up, xs = x >> up;
         const int64_t so = nchw ? (((int64_t)n * C + c) * Hs + ys) * Ws + xs : (((int64_t)n * Hs + ys) * Ws + xs) * src_ld + src_coff + c;
-        emit(load_elem(src, so, src_dtype), p * dst_ld + dst_coff + c, f32, hi, mid, lo);
+        // (a uint8 image is scaled like the reference's preprocess_batch: img.float() / 255, one fp32 division)
+        const float v = src_dtype == CDET_U8 ? (float)((const uint8_t*)src)[so] / 255.0f : load_elem(src, so, src_dtype);
+        emit(v, p * dst_ld + dst_coff + c, f32, hi, mid, lo);
     }
 }
 
@@ -305,7 +307,7 @@ extern "C" int cdet_split3(const void* src, int src_dtype, int src_ld, int src_c
                            void* dst_lo, int dst_ld, int dst_coff, int N, int H, int W, int C, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CDET_CHECK_ARG(src != nullptr && dst_hi != nullptr && dst_mid != nullptr && dst_lo != nullptr, "cdet_split3: null pointer");
-    CDET_CHECK_ARG(src_dtype == CDET_F32 || src_dtype == CDET_BF16 || src_dtype == CDET_F16, "cdet_split3: source dtype %d", src_dtype);
+    CDET_CHECK_ARG(src_dtype == CDET_F32 || src_dtype == CDET_BF16 || src_dtype == CDET_F16 || src_dtype == CDET_U8, "cdet_split3: source dtype %d", src_dtype);
     CDET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && dst_coff >= 0 && dst_coff + C <= dst_ld, "cdet_split3: bad geometry");
     CDET_CHECK_ARG(src_nchw || (src_coff >= 0 && src_coff + C <= src_ld), "cdet_split3: source slice outside its pixel row");
     CDET_CHECK_ARG(!upsample || (H % 2 == 0 && W % 2 == 0), "cdet_split3: an upsampled destination has even sides");

@@ -508,8 +508,8 @@ class CerberusDet(nn.Module):
         training = self.training if training is None else training
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
         if self.compute_dtype == torch.float32:
-            raise NotImplementedError("compiled plans (trainers.Averaging, val.run, CerberusDetInference streams) store activations in 16 bits: a "
-                                      "full_precision() model runs through model(x) only -- call model.bfloat16() / model.half() first")
+            raise NotImplementedError("compiled launch-list plans (engine.Plan: what trainers.Averaging drives) store activations in 16 bits: a "
+                                      "full_precision() model runs through model(x) / autograd only -- call model.bfloat16() / model.half() first")
         frozen = ()
         if training:  # blocks whose parameters are all frozen (freeze_shared_layers): train-form forward with batch statistics, running
             # statistics untouched, no backward (engine.Plan.frozen)
@@ -585,8 +585,9 @@ class CerberusDet(nn.Module):
         dev = next(super().parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
-        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
-            raise TypeError(f"full_precision(): image dtype {x.dtype} (expected a floating-point image scaled to [0, 1] like the reference's)")
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+            raise TypeError(f"full_precision(): image dtype {x.dtype} (expected uint8, divided by 255 like the reference's preprocess_batch, or a "
+                            "floating-point image already scaled to [0, 1])")
         key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision", self.training)
         plan = self._plans.pop(key, None)
         if plan is None:

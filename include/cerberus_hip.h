@@ -381,7 +381,8 @@ int cdet_sppf_pool_bwd(const void* buf, void* dbuf, int32_t ld, int32_t coff, in
  * convolutions in fp32. All maps NHWC [N, H, W, ld] with a channel slice [coff, coff + C); a map's three term buffers share its geometry.
  *
  * cdet_split3: dst pixel (n, y, x) <- src pixel (n, y >> upsample, x >> upsample): copy / Concat slice / nn.Upsample(None, 2, 'nearest')
- * (models/common.py:288-295 and the neck rows of the model YAML) / the NCHW input image (src_nchw = 1: src is [N, C, H, W]). src_dtype F32 / BF16 / F16;
+ * (models/common.py:288-295 and the neck rows of the model YAML) / the NCHW input image (src_nchw = 1: src is [N, C, H, W]). src_dtype F32 / BF16 / F16, or
+ * U8 (value / 255 in fp32: the reference's preprocess_batch);
  * dst_f32 may be null (only the terms are wanted). */
 int cdet_split3(const void* src, int32_t src_dtype, int32_t src_ld, int32_t src_coff, int32_t src_nchw, int32_t upsample, float* dst_f32, void* dst_hi,
                 void* dst_mid, void* dst_lo, int32_t dst_ld, int32_t dst_coff, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
