@@ -257,6 +257,16 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
         }
     };
 
+    auto dma_x_dead = [&](int i, int xb) {  // a prefetch behind the last chunk: same instruction, empty descriptor (the DMA writes zeros into the idle buffer)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);
+        unsigned char* dst = xbase + xb * XHB + (4 * i + wave) * 1024;
+        if (TRI && 4 * i + wave == 20) {
+            if (lane < 16) dma16<CDET_HALO_X_AUX>(rs, 0u, 0u, dst);
+        } else {
+            dma16<CDET_HALO_X_AUX>(rs, 0u, 0u, dst);
+        }
+    };
+
     // ---- fragment read offsets -------------------------------------------------------------------------------------------------
     // A (weights): row f*32 + l31 of the stage, k-slot 2*s + h
     const int aoff0 = l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
@@ -407,11 +417,19 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
             if (i == NM - 1) b_offsets(HZ + xbn * XHB, tapn, bo_nxt);
             if (!(ABL & 1)) {
                 if (NT == 9) {
+                    // (the half-k tail is the LAST chunk: its prefetches only keep the instruction count the waits rely on -- an empty descriptor at
+                    //  offset 0, so that the pixel offsets need not outlive the main loop: they were spilled to scratch for the tail alone)
                     if (i == NM - 2 && u < MAXXP) {
-                        if (xa) dma_x(XPS * u, chunk + 1, (chunk + 1) & 1);
+                        if (xa) {
+                            if (halfk) dma_x_dead(XPS * u, (chunk + 1) & 1);
+                            else dma_x(XPS * u, chunk + 1, (chunk + 1) & 1);
+                        }
                     }
                     if (XPS == 2 && i == NM - 3 && u < MAXXP) {
-                        if (na > 1) dma_x(XPS * u + 1, chunk + 1, (chunk + 1) & 1);
+                        if (na > 1) {
+                            if (halfk) dma_x_dead(XPS * u + 1, (chunk + 1) & 1);
+                            else dma_x(XPS * u + 1, chunk + 1, (chunk + 1) & 1);
+                        }
                     }
                 } else if (i < NXP1) {
                     dma_x(i, chunk + 2, (u + 2) % 3);
