@@ -488,7 +488,7 @@ class CerberusDet(nn.Module):
         six bf16 term-pair launches of the product's MFMA kernels accumulated in fp32, everything between them in fp32 (cerberusdet_amd/precise.py).
         Boxes / maps agree with the fp32 reference to <= 1e-3 (BASELINE.json's tolerance); roughly 8x the time of the bf16 plan. Eval mode, or train mode
         (batch-statistics BatchNorm, running statistics updated) with a backward at the same precision through autograd: `model(x, task)` ->
-        `loss.backward()` accumulates into the parameters' fp32 `.grad`. The trainer (trainers/averaging.py) keeps to the 16-bit plans."""
+        `loss.backward()` accumulates into the parameters' fp32 `.grad`; trainers.Averaging runs such a model as sequential task passes."""
         if self.compute_dtype != torch.float32:
             self.compute_dtype = torch.float32
             self._plans = {}
@@ -578,25 +578,30 @@ class CerberusDet(nn.Module):
                 outs[t] = maps if self.training else (plan.y[t], maps)
         return outs[task_ids] if isinstance(task_ids, str) else outs
 
-    def _forward_full_precision(self, tasks, x, task_ids):
-        """Eval forward of a full_precision() model (cerberusdet_amd/precise.py). Every call returns fresh `y`; the maps are views of the plan's."""
+    def full_precision_plan(self, tasks, x, training: bool):
+        """The cached PrecisePlan of (tasks, image shape / dtype, mode) of a full_precision() model."""
         from ..precise import PrecisePlan
 
-        dev = next(super().parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
-        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
-            raise TypeError(f"full_precision(): image dtype {x.dtype} (expected uint8, divided by 255 like the reference's preprocess_batch, or a "
-                            "floating-point image already scaled to [0, 1])")
-        key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision", self.training)
+        key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision", bool(training))
         plan = self._plans.pop(key, None)
         if plan is None:
             cap = int(os.environ.get("CDET_MAX_EVAL_PLANS", "6"))
             evals = [k for k in self._plans if k[3] is False]
             for k in evals[:max(len(evals) - cap + 1, 0)]:
                 self._plans.pop(k).release()
-            plan = PrecisePlan(self, tasks, x.shape[0], x.shape[2], x.shape[3], x.dtype, dev, training=self.training)
+            plan = PrecisePlan(self, tasks, x.shape[0], x.shape[2], x.shape[3], x.dtype, next(super().parameters()).device, training=bool(training))
         self._plans[key] = plan
+        return plan
+
+    def _forward_full_precision(self, tasks, x, task_ids):
+        """Forward of a full_precision() model (cerberusdet_amd/precise.py). Every call returns fresh `y`; the maps are views of the plan's."""
+        dev = next(super().parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+            raise TypeError(f"full_precision(): image dtype {x.dtype} (expected uint8, divided by 255 like the reference's preprocess_batch, or a "
+                            "floating-point image already scaled to [0, 1])")
+        plan = self.full_precision_plan(tasks, x, self.training)
         if self.training and torch.is_grad_enabled():
             from ..precise import run_with_autograd
 

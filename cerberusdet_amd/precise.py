@@ -21,7 +21,7 @@ gradient as six term-pair launches of the tap-resident kernels on the DGRAD oper
 launches of `cdet_conv2d_wgrad`, pool / upsample / Concat / shortcut gradients in `cdet_maxpool_bwd_f32` / `cdet_add_f32`, the projections' bias
 gradient in `cdet_colsum_f32`; parameter gradients accumulate into the fp32 `.grad` tensors like the 16-bit plans'. `out = model(x, task);
 loss(out).backward()` works through the autograd bridge at the bottom of this file. Cost: 6 MFMA launches + 1 elementwise pass per convolution and
-fp32 maps -- roughly 8x the time of the bf16 plan; it exists for parity, not for throughput (the trainer keeps to the 16-bit plans).
+fp32 maps -- roughly 8x the time of the bf16 plan; it exists for parity, not for throughput (trainers.Averaging runs it as sequential task passes).
 
 Walk order and graph semantics follow `CerberusDet.execution_plan` / `_inputs` exactly as engine.Plan._build does (reference
 cerberus.py:804-882, models/yolo.py:87-100, models/common.py:51-68, 107-117, 174-191, 230-245, 288-295).

@@ -302,6 +302,11 @@ class Averaging:
     def _pass_steps(self, task: str, batch: dict, n_max, active_tasks, fired):
         """One task pass: fused forward + criterion + backward; gradients accumulate. Returns loss items (device tensor[5])."""
         img = batch["img"]
+        if self.model.compute_dtype == torch.float32:
+            # a full_precision() model (cerberusdet_amd/precise.py): the same pass at the reference's own precision -- forward, the fused criterion on its
+            # fp32 head maps, the full-precision backward into the same .grad buckets; every reduction unit the task serves is then complete at once
+            # (no overlap with the backward: this path exists for parity, tests/test_gpu_full_precision.py)
+            return self._pass_full_precision(task, batch, n_max, active_tasks)
         plan = self.model.get_plan(task, img.shape, img.dtype, training=True)
         if not plan.hooks:
             for idx in {i for i, _ in plan.bwd_groups}:
@@ -314,6 +319,29 @@ class Averaging:
         gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max, dropped=self._gt_dropped)
         loss5 = plan.loss(task, gt, self.gains[task], grad_scale=float(self.loss_weights[task]))
         yield from plan.iter_backward(fired)
+        return loss5
+
+    def _pass_full_precision(self, task: str, batch: dict, n_max, active_tasks):
+        from ..ops import det_loss
+
+        img = batch["img"]
+        model = self.model
+        plan = model.full_precision_plan([task], img, training=True)
+        self._active = active_tasks
+        with torch.no_grad():
+            plan.run(img)
+            if self._gt_dropped is None:
+                self._gt_dropped = torch.zeros(1, dtype=torch.int32, device=img.device)
+            gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max, dropped=self._gt_dropped)
+            head = model.get_head(task)
+            loss5, dfe, _ = det_loss(plan.feats[task], gt, head.nc, self.gains[task], [float(s) for s in head.stride],
+                                     grad_scale=float(self.loss_weights[task]), grad_dtype=torch.float32)
+            for d, g in zip(plan.dfeats[task], dfe):
+                d.copy_(g)
+            plan.run_backward()
+        for key, u in self.units.items():
+            if task in u["serving"]:
+                self._unit_done(key, task)
         return loss5
 
     def _run_tasks_on_streams(self, active, batches, n_max, out):
@@ -485,7 +513,7 @@ class Averaging:
             counts = [torch.bincount(batches[t]["batch_idx"].reshape(-1).long(), minlength=batches[t]["img"].shape[0]).max()
                       for t in active if batches[t]["batch_idx"].numel()]
             n_max = max(int(torch.stack(counts).max()), 1) if counts else 1
-        if self.task_streams and len(active) > 1:
+        if self.task_streams and len(active) > 1 and self.model.compute_dtype != torch.float32:
             self._run_tasks_on_streams(active, batches, n_max, out)
         else:
             self.join_tail()
