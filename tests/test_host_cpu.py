@@ -59,6 +59,15 @@ def test_no_cpu_fallback():
     for kw in (dict(retain_tensors=True), dict(retain_all=True)):
         with pytest.raises(NotImplementedError):
             m(torch.zeros(1, 3, 64, 64), **kw)
+    # the full-precision path (cerberusdet_amd/precise.py) has no CPU form either, and the compiled 16-bit plans refuse an fp32 compute dtype
+    assert m.float() is m and m.compute_dtype == torch.bfloat16            # .float() stays a no-op: parameters are fp32 masters already
+    assert m.full_precision() is m and m.compute_dtype == torch.float32
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="MI355X"):
+            m.eval()(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError, match="16 bits"):
+        m.get_plan("a", (1, 3, 64, 64), torch.float32, training=False)
+    assert m.half().compute_dtype == torch.float16 and m.bfloat16().compute_dtype == torch.bfloat16
 
 
 @pytest.mark.parametrize("ref_name", list(CFGS))
@@ -196,6 +205,18 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     cd.dtype, cd.out_dtype, cd.src_ld, cd.dst_ld = L.BF16, L.BF16, 12, 16
     rc = lib.cdet_conv2d(C.byref(cd), one, one, None, None, None, one, None, None)
     assert rc < 0 and "multiples of 8" in lib.cdet_last_error().decode()  # Cs = 12
+    # the fp32 kernels of the full-precision path (csrc/precise.hip)
+    rc = lib.cdet_split3(one, L.F32, 8, 0, 0, 0, None, None, one, one, 8, 0, 1, 4, 4, 8, None)
+    assert rc < 0 and "null pointer" in lib.cdet_last_error().decode()
+    rc = lib.cdet_split3(one, L.F32, 8, 0, 0, 1, None, one, one, one, 8, 0, 1, 5, 4, 8, None)
+    assert rc < 0 and "even sides" in lib.cdet_last_error().decode()
+    rc = lib.cdet_epilogue_f32(one, 8, 0, None, None, 7, None, 0, 0, one, None, None, None, 8, 0, 16, 8, None)
+    assert rc < 0 and "activation" in lib.cdet_last_error().decode()
+    rc = lib.cdet_maxpool_f32(one, 8, 0, one, None, None, None, 8, 0, 1, 4, 4, 8, 4, None)
+    assert rc < 0 and "bad geometry" in lib.cdet_last_error().decode()
+    rc = lib.cdet_bn_train_f32(one, 8, 0, 16, 8, one, one, 1e-3, 0.03, one, None, one, one, one, None, None, None)
+    assert rc < 0 and "come together" in lib.cdet_last_error().decode()
+    assert lib.cdet_bn_train_f32_ws_doubles(80) == 128 * 2 * 80
     md = L.MergeDesc()
     md.N, md.T, md.max_det, md.iou_thres = 1, 9, 300, 0.8
     rc = lib.cdet_merge_tasks(C.byref(md), None, one, one, None)
