@@ -43,6 +43,15 @@ def run():
         y, yr = out[t][0].float().cpu().numpy(), ref[t][0].numpy()
         err = np.linalg.norm(y - yr) / np.linalg.norm(yr)
         assert err < 3e-2, f"eval forward mismatch for {t}: rel-L2 {err:.4f}"
+    # ---- the same forward at the reference's precision (model.full_precision(), precise.py) vs the fp32 oracle: tight
+    model.full_precision()
+    with torch.no_grad():
+        outp = model(x.to(dev))
+    for t in tasks:
+        y, yr = outp[t][0].cpu().numpy(), ref[t][0].numpy()
+        err = np.abs(y[:, :4] - yr[:, :4]).max() / np.abs(yr[:, :4]).max()
+        assert err < 1e-3 and np.abs(y[:, 4:] - yr[:, 4:]).max() < 1e-3, f"full-precision forward mismatch for {t}: {err:.2e}"
+    model.bfloat16()
     # ---- batched NMS vs oracle (bit exact)
     import importlib.util
 
