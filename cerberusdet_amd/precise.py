@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .models.common import C2f, Concat, Conv, SPPF, Upsample
-from .ops import View, conv_desc, detect_decode, dt, pack_weight, pack_weight_tiled, ptr, stream
+from .ops import View, conv_desc, detect_decode, dt, pack_weight, pack_weight_tiled, stream
 
 # operand-term pairs whose product is above 2^-24 relative: hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi
 _PAIRS = [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)]
@@ -226,13 +226,11 @@ class PrecisePlan:
                                           1 if n_ > 0 else 0, st), "precise weight gradient")
         _grad_of(rec.weight).add_(rec.dw[:rec.O, :rec.Ci])
         if rec.need_dx:
-            for i, j in _PAIRS:                # dX += conv(dz_i, W_j^T): every launch accumulates (other consumers of x may have written already)
-                if rec.dpath == "s2_tiled":
-                    L.check(rec.dfn(C.byref(rec.ddesc), dz_terms[i].data_ptr(), rec.packed_d[j].data_ptr(), None, None, None, x.g.data_ptr(), None, st),
-                            "precise data gradient")
-                else:
-                    L.check(rec.dfn(C.byref(rec.ddesc), dz_terms[i].data_ptr(), rec.packed_d[j].data_ptr(), None, None, None, x.g.data_ptr(), None, st),
-                            "precise data gradient")
+            # dX += conv(dz_i, W_j^T): every launch accumulates (other consumers of x may have written already). The three entry points -- tiled kernel on the
+            # DGRAD operand, stride-2 parity-class kernel, generic kernel in DGRAD mode -- share one argument list
+            for i, j in _PAIRS:
+                L.check(rec.dfn(C.byref(rec.ddesc), dz_terms[i].data_ptr(), rec.packed_d[j].data_ptr(), None, None, None, x.g.data_ptr(), None, st),
+                        "precise data gradient")
 
     def _conv_unit(self, m: Conv, x: Map, y: Map, res: Optional[Map] = None):
         """SiLU(BN(conv(x))) (+ res) -> y (models/common.py:51-68; BatchNorm folded as in fuseforward, or the fused module's own bias). Train plans:
