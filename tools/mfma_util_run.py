@@ -4,6 +4,7 @@
   conv_halo_kernel   linear tiles   40 x 40 320 -> 320 3x3   (38 launches per north-star forward, the most frequent)
   conv_halo_kernel   16 x 16 patch  80 x 80 160 -> 160 3x3
   conv_pair_kernel                  40 x 40 1600 -> 640 1x1
+  conv_halo_kernel   96-cout patch  160 x 160 80 -> 80 3x3   (round 5: three workgroups per CU; CDET_HALO_WG3=0 for two)
   conv_vt_kernel     stride 2       160 x 160 160 -> 320 3x3 (80 x 80 output)
   wgrad_halo_kernel                 40 x 40 320 -> 320 3x3 weight gradient"""
 import argparse
@@ -37,7 +38,7 @@ def main():
 
     N = a.bs
     jobs = []
-    for H, Ci, Co, k in ((40, 320, 320, 3), (80, 160, 160, 3), (40, 1600, 640, 1)):
+    for H, Ci, Co, k in ((40, 320, 320, 3), (80, 160, 160, 3), (40, 1600, 640, 1), (160, 80, 80, 3)):
         x, w = act(N, H, H, Ci), wt(Co, Ci, k)
         y = ops.new_act(N, H, H, Co, dt)
         wf, _ = ops.pack_weight_tiled(w, dt)
