@@ -556,7 +556,7 @@ class CerberusDet(nn.Module):
         tasks = [task_ids] if isinstance(task_ids, str) else list(task_ids)
         x = input_tensor.contiguous()
         if self.compute_dtype == torch.float32:
-            return self._forward_full_precision(tasks, x, task_ids)
+            return self._forward_full_precision(tasks, x, task_ids, zero_copy)
         plan = self.get_plan(tasks, x.shape, x.dtype)
         if self.training and torch.is_grad_enabled():
             from ..autograd_bridge import run_with_autograd
@@ -593,8 +593,9 @@ class CerberusDet(nn.Module):
         self._plans[key] = plan
         return plan
 
-    def _forward_full_precision(self, tasks, x, task_ids):
-        """Forward of a full_precision() model (cerberusdet_amd/precise.py). Every call returns fresh `y`; the maps are views of the plan's."""
+    def _forward_full_precision(self, tasks, x, task_ids, zero_copy=False):
+        """Forward of a full_precision() model (cerberusdet_amd/precise.py). Like the 16-bit plans: fresh tensors per call (one flat copy of the head
+        maps) unless zero_copy=True, which returns views of the plan's maps that the next forward of the configuration overwrites."""
         dev = next(super().parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("cerberusdet_amd runs on an MI355X only: move the model to 'cuda' (there is no CPU path)")
@@ -612,7 +613,7 @@ class CerberusDet(nn.Module):
         outs = {}
         for t in tasks:
             nc = self.get_head(t).nc
-            maps = [f[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
+            maps = [(f if zero_copy else f.clone())[..., :64 + nc].permute(0, 3, 1, 2) for f in plan.feats[t]]
             outs[t] = maps if self.training else (plan.y[t], maps)
         return outs[task_ids] if isinstance(task_ids, str) else outs
 
