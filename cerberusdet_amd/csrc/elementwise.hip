@@ -764,35 +764,42 @@ __global__ __launch_bounds__(256) void pool5_kernel(uint16_t* __restrict__ buf, 
 // launches; two launches and two round trips through L2 less on the serial trunk.
 template <int DT>
 __global__ __launch_bounds__(256) void sppf_pool3_kernel(uint16_t* __restrict__ buf, int ld, int coff, int C, int H, int W, int CV) {
+    // (round 5: the planes live in LDS as fp32 -- widened once at the load, narrowed once per stored slice; a window maximum is then 8 v_max_f32 per
+    //  neighbour instead of 16 conversions + 8 maxima + 8 conversions on packed 16-bit pairs -- and a workgroup owns 16 channels instead of 32, so the
+    //  20 x 20 level of a batch-32 forward is 640 workgroups in one round instead of 320 in two: 77 -> see profiles/r05_fwd_shapes_eval.txt)
     extern __shared__ __attribute__((aligned(16))) unsigned char sp[];
-    constexpr int G = 4;                                   // 8-channel vectors per workgroup
+    constexpr int G = 2;                                   // 8-channel vectors per workgroup
     const int groups = (CV + G - 1) / G;
     const int n = blockIdx.x / groups, g0 = (blockIdx.x % groups) * G;
     const int ng = CV - g0 < G ? CV - g0 : G;
     const int HW = H * W;
-    u32x4* const A = reinterpret_cast<u32x4*>(sp);         // [HW][G]
-    u32x4* const B = A + HW * G;
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    f32x8* const A = reinterpret_cast<f32x8*>(sp);         // [HW][G]
+    f32x8* const B = A + HW * G;
     uint16_t* const base = buf + (int64_t)n * HW * ld;
     for (int e = threadIdx.x; e < HW * ng; e += 256) {
         const int p = e / ng, g = e - p * ng;
-        A[p * G + g] = *reinterpret_cast<const u32x4*>(base + (int64_t)p * ld + coff + (g0 + g) * 8);
-    }
-    __syncthreads();
-    auto vmax = [](const u32x4& a, const u32x4& b) {
-        u32x4 o;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (int64_t)p * ld + coff + (g0 + g) * 8);
+        f32x8 f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float al = Elem<DT>::to_f32((uint16_t)(a[i] & 0xffff)), ah = Elem<DT>::to_f32((uint16_t)(a[i] >> 16));
-            const float bl = Elem<DT>::to_f32((uint16_t)(b[i] & 0xffff)), bh = Elem<DT>::to_f32((uint16_t)(b[i] >> 16));
-            o[i] = (uint32_t)Elem<DT>::from_f32(fmaxf(al, bl)) | ((uint32_t)Elem<DT>::from_f32(fmaxf(ah, bh)) << 16);
+            f[2 * i] = Elem<DT>::to_f32((uint16_t)(v[i] & 0xffff));
+            f[2 * i + 1] = Elem<DT>::to_f32((uint16_t)(v[i] >> 16));
         }
+        A[p * G + g] = f;
+    }
+    __syncthreads();
+    auto vmax = [](const f32x8& a, const f32x8& b) {
+        f32x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaxf(a[i], b[i]);
         return o;
     };
     for (int stage = 0; stage < 3; ++stage) {
         for (int e = threadIdx.x; e < HW * ng; e += 256) {  // rows: B = max over x - 2 .. x + 2 of A
             const int p = e / ng, g = e - p * ng;
             const int x = p % W;
-            u32x4 m = A[p * G + g];
+            f32x8 m = A[p * G + g];
 #pragma unroll
             for (int k = -2; k <= 2; ++k)
                 if (k != 0 && (unsigned)(x + k) < (unsigned)W) m = vmax(m, A[(p + k) * G + g]);
@@ -802,11 +809,14 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(uint16_t* __restrict__ 
         for (int e = threadIdx.x; e < HW * ng; e += 256) {  // columns: A = max over y - 2 .. y + 2 of B, and out
             const int p = e / ng, g = e - p * ng;
             const int y = p / W;
-            u32x4 m = B[p * G + g];
+            f32x8 m = B[p * G + g];
 #pragma unroll
             for (int k = -2; k <= 2; ++k)
                 if (k != 0 && (unsigned)(y + k) < (unsigned)H) m = vmax(m, B[(p + k * W) * G + g]);
-            *reinterpret_cast<u32x4*>(base + (int64_t)p * ld + coff + (stage + 1) * C + (g0 + g) * 8) = m;
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (uint32_t)Elem<DT>::from_f32(m[2 * i]) | ((uint32_t)Elem<DT>::from_f32(m[2 * i + 1]) << 16);
+            *reinterpret_cast<u32x4*>(base + (int64_t)p * ld + coff + (stage + 1) * C + (g0 + g) * 8) = o;
             if (stage < 2) A[p * G + g] = m;                // (nobody reads A in this pass)
         }
         __syncthreads();
@@ -1253,9 +1263,9 @@ extern "C" int cdet_upsample2_bwd(const void* ddst, int32_t ddst_ld, int32_t dds
 extern "C" int cdet_sppf_pool(void* buf, int32_t ld, int32_t coff, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
     if (int e = check16("cdet_sppf_pool", dtype, C, ld, coff, 0, 0)) return e;
     const int CV = C / 8;
-    if ((int64_t)H * W * 4 * 16 * 2 <= 60 * 1024 && tune_env("CDET_SPPF_FUSED", 1)) {  // the plane of 32 channels twice in LDS: one launch for the chain
-        const size_t lds = (size_t)H * W * 4 * 16 * 2;
-        DISPATCH16(dtype, hipLaunchKernelGGL((sppf_pool3_kernel<DT>), dim3(N * div_up(CV, 4)), dim3(256), lds, (hipStream_t)stream, (uint16_t*)buf, ld, coff,
+    if ((int64_t)H * W * 2 * 32 * 2 <= 60 * 1024 && tune_env("CDET_SPPF_FUSED", 1)) {  // the plane of 16 channels twice in LDS, as fp32: one launch for the chain
+        const size_t lds = (size_t)H * W * 2 * 32 * 2;
+        DISPATCH16(dtype, hipLaunchKernelGGL((sppf_pool3_kernel<DT>), dim3(N * div_up(CV, 2)), dim3(256), lds, (hipStream_t)stream, (uint16_t*)buf, ld, coff,
                                              C, H, W, CV));
         CDET_LAUNCH_CHECK();
         return 0;
