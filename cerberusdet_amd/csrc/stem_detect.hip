@@ -80,6 +80,60 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DecodeArgs d, int N,
     }
 }
 
+// Round 5: FOUR lanes per (image, anchor) for the engine's head maps (fp32 rows of 64 + pad8(nc) floats). Lane s of a group owns side s of the box: its
+// 16 DFL bins are one contiguous 64-byte run (four lanes = 256 contiguous bytes of the row, where the one-thread form had every lane 576 bytes from its
+// neighbour), the softmax expectation keeps the per-side order of the one-thread form (same bits), the four distances meet through three DPP reads of the
+// quad, every lane stores ONE of cx / cy / w / h and every fourth class. A quarter of the dependent chain per thread, four times the threads: the decode is
+// the tail of the eval forward (48 -> see profiles/r05_fwd_timeline.txt).
+__global__ __launch_bounds__(256) void detect_decode4_kernel(DecodeArgs d, int N, int nc, int f_ld, float* __restrict__ y) {
+    const int A = d.a_off[3];
+    const int64_t total = (int64_t)N * A * 4;
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (whole quads stay together: the grid covers `total` rounded up to a multiple of 4 by construction, and out-of-range quads do their reads on anchor 0)
+    for (int64_t t = first; t < (total + 255) / 256 * 256; t += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = t < total;
+        const int64_t idx = live ? t >> 2 : 0;
+        const int s = (int)(t & 3);
+        const int n = (int)(idx / A);
+        const int a = (int)(idx - (int64_t)n * A);
+        const int lvl = a >= d.a_off[2] ? 2 : (a >= d.a_off[1] ? 1 : 0);
+        const int la = a - d.a_off[lvl];
+        const int gx = la % d.w[lvl], gy = la / d.w[lvl];
+        const float* row = reinterpret_cast<const float*>(d.f[lvl]) + ((int64_t)n * d.h[lvl] * d.w[lvl] + la) * f_ld;
+        const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+        float v[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) {
+            const f32x4 q = row4[s * 4 + b4];
+            v[b4 * 4 + 0] = q[0]; v[b4 * 4 + 1] = q[1]; v[b4 * 4 + 2] = q[2]; v[b4 * 4 + 3] = q[3];
+        }
+#pragma unroll
+        for (int b = 0; b < 16; ++b) mx = fmaxf(mx, v[b]);
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const float e = expf(v[b] - mx);
+            den += e;
+            num += e * (float)b;
+        }
+        const float dist = num / den;
+        // the quad's four distances (quad_perm broadcasts of lanes 0..3 of the quad)
+        const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dist), 0x00, 0xf, 0xf, true));
+        const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dist), 0x55, 0xf, 0xf, true));
+        const float d2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dist), 0xAA, 0xf, 0xf, true));
+        const float d3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, dist), 0xFF, 0xf, 0xf, true));
+        const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f, st = d.stride[lvl];
+        const float x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3;
+        const float box = s == 0 ? (x1 + x2) * 0.5f * st : (s == 1 ? (y1 + y2) * 0.5f * st : (s == 2 ? (x2 - x1) * st : (y2 - y1) * st));
+        if (live) {
+            const int64_t yo = (int64_t)n * (4 + nc) * A + a;
+            y[yo + (int64_t)s * A] = box;
+            for (int c = s; c < nc; c += 4) y[yo + (int64_t)(4 + c) * A] = 1.0f / (1.0f + expf(-row[64 + c]));
+        }
+    }
+}
+
 }  // namespace cdet
 
 using namespace cdet;
@@ -117,6 +171,12 @@ extern "C" int cdet_detect_decode(const void* f0, const void* f1, const void* f2
     }
     d.a_off[3] = off;
     const int64_t total = (int64_t)N * off;
+    if (dtype == CDET_F32 && out_dtype == CDET_F32 && (f_ld & 3) == 0 && tune_env("CDET_DECODE4", 1)) {  // the engine's head maps: four lanes per anchor
+        const int64_t b4 = (total * 4 + 255) / 256;
+        hipLaunchKernelGGL(detect_decode4_kernel, dim3((unsigned)(b4 > 16384 ? 16384 : b4)), dim3(256), 0, (hipStream_t)stream, d, N, nc, f_ld, (float*)y);
+        CDET_LAUNCH_CHECK();
+        return 0;
+    }
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(detect_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d, N, nc, f_ld, dtype, y, out_dtype);

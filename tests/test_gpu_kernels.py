@@ -799,3 +799,25 @@ def test_val_run_smoke_on_tiny_model():
     res = val.run(m, mmeta["tasks"][0], batches, half=False)
     assert res["seen"] == 8 and int(res["nt"].sum()) == 24
     assert all(np.isfinite(res[k]) and 0.0 <= res[k] <= 1.0 for k in ("mp", "mr", "map50", "map"))
+
+
+def test_detect_decode_four_lane_form_carries_the_bits_of_the_one_thread_form():
+    """cdet_detect_decode picks the four-lanes-per-anchor kernel (round 5) for fp32 maps whose row length is a multiple of 4 and the one-thread-per-anchor
+    kernel otherwise: the same head maps in an 88-float and in an 85-float row layout (nc = 21) must give the same bits -- per side the DFL softmax
+    expectation runs in the same order in both forms. Batch 3, levels 20 x 12 / 10 x 6 / 5 x 3 (a last partial block)."""
+    from cerberusdet_amd import ops
+
+    nc, N = 21, 3
+    g = torch.Generator().manual_seed(12)
+    shapes = [(20, 12), (10, 6), (5, 3)]
+    maps = [torch.randn(N, h, w, 64 + nc, generator=g) * 3 for h, w in shapes]
+    outs = []
+    for ld in (88, 85):
+        feats = []
+        for m in maps:
+            f = torch.full((N, m.shape[1], m.shape[2], ld), float("nan"))
+            f[..., :64 + nc] = m
+            feats.append(f.to(DEV))
+        outs.append(ops.detect_decode(feats, nc, (8.0, 16.0, 32.0)))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
