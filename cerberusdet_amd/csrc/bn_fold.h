@@ -89,10 +89,11 @@ __device__ __forceinline__ void bn_stats_from_totals(float sf, float qf, double 
 //   row    this workgroup's row; [c0, c0 + ncols) its column range; cb its column-block index (< BNF_MAX_CB)
 //   flag   one LDS word nothing else uses any more
 // FWD: totals -> mean / invstd (+ running statistics); else (backward) totals -> sums [2C] and dgamma / dbeta.
+//   live   threads that take part (default: the whole workgroup; conv_halo_kernel's K-split form arrives here with its first 256 threads only)
 template <bool FWD>
 __device__ __forceinline__ void bn_fold_finish(const BnFold* __restrict__ fp, const float* __restrict__ part, int row, int c0, int ncols, int cb,
-                                               volatile int* flag) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+                                               volatile int* flag, int live = 0) {
+    const int tid = threadIdx.x, nt = live ? live : (int)blockDim.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the row has left the CU (sc1 stores)
     __syncthreads();
     const int nrows = fp->nrows, C = fp->C, ncl = fp->ncl;

@@ -53,6 +53,7 @@ struct HaloArgs {
     int halfk;  // 3x3 only: the last 32-channel chunk holds at most 16 channels (Cs = 80): its second k16 half is all zeros and is skipped
     int accum;  // HEPI_F32 only: y (fp32) += result
     CatSrcs cat;  // CAT instantiations (1x1 only): the source is a virtual Concat of up to three buffers (halo_common.h)
+    int ks_region;  // KS = 2: bytes of LDS of one K half (zero row + pixel buffers + weight ring)
 };
 
 constexpr int HEPI_STAGE_OFF = 6912;  // epilogue LDS map (after HZERO): statistics scratch [4][2][HC] fp32, scale/bias [2][HC] fp32, then the store staging
@@ -80,8 +81,15 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // the 64 x 160 wave tile -- and the workgroup's weight ring serves twice the pixels: LDS reads per FLOP -36 %, weight LDS-DMA per FLOP -50 %, one
 // barrier per 40 MFMAs instead of per 20. (Measured on the 256-pixel form, profiling build, 40 x 40 320 -> 320: the K loop takes 98 us, its MFMAs alone
 // 55, everything but the MFMAs alone 48 -- the two do not overlap; tools/conv_tiled_bench.py with CDET_HALO_ABLATE.)
-template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false, bool CAT = false>
-__global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) void conv_halo_kernel(const HaloArgs a) {
+// KS = 2 (round 5, late): the half-tile form with the K loop SPLIT INSIDE THE WORKGROUP. The 128-pixel launches (20 x 20 maps at batch 32: 200 workgroups, at
+// most one per CU) are a single 90-step dependent chain per workgroup with one wave per SIMD -- nothing covers a wave's DMA issue cost or its barrier
+// waits (34 us for 0.015 TFLOP). Eight waves: waves 0-3 run the first half of the channel chunks, waves 4-7 the second half of the SAME pixels and couts
+// in an LDS region of their own (two waves per SIMD: each covers the other's bubbles, and the chain is half as long); at the end the upper half hands
+// its accumulators over through LDS and exits (a finished wave no longer takes part in s_barrier), the lower half adds them and runs the unchanged
+// epilogue. Sum order: (first half's chunks in order) + (second half's chunks in order) -- deterministic, not the one-chain order.
+template <int DT, int NT, int NF, int EPI, int NSW, bool PATCH, int NG = 2, int ABL = 0, bool OMAP = false, bool CAT = false, int KS = 1>
+__global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) void conv_halo_kernel(const HaloArgs a) {
+    static_assert(KS == 1 || (KS == 2 && NG == 1 && NT == 9 && NSW == 3 && !PATCH && !OMAP && !CAT && ABL == 0), "the in-workgroup K split: 3x3 half tiles only");
     // TRI (round 5, CDET_HALO_WG3=1): THREE workgroups per CU for the 96-cout patch form (the 80-channel layers of the 160 x 160 stage, where a
     // workgroup's life is a chain of latencies -- tile fetch, 27 short K steps, statistics, store -- and two resident workgroups leave the MFMA pipe idle
     // 65 % of the time). 160 KB / 3 in the LDS allocation granule of gfx950 (1280 B) = 42 granules = 53 760 B: two 18 x 18-row pixel buffers without
@@ -112,11 +120,14 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
     constexpr int NM = NG * NF;           // MFMAs per phase (one k16 half of a step)
     constexpr int NR = NF + NG;           // fragment reads per phase (two per MFMA slot)
     static_assert(NM >= (NR + 1) / 2 + 1, "phase B needs a slot for the weight DMA in front of the fragment reads");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int khalf = KS == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;  // which half of the K loop this wave runs
+    unsigned char* const smem = smem_all + (KS == 2 ? khalf * a.ks_region : 0);              // ... in an LDS region of its own
+    const int t = KS == 2 ? (int)threadIdx.x & 255 : (int)threadIdx.x;                       // thread / wave index inside the half
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, h = lane >> 5;
+    const int cbeg = KS == 2 ? khalf * (a.nchunk >> 1) : 0;                                  // first channel chunk of this half
 
     // XCD-aware remap (bijective): consecutive logical ids -- the cout blocks of one pixel tile, then the next pixel tile -- run on ONE XCD
     int L;
@@ -325,9 +336,9 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
     // ---- prologue: chunk 0 of X (1x1: chunks 0 and 1), weight tiles of steps 0 .. NSW-1 -------------------------------------------
 #pragma unroll
     for (int i = 0; i < MAXXPK; ++i)
-        if (i < nxpw) dma_x(i, 0, 0);
+        if (i < nxpw) dma_x(i, cbeg, cbeg & 1);
 #pragma unroll
-    for (int j = 0; j < NWP; ++j) dma_w1(0, 0, j);
+    for (int j = 0; j < NWP; ++j) dma_w1(cbeg * NT, 0, j);
     if (NT == 1) {
 #pragma unroll
         for (int i = 0; i < NXP1; ++i) dma_x(i, 1, 1);
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
 #pragma unroll
     for (int sg = 1; sg < NSW; ++sg) {
 #pragma unroll
-        for (int j = 0; j < NWP; ++j) dma_w1(sg, sg, j);
+        for (int j = 0; j < NWP; ++j) dma_w1(cbeg * NT + sg, sg, j);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NT == 1 ? NXP1 : 0) + (NSW - 1) * NWP) : "memory");  // tile 0 and chunk 0 have landed
     __builtin_amdgcn_s_barrier();
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
 #endif
     int bo_cur[NG], bo_nxt[NG];
     u32x4 a0[NF], b0[NG], a1[NF], b1[NG];
-    b_offsets(HZ, 0, bo_cur);
+    b_offsets(HZ + (cbeg & 1) * XHB, 0, bo_cur);
 #pragma unroll
     for (int i = 0; i < NR; ++i) frag(wbase, bo_cur, 0, i, a0, b0);
 
@@ -495,12 +506,12 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
 
     if (ABL & 16) {
     } else if (NT == 9) {
-        const int nfull = a.halfk ? a.nchunk - 1 : a.nchunk;
-        for (int chunk = 0; chunk < nfull; ++chunk) {
+        const int nfull = KS == 2 ? cbeg + (a.nchunk >> 1) : (a.halfk ? a.nchunk - 1 : a.nchunk);  // (KS = 2: an even number of full chunks -- host check)
+        for (int chunk = cbeg; chunk < nfull; ++chunk) {
 #pragma unroll
             for (int u = 0; u < 9; ++u) step(chunk * 9 + u, chunk, u, std::false_type{});
         }
-        if (a.halfk) {
+        if (KS == 1 && a.halfk) {
 #pragma unroll
             for (int u = 0; u < 9; ++u) step(nfull * 9 + u, nfull, u, std::true_type{});
         }
@@ -522,6 +533,30 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");  // asm MFMAs are opaque to the hazard recogniser; trailing (dead) DMA drained
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if (KS == 2) {
+        // the upper half's accumulators -> LDS [register][256 lanes of the half] (conflict-free: consecutive lanes, consecutive words), then it is done
+        float* const ex = reinterpret_cast<float*>(smem_all);
+        if (khalf == 1) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[((f * NG + g) * 16 + r) * 256 + t] = acc[f][g][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (khalf == 1) return;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][g][r] += ex[((f * NG + g) * 16 + r) * 256 + t];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // (the four remaining waves: the epilogue reuses this LDS)
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- BN statistics of the raw convolution (train mode): per (pixel block, channel) partial sums ---------------------------------
     if (a.stats != nullptr) {
@@ -685,7 +720,7 @@ __global__ __launch_bounds__(256, NG == 4 ? 1 : ((PATCH && NSW == 2) ? 3 : 2)) v
                 a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
             }
         }
-        if (a.fold != nullptr) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem));
+        if (a.fold != nullptr) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem), 256);
     }
 #ifdef CDET_PROFILING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -798,6 +833,7 @@ struct HaloPlan {
     bool ok, patch;
     int nf, ng, hp, XH, nsw, nxb;
     bool tri;
+    int ks;  // 2: the K loop split inside the workgroup (3x3 half tiles with an even number of full channel chunks)
     size_t lds;
 };
 
@@ -875,6 +911,19 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     const size_t epi = (size_t)HZERO + HEPI_STAGE_OFF + 4 * 32 * (size_t)(rb * 2 + 16);  // the epilogue's store staging
     if (pl.lds < epi) pl.lds = epi;
     if (pl.tri && pl.lds != 42 * 1280) return HaloPlan{};
+    // the half-tile form's K loop split inside the workgroup (KS = 2 in the kernel): 3x3, 160-cout blocks, >= 4 full chunks, an even number of them, and a
+    // grid that gives no CU a second workgroup anyway (the split form owns its CU: 20 x 20 320 -> 320 at batch 32, 200 workgroups, 34.3 -> 31.2 us;
+    // 640 -> 320 57.5 -> 51.6; a 400-workgroup grid loses 7 %). CDET_HALO_KS=1 keeps the one-chain form, =2 forces the split (tests)
+    pl.ks = 1;
+    {
+        const char* e = getenv("CDET_HALO_KS");
+        const int nchunk = div_up(d->Cs, 32);
+        const int64_t nblk = (int64_t)div_up(M, pl.hp) * div_up(d->Cd, rb);
+        const int ev = e ? atoi(e) : 0;
+        if (ev != 1 && (ev == 2 || nblk <= 256) && pl.ng == 1 && d->kh == 3 && pl.nf == 5 && pl.nsw == 3 && !pl.patch && d->Cs % 32 == 0 && nchunk >= 4 &&
+            nchunk % 2 == 0 && 2 * pl.lds <= 160 * 1024)
+            pl.ks = 2;
+    }
     pl.ok = true;
     return pl;
 }
@@ -921,6 +970,22 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
     hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG>), dim3(nblocks), dim3(256), lds, s, a);
 }
 
+// the in-workgroup K split of the half-tile form: 512 threads, two LDS regions of the one-chain form's size (at least the 80 KiB of the hand-over)
+template <int DT, int NF, int EPI>
+static void launch_halo_ks2(HaloArgs a, size_t lds_half, int nblocks, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, 9, NF, EPI, 3, false, 1, 0, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr = true;
+    }
+    a.ks_region = (int)lds_half;
+    size_t lds = 2 * lds_half;
+    const size_t ex = (size_t)NF * 16 * 256 * 4;
+    if (lds < ex) lds = ex;
+    hipLaunchKernelGGL((conv_halo_kernel<DT, 9, NF, EPI, 3, false, 1, 0, false, false, 2>), dim3(nblocks), dim3(512), lds, s, a);
+}
+
 template <int DT, int NF, int NG>
 static void launch_halo_cat(const HaloArgs& a, size_t lds, int nblocks, hipStream_t s) {
     static bool attr = false;
@@ -951,7 +1016,9 @@ static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nbl
         if constexpr (NF == 3 && EPI != HEPI_F32) launch_halo<DT, 9, 3, EPI, 3, true, 3>(a, pl.lds, nblocks, s);
     } else if (pl.ng == 1) {
         if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
-        else launch_halo<DT, 9, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
+        else if (pl.ks == 2) {
+            if constexpr (NF == 5) launch_halo_ks2<DT, 5, EPI>(a, pl.lds, nblocks, s);
+        } else launch_halo<DT, 9, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
     } else if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 2>(a, pl.lds, nblocks, s);
     else if (pl.tri) {
         if constexpr (NF == 3 && EPI != HEPI_F32) launch_halo<DT, 9, 3, EPI, 2, true, 2>(a, pl.lds, nblocks, s);

@@ -53,7 +53,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("ng", [0, 1, 2, 3, 4, "wg3"])
+@pytest.mark.parametrize("ng", [0, 1, 2, 3, 4, "wg3", "ks1", "ks2"])
 @pytest.mark.parametrize("case", CASES)
 def test_tiled_conv_fwd_epilogue_stats(case, ng, monkeypatch):
     """ng: 0 = the library's own choice of tile (half tiles when 256-pixel tiles would under-fill the chip), 1 / 2 = pinned; 4 = the round-5
@@ -65,7 +65,11 @@ def test_tiled_conv_fwd_epilogue_stats(case, ng, monkeypatch):
     from cerberusdet_amd import _lib as L
 
     monkeypatch.delenv("CDET_HALO_WG3", raising=False)
-    if ng == "wg3":  # three workgroups per CU for the 96-cout patch form (conv_halo.hip: TRI); other geometries keep the library's choice
+    monkeypatch.delenv("CDET_HALO_KS", raising=False)
+    if ng in ("ks1", "ks2"):  # the half-tile form with its K loop as one chain / split inside the workgroup (conv_halo.hip: KS); other geometries unaffected
+        monkeypatch.setenv("CDET_HALO_KS", ng[2])
+        monkeypatch.setenv("CDET_HALO_NG", "1")
+    elif ng == "wg3":  # three workgroups per CU for the 96-cout patch form (conv_halo.hip: TRI); other geometries keep the library's choice
         monkeypatch.setenv("CDET_HALO_WG3", "1")
         monkeypatch.delenv("CDET_HALO_NG", raising=False)
     elif ng:
