@@ -1051,6 +1051,11 @@ bool pair_plan_ok(const cdet_conv_desc* d);
 int pair_launch(const cdet_conv_desc* d, const void* x, const void* w_tiled, const float* scale, const float* bias, const void* residual, void* y,
                 float* stats, hipStream_t s, const CatSrcs* cat = nullptr, const BnFold* fold = nullptr);
 
+// csrc/conv_pp.hip: the two-phase (ping-pong) 8-wave form of the 3x3 160-cout tile -- two pixel tiles share one weight ring
+bool pp_plan_ok(const cdet_conv_desc* d, int nf, int ng, bool patch, int XH);
+int pp_launch(const cdet_conv_desc* d, bool patch, int XH, int n_pblk, const void* x, const void* w_tiled, const float* scale, const float* bias,
+              const void* residual, void* y, float* stats, hipStream_t s);
+
 // host-side check + fill of a virtual-Concat source list against the convolution's descriptor
 static int cat_fill(const cdet_conv_desc* d, const cdet_cat_src* srcs, int n, CatSrcs* c) {
     if (!srcs || n < 1 || n > 3) return 0;
@@ -1189,6 +1194,15 @@ static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void*
         const int rc = pair_launch(d, x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream, cat, fold);
         CDET_LAUNCH_CHECK();
         return rc;
+    }
+    {
+        static int pp_mode = -1;  // CDET_CONV_PP=0: the 4-wave form everywhere (A/B timing; read once)
+        if (pp_mode < 0) pp_mode = getenv("CDET_CONV_PP") ? atoi(getenv("CDET_CONV_PP")) : 1;
+        if (pp_mode && !cat && !fold && !pl.tri && pl.ks == 1 && pp_plan_ok(d, pl.nf, pl.ng, pl.patch, pl.XH)) {
+            const int rc = pp_launch(d, pl.patch, pl.XH, halo_pixel_tiles(d, pl), x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream);
+            CDET_LAUNCH_CHECK();
+            return rc;
+        }
     }
     const int rb = pl.nf * 32;
     HaloArgs a;

@@ -36,6 +36,8 @@ ROOT = FILE.parents[1]
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+from cerberusdet_amd.utils.torch_utils import parse_device, select_device  # noqa: E402
+
 LOCAL_RANK = int(os.getenv("LOCAL_RANK", -1))
 RANK = int(os.getenv("RANK", -1))
 WORLD_SIZE = int(os.getenv("WORLD_SIZE", 1))
@@ -301,7 +303,14 @@ def save_training_checkpoint(path, model, trainer, epoch=-1, best_fitness=0.0, b
 
 
 def main(opt):
-    device = torch.device("cuda", max(LOCAL_RANK, 0))
+    # reference train.py:375-388: under a launcher the rank's GPU is LOCAL_RANK, otherwise `select_device(opt.device)`; --device cpu raises here
+    # (no CPU path) instead of silently training on a GPU
+    if LOCAL_RANK != -1:
+        parse_device(opt.device)  # (still refuses 'cpu' / malformed values)
+        assert torch.cuda.device_count() > LOCAL_RANK, "insufficient GPUs for the DDP command"
+        device = torch.device("cuda", LOCAL_RANK)
+    else:
+        device = select_device(opt.device)
     torch.cuda.set_device(device)
     if LOCAL_RANK != -1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -296,3 +296,36 @@ def test_pending_prediction_builds_the_reference_result_dicts():
                    [{"box": [5, 6, 7, 8], "score": 0.5, "label": 0, "label_name": "a", "task": "voc"}]]
     assert all(isinstance(v, int) for v in res[0][0]["box"]) and isinstance(res[0][0]["label"], int) and isinstance(res[0][0]["score"], float)
     assert p.result() is res and ev.waited == 1  # built once
+
+
+def test_train_entry_honours_device_and_refuses_cpu(monkeypatch):
+    """reference train.py:386-388 + utils/torch_utils.py:75-100: `--device` selects the GPU ('N', 'cuda:N', 'N,M'); 'cpu' would train on the
+    CPU there -- here it must raise instead of silently training on cuda:0 (BASELINE config 1's literal invocation)."""
+    from cerberusdet_amd import train as T
+    from cerberusdet_amd.utils import torch_utils as TU
+
+    assert TU.parse_device("") == 0 and TU.parse_device("cuda") == 0
+    assert TU.parse_device("3") == 3 and TU.parse_device("cuda:5") == 5 and TU.parse_device(" 2,3 ") == 2 and TU.parse_device(1) == 1
+    with pytest.raises(RuntimeError, match="not supported"):
+        TU.parse_device("cpu")
+    with pytest.raises(ValueError):
+        TU.parse_device("gpu0")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert TU.select_device("1") == torch.device("cuda", 1)
+    with pytest.raises(RuntimeError, match="only 2 GPU"):
+        TU.select_device("4")
+    # the entry point itself: refused before anything touches a GPU (with and without a launcher's LOCAL_RANK)
+    seen = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: seen.append(d))
+    monkeypatch.setattr(T, "train", lambda hyp, opt, device: seen.append(("train", device)) or "ok")
+    opt = T.parse_opt(True)
+    for lr in (-1, 0):
+        monkeypatch.setattr(T, "LOCAL_RANK", lr)
+        opt.device = "cpu"
+        with pytest.raises(RuntimeError, match="not supported"):
+            T.main(opt)
+    assert seen == []
+    monkeypatch.setattr(T, "LOCAL_RANK", -1)
+    opt.device = "1"
+    assert T.main(opt) == "ok"
+    assert seen == [torch.device("cuda", 1), ("train", torch.device("cuda", 1))]
