@@ -263,12 +263,17 @@ def nms_inputs(bs, nc, na, seed=7, dtype=torch.float16):
     return y.to(dtype)
 
 
-def north_star_forward(model, device, bs=32, imgsz=640, reps=40):
+def north_star_forward(model, device, bs=32, imgsz=640, reps=40, dtype=torch.bfloat16):
     """BASELINE.json north_star: YOLOv8x 2-task all-heads FORWARD at batch 32 @640 (eval form: BN folded into the conv epilogue,
     decode included), bf16 storage / fp32 accumulate, HIP-event timed on the launch stream in this process. Algorithmic work:
-    381.31 GFLOP per image (README.md:241 of the reference) -> fraction of the 2.5 PF/s dense bf16 MFMA peak."""
-    model.eval().bfloat16()
-    x = torch.rand(bs, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(3)).bfloat16().to(device)
+    381.31 GFLOP per image (README.md:241 of the reference) -> fraction of the 2.5 PF/s dense bf16 MFMA peak.
+    dtype = torch.float16 (`north_star_fwd_fp16`, round 6): the same protocol on the fp16 plans -- the reference's own inference dtype
+    (cerberusdet_inference.py:34-40 `model.half()`), three mantissa bits more than bf16 at the same MFMA rate: the plan on which BOTH halves of the
+    north star -- >= 40 % of the MFMA peak AND boxes within 1e-3 of the image scale of the full-precision forward -- can hold at once."""
+    name = "bf16" if dtype == torch.bfloat16 else "fp16"
+    model.eval()
+    model.bfloat16() if dtype == torch.bfloat16 else model.half()
+    x = torch.rand(bs, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(3)).to(dtype).to(device)
     with torch.no_grad():
         # steady state: after a few seconds of host-side work (the instrumented replay above) the GPU sits in a low clock state and
         # takes ~1 s of continuous load to ramp back up -- 3 warm-up forwards measured 16.2 ms where the same forward runs 14.0 ms
@@ -311,21 +316,24 @@ def north_star_forward(model, device, bs=32, imgsz=640, reps=40):
             model.full_precision()
             full = model(x[:2].contiguous())
             torch.cuda.synchronize()
+            px = max(float((keep[t][0][:, :4] - full[t][0][:, :4]).abs().max()) for t in full)
+            pr = max(float((keep[t][0][:, 4:] - full[t][0][:, 4:]).abs().max()) for t in full)
             vs_full = {
-                "images": 2,
+                "images": 2, "boxes_max_abs_over_image_size": float("%.3e" % (px / imgsz)),
+                "within_1e-3": bool(px / imgsz <= 1e-3 and pr <= 1e-3),  # north_star: boxes within 1e-3 rel (of the 640-pixel image scale), probabilities 1e-3 abs
                 "head_maps_rel_l2_max": float("%.3e" % max(float((a - b).norm() / b.norm()) for t in full for a, b in zip(keep[t][1], full[t][1]))),
                 "boxes_max_abs_px": float("%.3e" % max(float((keep[t][0][:, :4] - full[t][0][:, :4]).abs().max()) for t in full)),
                 "class_prob_max_abs": float("%.3e" % max(float((keep[t][0][:, 4:] - full[t][0][:, 4:]).abs().max()) for t in full)),
                 "note": "random-init weights after the timed training steps: the head maps are dominated by their biases (models/yolo.py bias_init)",
             }
             del full
-            model.bfloat16()  # (switching the compute dtype drops the cached plans, the full-precision one with its fp32 maps included)
+            model.bfloat16() if dtype == torch.bfloat16 else model.half()  # (switching the compute dtype drops the cached plans, the full-precision one included)
     tf = bs * 381.31e9 * (imgsz / 640) ** 2 / (ms * 1e-3) / 1e12
     model.train()
     return {"ms": round(ms, 3), "tflops": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "images_per_sec": round(bs / ms * 1e3, 1),
-            "config": f"YOLOv8x 2-task all-heads forward + decode, eval form (BN folded), bf16, batch {bs} @{imgsz}; default model(x) call (fresh output tensors)",
+            "config": f"YOLOv8x 2-task all-heads forward + decode, eval form (BN folded), {name}, batch {bs} @{imgsz}; default model(x) call (fresh output tensors)",
             "ms_with_fresh_output_tensors": round(ms, 3), "ms_zero_copy": round(ms_zc, 3),
-            "outputs_finite": finite, "fresh_equals_zero_copy": same, "y_checksum": checksum, "bf16_vs_full_precision": vs_full,
+            "outputs_finite": finite, "fresh_equals_zero_copy": same, "y_checksum": checksum, f"{name}_vs_full_precision": vs_full,
             "gflop_per_image": 381.31, "timing": f"HIP events around {reps} back-to-back forwards on the launch stream after {n_w} warm-up forwards (>= 1 s)"}
 
 
@@ -591,6 +599,37 @@ def dry_comm(args, virtual_ranks=3, batch=2, imgsz=128):
     return out
 
 
+def stub_ranks(args, rank, world, emit):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    mode = os.environ["CDET_BENCH_STUB"]
+    if mode == "fail" and rank == world - 1:
+        sys.exit(3)  # a rank that dies: the launcher's exit code has to reach the caller of `bench.py --gpus N`
+
+    def step():
+        time.sleep(0.002)
+        t = torch.ones(4) * (rank + 1)
+        dist.all_reduce(t)  # the stand-in's one exchange
+        return float(t[0])
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s_ = step()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        emit({"metric": "images/sec train @640 YOLOv8x 2-task", "stub": True, "value": round(args.batch * len(TASKS) * world * args.steps / float(tt), 2),
+              "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tt) / args.steps * 1e3, 3),
+              "scaling": "weak", "sum_of_ranks": s_, "argv": sys.argv[1:], "master_port": os.environ.get("MASTER_PORT")})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -643,6 +682,10 @@ def main():
         sys.exit(subprocess.run(cmd, env=env).returncode)
     if args.gpus != world:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if os.environ.get("CDET_BENCH_STUB"):
+        # tests/test_distributed_cpu.py: the launcher path without a GPU -- the ranks rendezvous over gloo and run the SAME timing protocol
+        # (warm-up, barrier, K steps, barrier, MAX over ranks, rank 0 prints the one JSON line) around a stand-in step. Not a measurement.
+        return stub_ranks(args, rank, world, emit)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("CDET_REDUCE_ALWAYS") == "1"
@@ -687,6 +730,11 @@ def main():
     for i in range(args.warmup):
         items = trainer.train_step(data[i % n_distinct], n_max=n_max, defer_tail=defer)
     sync()
+    comm_timer = None
+    if use_dist:  # where the compute streams wait for communication (event pairs; trainers/averaging.py::CommTimer) -- read after the timed region
+        from cerberusdet_amd.trainers.averaging import CommTimer
+
+        comm_timer = model._comm_timer = CommTimer()
     t0 = time.perf_counter()
     for i in range(args.steps):
         items = trainer.train_step(data[(args.warmup + i) % n_distinct], n_max=n_max, defer_tail=defer)
@@ -697,6 +745,16 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    comm_exposed = None
+    if comm_timer is not None:
+        c = comm_timer.collect()
+        model._comm_timer = None
+        n_sp = int(c.pop("n_spans", 0))
+        comm_exposed = {k: round(v / args.steps, 3) for k, v in c.items()}
+        comm_exposed["total"] = round(sum(c.values()) / args.steps, 3)
+        comm_exposed["spans_per_step"] = round(n_sp / args.steps, 1)
+        comm_exposed["what"] = ("ms per iteration (this rank) a compute stream spent waiting for communication: grad_wait = the join on the gradient all-reduce "
+                                "handles in front of the optimizer step, syncbn = the SyncBatchNorm statistics collectives (on their layer's dependent chain)")
     loss_items = {t: [round(float(v), 5) for v in items[t].tolist()] for t in TASKS}
     finite = all(np.isfinite(v).all() for v in loss_items.values())
 
@@ -721,6 +779,16 @@ def main():
             "step_tflop_per_gpu": round(step_tflop, 2), "achieved_tflops_per_gpu": round(step_tflop / (ms_per_step / 1e3), 1),
             "loss_items": loss_items, "loss_finite": bool(finite),
         }
+        if comm_exposed is not None:
+            out["comm_exposed_ms"] = comm_exposed
+        try:
+            from cerberusdet_amd import _lib as _L
+
+            out["switches"] = _L.active_switches()  # every library switch off its default + the build flavour ("" = the product configuration)
+            st = trainer.scaler_state()
+            out["grad_scaler"] = {"scale": st["scale"], "skipped_steps": st["skipped_steps"]}
+        except Exception as e:  # noqa: BLE001
+            out["switches"] = f"unavailable: {e}"
         if not args.no_breakdown:
             agg = agg_all if agg_all is not None else kernel_breakdown(trainer, data[0], n_max)
             tot = sum(a["ms"] for a in agg.values())
@@ -764,6 +832,8 @@ def main():
                                    for k, v in agg.items() if v["flops"] > 0}
         if not args.no_infer and world == 1:
             out["north_star_fwd"] = north_star_forward(model, device, bs=args.batch, imgsz=args.imgsz)
+            out["north_star_fwd_fp16"] = north_star_forward(model, device, bs=args.batch, imgsz=args.imgsz, dtype=torch.float16)
+            model.bfloat16()
             out["inference"] = inference_section(model, device)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would just wait at the barrier
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -42,7 +42,7 @@ BN_FOLD_TICKET_WORDS = 8 * (1 + 128)
 class LossDesc(C.Structure):
     _fields_ = [("N", i32), ("nc", i32), ("n_max", i32), ("hw", i32 * 6), ("stride", f32 * 3), ("gain_box", f32),
                 ("gain_cls", f32), ("gain_dfl", f32), ("grad_scale", f32), ("dtype", i32), ("grad_dtype", i32),
-                ("f_ld", i32), ("topk", i32), ("alpha", f32), ("beta", f32)]
+                ("f_ld", i32), ("topk", i32), ("alpha", f32), ("beta", f32), ("grad_scale_dev", vp)]
 
 
 class NmsDesc(C.Structure):
@@ -100,6 +100,10 @@ _SIGS = {
     "cdet_version": (i32, []),
     "cdet_last_error": (C.c_char_p, []),
     "cdet_device_info": (i32, [C.POINTER(i32)]),
+    "cdet_set_switch": (i32, [C.c_char_p, i32]),
+    "cdet_get_switch": (i32, [C.c_char_p, C.POINTER(i32)]),
+    "cdet_active_switches": (i32, [C.c_char_p, i32]),
+    "cdet_has_experiments": (i32, []),
     "cdet_conv2d_stat_blocks": (i32, [C.POINTER(ConvDesc)]),
     "cdet_conv2d": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
     "cdet_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
@@ -181,9 +185,10 @@ _SIGS = {
     "cdet_peer_import": (i32, [vp, C.POINTER(vp)]),
     "cdet_peer_close": (i32, [vp]),
     "cdet_peer_allreduce": (i32, [vp, i32, vp, i32, i32, i64, i64, C.c_uint32, vp, i32, vp]),
-    "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp]),
+    "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp, vp]),
     "cdet_accumulate_clear": (i32, [vp, vp, i64, vp]),
-    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, C.POINTER(f32), i32, f32, f32, vp]),
+    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, C.POINTER(f32), i32, f32, f32, vp, vp]),
+    "cdet_scaler_update": (i32, [vp, vp, f32, f32, i32, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
@@ -233,3 +238,46 @@ def check(code, what=""):
 
 def is_built() -> bool:
     return LIB_PATH.exists()
+
+
+SWITCH_DEFAULT = -2147483648
+
+
+def set_switch(name: str, value=None) -> None:
+    """Pin a kernel-form switch of the library (csrc/switches.h; `name` = "conv_pp" or "CDET_CONV_PP"); None restores the default. The library
+    reads its CDET_* environment ONCE at load -- tests and A/B tools that compare two forms inside one process go through here."""
+    check(load().cdet_set_switch(name.encode(), SWITCH_DEFAULT if value is None else int(value)), "cdet_set_switch")
+
+
+def get_switch(name: str):
+    v = i32(0)
+    check(load().cdet_get_switch(name.encode(), C.byref(v)), "cdet_get_switch")
+    return None if v.value == SWITCH_DEFAULT else v.value
+
+
+def active_switches() -> str:
+    buf = C.create_string_buffer(1024)
+    load().cdet_active_switches(buf, 1024)
+    return buf.value.decode()
+
+
+class switches:
+    """Context manager: `with _lib.switches(conv_pp=0, halo_ng=1): ...` pins switches for the block and restores what was there before."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_switch(k)
+            set_switch(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:  # (was "not pinned": restoring the DEFAULT is the same thing only for switches whose default is auto)
+                load().cdet_set_switch(k.encode(), SWITCH_DEFAULT)
+            else:
+                set_switch(k, v)
+        return False

@@ -19,6 +19,15 @@
 #pragma once
 #include "common.h"
 
+// The in-launch reduction lost its A/B (profiles/r05_bn_fold_ab.txt: -2.6 % on the training step) and is kept for the record only: its code is
+// compiled into the kernels of -DCDET_EXPERIMENTS builds; in the product build CDET_FOLD() is `false`, the branches fold away and the entry
+// points that take a descriptor refuse it.
+#ifdef CDET_EXPERIMENTS
+#define CDET_FOLD(p) ((p) != nullptr)
+#else
+#define CDET_FOLD(p) false
+#endif
+
 namespace cdet {
 
 constexpr int BNF_CL = 32;           // rows per cluster

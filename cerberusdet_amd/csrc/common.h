@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include "../../include/cerberus_hip.h"
+#include "switches.h"
 
 namespace cdet {
 

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((P
                 sv += stl[(m * 2 + 0) * HC + t];
                 qv += stl[(m * 2 + 1) * HC + t];
             }
-            if (a.fold != nullptr) {  // write-through (sc1) stores: the workgroup that draws the last ticket reads them from any XCD
+            if (CDET_FOLD(a.fold)) {  // write-through (sc1) stores: the workgroup that draws the last ticket reads them from any XCD
                 const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(a.stats);
                 bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 0) * a.Cd + c0 + t) * 4), sv);
                 bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 1) * a.Cd + c0 + t) * 4), qv);
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((P
                 a.stats[((int64_t)pblk * 2 + 1) * a.Cd + c0 + t] = qv;
             }
         }
-        if (a.fold != nullptr) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem), 256);
+        if (CDET_FOLD(a.fold)) bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem), 256);
     }
 #ifdef CDET_PROFILING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((P
 // ------------------------------------------------------------------------------------------------------------------------------------
 // (CDET_RB160_AS_96, experiment builds only: 160-row operands as two 96-row blocks -- the 174-179-VGPR instantiation instead of the 251-VGPR one, so that
 //  a BatchNorm wave of the other task's pass fits beside two convolution workgroups on a SIMD; profiles/r05_bn_beside_conv.txt)
-#ifdef CDET_RB160_AS_96
+#if defined(CDET_EXPERIMENTS) && defined(CDET_RB160_AS_96)
 static __host__ __device__ __forceinline__ int row_block(int rows) { return (rows <= 96 || rows == 160) ? 96 : 160; }
 #else
 static __host__ __device__ __forceinline__ int row_block(int rows) { return rows <= 96 ? 96 : 160; }
@@ -853,11 +853,13 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
     // half tiles (128 pixels, one 32-pixel fragment per wave) when 256-pixel tiles would not even give every CU one workgroup
     pl.ng = (div_up(M, HP) * div_up(d->Cd, rb) < 256 && M > 128) ? 1 : 2;
-    if (const char* e = getenv("CDET_HALO_NG")) {  // CDET_HALO_NG=1|2|4 pins the tile size (tests cover the forms on the same shapes; A/B timing)
-        const int force = atoi(e);
+    if (sw_is(SW_HALO_NG)) {  // halo_ng = 1 | 2 pins the tile size (tests cover the forms on the same shapes; A/B timing)
+        const int force = sw(SW_HALO_NG);
         if (force == 1 || force == 2) pl.ng = force;
-        // the 512-pixel tile (one workgroup per CU): 3x3, 160-cout blocks, 16-bit output, linear halo (maps up to 95 wide)
+#ifdef CDET_EXPERIMENTS
+        // the 512-pixel tile (one workgroup per CU): 3x3, 160-cout blocks, 16-bit output, linear halo (maps up to 95 wide) -- 9-14 % slower, kept for the record
         if (force == 4 && d->kh == 3 && rb == 160 && d->out_dtype != CDET_F32 && d->Ws <= 95) pl.ng = 4;
+#endif
     }
     pl.hp = 128 * pl.ng;
     if (d->kh == 1) {
@@ -875,7 +877,8 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
         // CDET_HALO_NG=3 (round-5 experiment, opt-in): the 96-cout tile on tall maps as 24-row x 16-column patches (384 pixels) when at most 6 % of
         // the patch rows hang over the bottom edge (160 = 6 x 24 + 16: 5 %). Measured on 160 x 160 80 -> 80: 0.1381 against 0.1372 ms -- a third less
         // weight LDS-DMA, a fifth fewer fragment reads and barriers per MFMA buy NOTHING there (profiles/r05_halo_ng4.txt, section 3)
-        if (pl.patch && pl.nf == 3 && d->out_dtype != CDET_F32 && getenv("CDET_HALO_NG") && atoi(getenv("CDET_HALO_NG")) == 3) {
+#ifdef CDET_EXPERIMENTS
+        if (pl.patch && pl.nf == 3 && d->out_dtype != CDET_F32 && sw(SW_HALO_NG) == 3) {
             const int rows3 = div_up(d->Hs, 24) * 24;
             if ((rows3 - d->Hs) * 100 <= 6 * d->Hs) {
                 pl.ng = 3;
@@ -883,12 +886,12 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
                 pl.XH = (26 * PATCH_HPW + 15) / 16 * 16;  // 480
             }
         }
+#endif
         if (pl.XH > 16 * 4 * MAXXP * (pl.ng >= 3 ? 2 : 1)) return pl;
         // three workgroups per CU for the 96-cout 16 x 16 patch form (see TRI in the kernel) when the grid holds at least three full rounds of them
         // (160 x 160 80 -> 80 at batch 32: 3 200 workgroups, 0.142 -> 0.131 ms; 80 x 80 80 -> 80 with 800 loses 6 % and keeps two).
         // CDET_HALO_WG3=1 forces the form (tests), 0 disables it
-        const char* w3 = getenv("CDET_HALO_WG3");
-        const int w3v = w3 ? atoi(w3) : -1;
+        const int w3v = sw_is(SW_HALO_WG3) ? sw(SW_HALO_WG3) : -1;
         const int64_t tiles = (int64_t)d->N * (d->Hs / PATCH_W) * (d->Ws / PATCH_W) * div_up(d->Cd, rb);
         if (pl.patch && pl.ng == 2 && pl.nf == 3 && d->out_dtype != CDET_F32 && (w3v == 1 || (w3v < 0 && tiles >= 3 * 768))) {
             pl.tri = true;
@@ -916,10 +919,9 @@ static HaloPlan halo_plan(const cdet_conv_desc* d) {
     // 640 -> 320 57.5 -> 51.6; a 400-workgroup grid loses 7 %). CDET_HALO_KS=1 keeps the one-chain form, =2 forces the split (tests)
     pl.ks = 1;
     {
-        const char* e = getenv("CDET_HALO_KS");
         const int nchunk = div_up(d->Cs, 32);
         const int64_t nblk = (int64_t)div_up(M, pl.hp) * div_up(d->Cd, rb);
-        const int ev = e ? atoi(e) : 0;
+        const int ev = sw_is(SW_HALO_KS) ? sw(SW_HALO_KS) : 0;
         if (ev != 1 && (ev == 2 || nblk <= 256) && pl.ng == 1 && d->kh == 3 && pl.nf == 5 && pl.nsw == 3 && !pl.patch && d->Cs % 32 == 0 && nchunk >= 4 &&
             nchunk % 2 == 0 && 2 * pl.lds <= 160 * 1024)
             pl.ks = 2;
@@ -1010,11 +1012,17 @@ static void dispatch_halo_cat(const HaloArgs& a, const HaloPlan& pl, int nblocks
 
 template <int DT, int NF, int EPI>
 static void dispatch_halo2(const HaloArgs& a, int k, const HaloPlan& pl, int nblocks, hipStream_t s) {
+#ifdef CDET_EXPERIMENTS
     if (pl.ng == 4) {
         if constexpr (NF == 5 && EPI != HEPI_F32) launch_halo<DT, 9, 5, EPI, 6, false, 4>(a, pl.lds, nblocks, s);
-    } else if (pl.ng == 3) {
+        return;
+    }
+    if (pl.ng == 3) {
         if constexpr (NF == 3 && EPI != HEPI_F32) launch_halo<DT, 9, 3, EPI, 3, true, 3>(a, pl.lds, nblocks, s);
-    } else if (pl.ng == 1) {
+        return;
+    }
+#endif
+    if (pl.ng == 1) {
         if (k == 1) launch_halo<DT, 1, NF, EPI, 3, false, 1>(a, pl.lds, nblocks, s);
         else if (pl.ks == 2) {
             if constexpr (NF == 5) launch_halo_ks2<DT, 5, EPI>(a, pl.lds, nblocks, s);
@@ -1168,11 +1176,17 @@ extern "C" int cdet_conv2d_tiled(const cdet_conv_desc* d, const void* x, const v
 extern "C" int cdet_conv2d_tiled_bn(const cdet_conv_desc* d, const void* x, const void* w_tiled, void* y, float* stats, const cdet_bn_fold* fold_dev,
                                     void* stream) {
     CDET_CHECK_ARG(stats, "cdet_conv2d_tiled_bn: the partial-sum rows are needed with or without the fold");
+#ifndef CDET_EXPERIMENTS
+    CDET_CHECK_ARG(!fold_dev, "cdet_conv2d_tiled_bn: the in-launch BatchNorm fold is compiled into -DCDET_EXPERIMENTS builds only (cdet_has_experiments())");
+#endif
     CDET_CHECK_ARG(!fold_dev || cdet_conv2d_tiled_bn_ok(d), "cdet_conv2d_tiled_bn: this launch has more partial rows / column blocks than the fold takes");
     return conv2d_tiled_impl(d, x, w_tiled, nullptr, nullptr, nullptr, y, stats, stream, nullptr, fold_dev);
 }
 
 extern "C" int cdet_conv2d_tiled_bn_ok(const cdet_conv_desc* d) {
+#ifndef CDET_EXPERIMENTS
+    return 0;  // (the in-launch BatchNorm fold is an experiment build's: bn_fold.h)
+#endif
     if (!d || !cdet_conv2d_tiled_ok(d) || d->out_dtype == CDET_F32) return 0;
     const HaloPlan pl = halo_plan(d);
     if (!pl.ok) return 0;
@@ -1196,9 +1210,11 @@ static int conv2d_tiled_impl(const cdet_conv_desc* d, const void* x, const void*
         return rc;
     }
     {
-        static int pp_mode = -1;  // CDET_CONV_PP=0: the 4-wave form everywhere (A/B timing; read once)
-        if (pp_mode < 0) pp_mode = getenv("CDET_CONV_PP") ? atoi(getenv("CDET_CONV_PP")) : 1;
-        if (pp_mode && !cat && !fold && !pl.tri && pl.ks == 1 && pp_plan_ok(d, pl.nf, pl.ng, pl.patch, pl.XH)) {
+        const int pp_mode = sw(SW_CONV_PP);
+        // mode 1: launches whose pair grid is a single round (one 8-wave workgroup per CU at most: the 40 x 40 layers at batch 32); a multi-round launch
+        // of the 4-wave form hides prologues / epilogues behind its other workgroup's K loop, the one-workgroup-per-CU form cannot. 2: wherever it fits
+        const int n_pair_wg = (halo_pixel_tiles(d, pl) + 1) / 2 * div_up(d->Cd, 160);
+        if (pp_mode && (pp_mode == 2 || n_pair_wg <= 256) && !cat && !fold && !pl.tri && pl.ks == 1 && pp_plan_ok(d, pl.nf, pl.ng, pl.patch, pl.XH)) {
             const int rc = pp_launch(d, pl.patch, pl.XH, halo_pixel_tiles(d, pl), x, w_tiled, scale, bias, residual, y, stats, (hipStream_t)stream);
             CDET_LAUNCH_CHECK();
             return rc;

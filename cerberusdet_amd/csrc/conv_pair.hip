@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
                     sv += stl[((cbh * 4 + m) * 2 + 0) * HC + c];
                     qv += stl[((cbh * 4 + m) * 2 + 1) * HC + c];
                 }
-                if (a.fold != nullptr) {
+                if (CDET_FOLD(a.fold)) {
                     const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(a.stats);
                     bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 0) * a.Cd + co) * 4), sv);
                     bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 1) * a.Cd + co) * 4), qv);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
     }
     // train form with the statistics finished in this launch (bn_fold.h): the workgroup's row share (both cout blocks: 2 HC columns) went out with
     // write-through stores above; tickets at the very end, when the staging LDS is free
-    if (EPI == HEPI_RAW && a.stats != nullptr && a.fold != nullptr)
+    if (EPI == HEPI_RAW && a.stats != nullptr && CDET_FOLD(a.fold))
         bn_fold_finish<true>(a.fold, a.stats, pblk, pair * 2 * HC, 2 * HC, pair, reinterpret_cast<volatile int*>(smem));
 }
 
@@ -374,7 +374,7 @@ static void launch_pair(const PairArgs& a, size_t lds, int nblocks, hipStream_t 
 
 // 1x1, stride 1, 16-bit in == out, an even number (>= 2) of 160-cout blocks, enough pixel tiles to give every CU a workgroup
 bool pair_plan_ok(const cdet_conv_desc* d) {
-    const int mode = getenv("CDET_CONV_PAIR") ? atoi(getenv("CDET_CONV_PAIR")) : 1;  // 0: never (A/B timing), 2: whenever the geometry allows (tests)
+    const int mode = sw(SW_CONV_PAIR);  // 0: never (A/B timing), 2: whenever the geometry allows (tests)
     if (mode == 0) return false;
     if (!(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0)) return false;
     if (d->Cd < 320) return false;

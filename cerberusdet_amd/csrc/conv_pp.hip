@@ -61,8 +61,11 @@ constexpr int PP_STAGE_OFF = 6912;    // (= HEPI_STAGE_OFF)
 __device__ unsigned long long* g_pp_dbg = nullptr;
 #endif
 
-template <int DT, int EPI, bool PATCH>
+// ABL (timing experiments, -DCDET_PROFILING builds only): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 32 = per-phase s_memtime stamps
+// (tools/pp_timeline.py; the stamps themselves stretch every phase -- read them as proportions)
+template <int DT, int EPI, bool PATCH, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
+    constexpr bool TL = (ABL & 32) != 0;
     constexpr int NF = 5, NG = 2;
     constexpr int HC = NF * 32;           // couts per block
     constexpr int WTILE = HC * HROW;      // 10240 bytes per (cblk, chunk, tap) weight tile
@@ -109,7 +112,11 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
     if (tid < 16) reinterpret_cast<uint32_t*>(smem)[tid] = 0u;  // zero row (visible after the first barrier)
 #ifdef CDET_PROFILING
     unsigned long long tp_start = 0, tp_loop = 0, tp_epi = 0, tp_mb = 0, tp_m = 0, tp_c = 0;
-    if (g_pp_dbg != nullptr && tid == 0) tp_start = __builtin_readcyclecounter();
+    unsigned long long tr_start = 0;  // s_memrealtime: 100 MHz, one counter for the whole chip (s_memtime counters differ between XCCs)
+    if (g_pp_dbg != nullptr && tid == 0) {
+        tp_start = __builtin_readcyclecounter();
+        tr_start = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
 
     // ---- pixel DMA pieces of this wave: piece id 4*i + wave covers halo rows 16*id .. 16*id+15, 4 lanes (64 B) per row ---------------------------
@@ -231,7 +238,10 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
     };
     // fragment i of a k16 half: i < NG -> pixel rows (B operand), else weight rows (A operand); read order = use order
     auto frag = [&](const unsigned char* ws_, const int (&bo)[NG], int s_, int i, u32x4 (&af)[NF], u32x4 (&bf)[NG]) {
-        if (i < NG) bf[i] = *reinterpret_cast<const u32x4*>(smem + (bo[i] ^ (s_ << 5)));
+        if (ABL & 2) {
+            if (i < NG) bf[i] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+            else af[i - NG] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+        } else if (i < NG) bf[i] = *reinterpret_cast<const u32x4*>(smem + (bo[i] ^ (s_ << 5)));
         else af[i - NG] = *reinterpret_cast<const u32x4*>(ws_ + ((aoff0 ^ (s_ << 5)) + (i - NG) * 32 * HROW));
     };
 
@@ -262,20 +272,24 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) frag(ws, bo_cur, 1, i, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        if (u < MAXXP) {
-            if (xa) dma_x(u, chunk + 1, (chunk + 1) & 1);
+        if (!(ABL & 1)) {
+            if (u < MAXXP) {
+                if (xa) dma_x(u, chunk + 1, (chunk + 1) & 1);
+            }
+            dma_w(st + 2, (u + 2) % 3);
         }
-        dma_w(st + 2, (u + 2) % 3);
         __builtin_amdgcn_sched_barrier(0);
         b_offsets(HZERO + grp * 2 * XHB + xbn * XHB, tapn, bo_nxt);
         __builtin_amdgcn_sched_barrier(0);
         // everything issued before this phase has landed: T(st+1) (both groups wait for their shares one barrier before anyone reads the tile) and the
         // pixel pieces of earlier phases; this phase's two weight pieces and its pixel piece stay in flight
-        if (xa) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (!(ABL & 1)) {
+            if (xa) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
 #ifdef CDET_PROFILING
         unsigned long long tq = 0;
-        if (g_pp_dbg != nullptr && tid == 0) {
+        if (TL && g_pp_dbg != nullptr && tid == 0) {
             tq = __builtin_readcyclecounter();
             tp_mb += tq - tp_prev;
         }
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #ifdef CDET_PROFILING
-        if (g_pp_dbg != nullptr && tid == 0) {
+        if (TL && g_pp_dbg != nullptr && tid == 0) {
             tq = __builtin_readcyclecounter();
             tp_m += tq - tp_prev;
             tp_prev = tq;
@@ -291,10 +305,17 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
 #endif
         // ---- compute phase ----
         __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 4)) {
 #pragma unroll
-        for (int i = 0; i < NM; ++i) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
+            for (int i = 0; i < NM; ++i) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
 #pragma unroll
-        for (int i = 0; i < NM; ++i) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+            for (int i = 0; i < NM; ++i) mfma32<DT>(a1[i / NG], b1[i % NG], acc[i / NG][i % NG]);
+        } else {  // keep the fragments alive (and their waits in place)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) asm volatile("" ::"v"(a0[i]), "v"(a1[i]));
+#pragma unroll
+            for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(b0[i]), "v"(b1[i]));
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (!last) {
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef CDET_PROFILING
-        if (g_pp_dbg != nullptr && tid == 0) {
+        if (TL && g_pp_dbg != nullptr && tid == 0) {
             tq = __builtin_readcyclecounter();
             tp_c += tq - tp_prev;
             tp_prev = tq;
@@ -455,7 +476,11 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long* o = g_pp_dbg + (size_t)blockIdx.x * 8;
         o[0] = tp_start; o[1] = tp_loop; o[2] = tp_epi; o[3] = __builtin_readcyclecounter();
-        o[4] = tp_mb; o[5] = tp_m; o[6] = tp_c;
+        if (TL) {
+            o[4] = tp_mb; o[5] = tp_m; o[6] = tp_c;
+        } else {
+            o[4] = tr_start; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = 0;
+        }
         o[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
     }
 #endif
@@ -468,6 +493,26 @@ static void launch_pp(const PpArgs& a, size_t lds, int nblocks, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)conv_pp_kernel<DT, EPI, PATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
+#ifdef CDET_PROFILING
+    static int abl = -1;
+    if (abl < 0) {
+        const char* e = getenv("CDET_PP_ABLATE");
+        abl = e ? atoi(e) : 0;
+        if (abl & ~32) fprintf(stderr, "[cdet] CDET_PP_ABLATE=%d: conv results are WRONG by design (timing experiment)\n", abl);
+    }
+    if constexpr (DT == CDET_BF16 && EPI == HEPI_FULL && !PATCH) {
+#define CDET_PPABL(N)                                                                                                                       \
+    case N:                                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)conv_pp_kernel<DT, EPI, PATCH, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+        hipLaunchKernelGGL((conv_pp_kernel<DT, EPI, PATCH, N>), dim3(nblocks), dim3(512), lds, s, a);                                        \
+        return;
+        switch (abl) {
+            CDET_PPABL(1) CDET_PPABL(2) CDET_PPABL(3) CDET_PPABL(4) CDET_PPABL(5) CDET_PPABL(6) CDET_PPABL(7) CDET_PPABL(32)
+            default: break;
+        }
+#undef CDET_PPABL
+    }
+#endif
     hipLaunchKernelGGL((conv_pp_kernel<DT, EPI, PATCH>), dim3(nblocks), dim3(512), lds, s, a);
 }
 

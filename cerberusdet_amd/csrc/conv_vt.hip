@@ -422,7 +422,7 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
                 sv += stl[(m * 2 + 0) * HC + t];
                 qv += stl[(m * 2 + 1) * HC + t];
             }
-            if (a.fold != nullptr) {
+            if (CDET_FOLD(a.fold)) {
                 const __amdgpu_buffer_rsrc_t rs_ = bnf_rsrc(a.stats);
                 bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 0) * a.Cd + c0 + t) * 4), sv);
                 bnf_stf(rs_, (unsigned)((((int64_t)pblk * 2 + 1) * a.Cd + c0 + t) * 4), qv);
@@ -529,7 +529,7 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
         __builtin_amdgcn_wave_barrier();
     }
     // train form with the statistics finished in this launch (bn_fold.h); tickets at the very end, when the staging LDS is free
-    if (FWD && EPI == HEPI_RAW && a.stats != nullptr && a.fold != nullptr)
+    if (FWD && EPI == HEPI_RAW && a.stats != nullptr && CDET_FOLD(a.fold))
         bn_fold_finish<true>(a.fold, a.stats, pblk, c0, HC, cblk, reinterpret_cast<volatile int*>(smem));
 }
 
@@ -568,7 +568,7 @@ struct VtPlan {
     size_t lds;
 };
 
-#ifdef CDET_RB160_AS_96
+#if defined(CDET_EXPERIMENTS) && defined(CDET_RB160_AS_96)
 static int vt_row_block(int rows) { return (rows <= 96 || rows == 160) ? 96 : 160; }  // (experiment builds only: see conv_halo.hip::row_block)
 #else
 static int vt_row_block(int rows) { return rows <= 96 ? 96 : 160; }
@@ -725,6 +725,9 @@ static int s2_tiled_impl(const cdet_conv_desc* d, const void* x, const void* w_t
 }
 
 extern "C" int cdet_conv2d_s2_tiled_bn_ok(const cdet_conv_desc* d) {
+#ifndef CDET_EXPERIMENTS
+    return 0;  // (the in-launch BatchNorm fold is an experiment build's: bn_fold.h)
+#endif
     if (!d || !cdet_conv2d_s2_tiled_ok(d) || d->out_dtype == CDET_F32 || d->mode != CDET_CONV_FWD) return 0;
     const VtPlan pl = vt_plan(d, false);
     return pl.ok && cdet_conv2d_s2_tiled_stat_blocks(d) <= BNF_CL * BNF_MAX_CL && div_up(d->Cd, pl.nf * 32) <= BNF_MAX_CB;
@@ -734,6 +737,9 @@ extern "C" int cdet_conv2d_s2_tiled_bn_ok(const cdet_conv_desc* d) {
 extern "C" int cdet_conv2d_s2_tiled_bn(const cdet_conv_desc* d, const void* x, const void* w_tiled, void* y, float* stats, const cdet_bn_fold* fold_dev,
                                        void* stream) {
     CDET_CHECK_ARG(stats, "cdet_conv2d_s2_tiled_bn: the partial-sum rows are needed with or without the fold");
+#ifndef CDET_EXPERIMENTS
+    CDET_CHECK_ARG(!fold_dev, "cdet_conv2d_s2_tiled_bn: the in-launch BatchNorm fold is compiled into -DCDET_EXPERIMENTS builds only (cdet_has_experiments())");
+#endif
     CDET_CHECK_ARG(!fold_dev || cdet_conv2d_s2_tiled_bn_ok(d), "cdet_conv2d_s2_tiled_bn: this launch has more partial rows / column blocks than the fold takes");
     return s2_tiled_impl(d, x, w_tiled, nullptr, nullptr, nullptr, y, stats, stream, fold_dev);
 }

@@ -520,15 +520,15 @@ bool wgrad_halo_plan(const cdet_conv_desc* d, WgradHaloPlan* out, int n_items) {
     if (d->Cs * 10 < (d->Cs + 31) / 32 * 32 * 7) return false;  // last cin tile more than 30 % empty
     if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
     int force_nci = 0;
-    if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel (the tests compare the two); 4: 64-cin tile where it fits
-        force_nci = atoi(e);
+    if (sw_is(SW_WGRAD_HALO)) {  // 0: im2col kernel (the tests compare the two); 4: 64-cin tile where it fits
+        force_nci = sw(SW_WGRAD_HALO);
         if (force_nci == 0) return false;
     }
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;
     // maps that split into 8 x 16 patches: the patch form of the 32-cin tiles (four / three stage buffers; CDET_WGRAD_PATCH=0 keeps the linear
     // form -- the tests compare the two; 1: the 80-cout tile only)
     bool patch = force_nci != 4 && d->Hs % 8 == 0 && d->Ws % 16 == 0;
-    if (const char* e = getenv("CDET_WGRAD_PATCH")) patch = patch && atoi(e) != 0 && (narrow || atoi(e) != 1);
+    if (sw_is(SW_WGRAD_PATCH)) patch = patch && sw(SW_WGRAD_PATCH) != 0 && (narrow || sw(SW_WGRAD_PATCH) != 1);
     const int XH = patch ? 192 : (WH_P + 2 * (d->Ws + 1) + 31) / 32 * 32;
     auto lds_of = [&](int nci) {
         return patch ? (narrow ? 4 * (size_t)(8 * 3072 + nci * XH * 32) : 3 * (size_t)(WH_DYB + nci * XH * 32))
@@ -629,9 +629,9 @@ bool wgrad_gemm_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     if (d->Cs % 16 != 0 || d->Cd < 128) return false;
     if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
     bool wide_only = true;
-    if (const char* e = getenv("CDET_WGRAD_HALO")) {  // 0: im2col kernel everywhere; 3: this kernel for every Cout >= 128 (tests)
-        if (atoi(e) == 0) return false;
-        wide_only = atoi(e) != 3;
+    if (sw_is(SW_WGRAD_HALO)) {  // 0: im2col kernel everywhere; 3: this kernel for every Cout >= 128 (tests)
+        if (sw(SW_WGRAD_HALO) == 0) return false;
+        wide_only = sw(SW_WGRAD_HALO) != 3;
     }
     if (wide_only && d->Cd <= 320) return false;
     const int64_t M = (int64_t)d->N * d->Hs * d->Ws;

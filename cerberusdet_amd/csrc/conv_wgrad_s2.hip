@@ -257,8 +257,7 @@ bool wgrad_s2_plan(const cdet_conv_desc* d, WgradHaloPlan* out) {
     if (d->Cs % 16 != 0 || d->Cd < 128) return false;
     if (d->Cs * 10 < (d->Cs + 31) / 32 * 32 * 7) return false;  // last cin tile more than 30 % empty
     if (!(d->dtype == CDET_BF16 || d->dtype == CDET_F16)) return false;
-    if (const char* e = getenv("CDET_WGRAD_S2"))  // 0: im2col kernel (the tests compare the two)
-        if (atoi(e) == 0) return false;
+    if (sw(SW_WGRAD_S2) == 0) return false;  // 0: im2col kernel (the tests compare the two)
     const int ty = div_up(d->Hd, 8), tx = div_up(d->Wd, 16);
     if ((int64_t)d->Hd * d->Wd * 4 < (int64_t)ty * 8 * tx * 16 * 3) return false;  // patches less than 75 % full (the 20x20 maps: 52 %)
     const int64_t Min = (int64_t)d->N * d->Hs * d->Ws, Mout = (int64_t)d->N * d->Hd * d->Wd;

@@ -31,6 +31,7 @@ struct LossArgs {
     int N, nc, n_max, A, f_ld, dtype, grad_dtype, topk;
     int vec;  // rows are multiples of eight elements and every map pointer is 16-byte aligned: loss_grad_kernel moves them as 16-byte vectors
     float alpha, beta, gain_box, gain_cls, gain_dfl, grad_scale;
+    const float* grad_scale_dev;  // GradScaler scale on the device (NULL: none)
     const float* gt;        // [N, n_max, 5]
     // workspace
     float* pbox;            // [N, A, 4] grid units (xyxy)
@@ -351,7 +352,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const LossArgs a) {
     __shared__ float sh[4];
     const int64_t total = (int64_t)a.N * a.A;
     const float tss = (float)a.tss[0];
-    const float gmul = 2.f * (float)a.N * a.grad_scale;  // d(2*bs*total)/d(total), times the caller's scale
+    // d(2*bs*total)/d(total), times the caller's scale, times the GradScaler's (scaler.scale(loss).backward(), averaging.py:158; a power of two)
+    const float gmul = 2.f * (float)a.N * a.grad_scale * (a.grad_scale_dev ? a.grad_scale_dev[0] : 1.f);
     float l_box = 0.f, l_cls = 0.f, l_dfl = 0.f;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / a.A), an = (int)(idx - (int64_t)n * a.A);
@@ -621,6 +623,7 @@ extern "C" int cdet_det_loss(const cdet_loss_desc* d, const void* f0, const void
     }
     a.alpha = d->alpha; a.beta = d->beta; a.gain_box = d->gain_box; a.gain_cls = d->gain_cls; a.gain_dfl = d->gain_dfl;
     a.grad_scale = d->grad_scale;
+    a.grad_scale_dev = d->grad_scale_dev;
     a.gt = gt;
     const WsLayout L = ws_layout(d->N, a.A, d->n_max);
     char* p = (char*)ws;

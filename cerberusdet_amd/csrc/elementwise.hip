@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce2_kernel(const uint16_t
         }
     }
     __syncthreads();
-    if (fold == nullptr) {
+    if (!CDET_FOLD(fold)) {
         for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
             float acc = 0.f;
             for (int r = 0; r < cm.rows_per_pass; ++r) acc += shm[r * 2 * C + j];
@@ -1119,6 +1119,9 @@ extern "C" int cdet_bn_silu_bwd_reduce_fold(const void* dy, int32_t dy_ld, int32
                                             const float* mean, const float* invstd, const float* gamma, const float* beta, float* part, int64_t M,
                                             int32_t C, int32_t dtype, const cdet_bn_fold* fold_dev, void* stream) {
     CDET_CHECK_ARG(fold_dev, "cdet_bn_silu_bwd_reduce_fold: null descriptor");
+#ifndef CDET_EXPERIMENTS
+    CDET_CHECK_ARG(false, "cdet_bn_silu_bwd_reduce_fold: the in-launch BatchNorm fold is compiled into -DCDET_EXPERIMENTS builds only (cdet_has_experiments())");
+#endif
     CDET_CHECK_ARG(bn_v2() && bn_small(M, dy_ld) && bn_small(M, z_ld), "cdet_bn_silu_bwd_reduce_fold: tensors of 2 GiB and more take the two-launch form");
     return bn_silu_bwd_reduce_impl(dy, dy_ld, dy_coff, z, z_ld, z_coff, mean, invstd, gamma, beta, part, M, C, dtype, fold_dev, stream);
 }

@@ -12,9 +12,12 @@ constexpr int OPT_SGD_BLOCKS = 256;       // update kernel: measured 1.18 / 1.08
 // Block b of a slot sums the contiguous chunk [b n / B, (b + 1) n / B) of the gradient: 16-byte loads over the aligned middle of the chunk (the bucket
 // slices behind an odd-sized bias vector start unaligned), four independent partial sums per lane. (The strided scalar form ran at 1.5 TB/s: 0.28 ms of
 // the iteration's serial tail for 420 MB.)
-__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const cdet_param_slot* __restrict__ slots, float* __restrict__ out) {
+// `scaler` (GradScaler state, NULL = no loss scaling): the norm is that of the UNSCALED gradients g / scale -- what the reference's
+// scaler.unscale_() leaves in p.grad before clip_grad_norm_ (trainers/averaging.py:207-208) -- so a large loss scale cannot overflow the sum.
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const cdet_param_slot* __restrict__ slots, float* __restrict__ out, const float* __restrict__ scaler) {
     __shared__ float sh[4];
     const cdet_param_slot sl = slots[blockIdx.y];
+    const float inv = scaler ? 1.f / scaler[0] : 1.f;
     float acc = 0.f;
     if (sl.g) {
         const int64_t per = (sl.n + gridDim.x - 1) / gridDim.x;
@@ -25,6 +28,8 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const cdet_param_slot*
             int64_t a0 = lo + ((4 - (int)((reinterpret_cast<uintptr_t>(g + lo) >> 2) & 3)) & 3);
             if (a0 > hi) a0 = hi;
             for (int64_t i = lo + threadIdx.x; i < a0; i += 256) acc += g[i] * g[i];
+            // (the unscale factor is applied to the block's partial sum below: (inv g)^2 summed = inv^2 x sum g^2 up to rounding; with inv a power of
+            //  two -- every GradScaler scale is -- it is exact, and with scaler == NULL the arithmetic is the unscaled kernel's, bit for bit)
             const int64_t n4 = (hi - a0) >> 2;
             const f32x4* g4 = reinterpret_cast<const f32x4*>(g + a0);
             f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
@@ -40,7 +45,10 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const cdet_param_slot*
     for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[1 + blockIdx.y * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) {
+        const float tot = sh[0] + sh[1] + sh[2] + sh[3];
+        out[1 + blockIdx.y * gridDim.x + blockIdx.x] = scaler ? tot * inv * inv : tot;
+    }
 }
 
 __global__ __launch_bounds__(1024) void sqnorm_finish_kernel(float* out, int n) {
@@ -60,14 +68,30 @@ struct GroupLr {
     float v[4];
 };
 
+// GradScaler step semantics (reference trainers/averaging.py:61, 205-223: scaler.unscale_ -> clip_grad_norm_ -> scaler.step -> scaler.update ->
+// zero_grad -> ema.update): when the gradient norm is not finite (an inf / NaN anywhere in the gradients) the optimizer step is SKIPPED -- weights
+// and momentum buffers keep their bits, the gradients are zeroed, and the EMA lerp still runs (the reference calls ema.update regardless). The norm
+// is the found-inf flag: inf^2 = inf and NaN propagate through the fixed-order sum of cdet_grad_sqnorm.
 __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __restrict__ slots, const float* __restrict__ sqnorm, float max_norm,
-                                                      GroupLr lrs, float momentum, float ema_decay) {
+                                                      GroupLr lrs, float momentum, float ema_decay, const float* __restrict__ scaler) {
     const cdet_param_slot sl = slots[blockIdx.y];
     const float lr = lrs.v[sl.group & 3];
     float coef = 1.f;
+    bool skip = false;
     if (sqnorm) {
-        const float total = sqrtf(sqnorm[0]);
+        const float sq = sqnorm[0];
+        skip = !(sq <= 3.402823466e38f);                // inf or NaN: found_inf
+        const float total = sqrtf(sq);
         coef = fminf(max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    }
+    if (scaler) coef *= 1.f / scaler[0];                // scaler.unscale_ (a power of two: exact)
+    if (skip) {
+        // found_inf: p and the momentum buffer are not touched; optimizer.zero_grad() and ema.update(model) still happen
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sl.n; i += (int64_t)gridDim.x * 256) {
+            if (sl.g) sl.g[i] = 0.f;
+            if (sl.ema) sl.ema[i] = sl.ema[i] * ema_decay + (1.f - ema_decay) * sl.p[i];
+        }
+        return;
     }
     // 16-byte path when the slot's four arrays allow it (conv weights: 80 % of the bytes); scalar otherwise (odd-sized bias vectors
     // shift the alignment of the bucket slices behind them)
@@ -110,6 +134,30 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __r
     }
 }
 
+// scaler.update() (torch.cuda.amp.GradScaler, reference trainers/averaging.py:61, 220): state = {scale, growth_tracker, skipped steps, found_inf of
+// this step}. found_inf: scale *= backoff, tracker = 0; else tracker += 1 and, at growth_interval, scale *= growth, tracker = 0. growth_interval <= 0
+// keeps the scale fixed (bf16 plans: scale 1, only the skip semantics apply). One thread; runs behind the update kernels that read the old scale.
+__global__ void scaler_update_kernel(float* __restrict__ st, const float* __restrict__ sqnorm, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool found = !(sqnorm[0] <= 3.402823466e38f);
+    st[3] = found ? 1.f : 0.f;
+    if (found) {
+        st[2] += 1.f;
+        if (interval > 0) {
+            st[0] *= backoff;
+            st[1] = 0.f;
+        }
+    } else if (interval > 0) {
+        const float tr = st[1] + 1.f;
+        if (tr >= (float)interval) {
+            st[0] *= growth;
+            st[1] = 0.f;
+        } else {
+            st[1] = tr;
+        }
+    }
+}
+
 // dst += src; src = 0 -- the per-task gradient buckets of the blocks several tasks share are folded into the block's bucket in task order
 __global__ __launch_bounds__(256) void accumulate_clear_kernel(float* __restrict__ dst, float* __restrict__ src, int64_t n) {
     const int64_t n4 = n >> 2;
@@ -144,10 +192,10 @@ extern "C" int cdet_accumulate_clear(float* dst, float* src, int64_t n, void* st
     return 0;
 }
 
-extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, void* stream) {
+extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, const float* scaler, void* stream) {
     CDET_CHECK_ARG(slots_dev && out && n_slots > 0, "cdet_grad_sqnorm: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(OPT_BLOCKS_PER_SLOT, n_slots), dim3(256), 0, s, slots_dev, out);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(OPT_BLOCKS_PER_SLOT, n_slots), dim3(256), 0, s, slots_dev, out, scaler);
     CDET_LAUNCH_CHECK();
     hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(1024), 0, s, out, n_slots * OPT_BLOCKS_PER_SLOT);
     CDET_LAUNCH_CHECK();
@@ -155,12 +203,20 @@ extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slot
 }
 
 extern "C" int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm, const float* lrs,
-                                 int32_t n_groups, float momentum, float ema_decay, void* stream) {
+                                 int32_t n_groups, float momentum, float ema_decay, const float* scaler, void* stream) {
     CDET_CHECK_ARG(slots_dev && n_slots > 0 && lrs && n_groups >= 1 && n_groups <= 4, "cdet_sgd_ema_step: bad arguments");
     GroupLr gl{{0.f, 0.f, 0.f, 0.f}};
     for (int i = 0; i < n_groups; ++i) gl.v[i] = lrs[i];
     hipLaunchKernelGGL(sgd_ema_kernel, dim3(tune_env("CDET_OPT_BLOCKS", OPT_SGD_BLOCKS), n_slots), dim3(256), 0, (hipStream_t)stream, slots_dev, sqnorm,
-                       max_norm, gl, momentum, ema_decay);
+                       max_norm, gl, momentum, ema_decay, scaler);
+    CDET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cdet_scaler_update(float* scaler, const float* sqnorm, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream) {
+    CDET_CHECK_ARG(scaler && sqnorm, "cdet_scaler_update: null pointer");
+    CDET_CHECK_ARG(growth_interval <= 0 || (growth_factor > 1.f && backoff_factor > 0.f && backoff_factor < 1.f), "cdet_scaler_update: growth > 1, 0 < backoff < 1");
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, sqnorm, growth_factor, backoff_factor, growth_interval);
     CDET_LAUNCH_CHECK();
     return 0;
 }

@@ -140,17 +140,20 @@ extern "C" int cdet_peer_allreduce(float* vec, int32_t n, const void* peer_table
     CDET_CHECK_ARG(vec && peer_table && err && n > 0, "cdet_peer_allreduce: bad arguments");
     CDET_CHECK_ARG(world >= 1 && world <= 64 && rank >= 0 && rank < world && epoch != 0, "cdet_peer_allreduce: bad world / rank / epoch");
     CDET_CHECK_ARG(phase >= 0 && phase <= 2, "cdet_peer_allreduce: phase must be 0 (whole exchange), 1 (publish) or 2 (collect)");
-    static unsigned long long spin = 0;
-    if (!spin) {
-        // wait budget per exchange in wall time. Default 10 min, the order of a collective library's watchdog: ordinary rank skew (a host-bound
-        // loader, a plan compile on one rank, checkpoint IO) must never trip it -- a process group would simply have waited.
-        const char* e = getenv("CDET_PEER_SPIN_MS");
-        int dev = 0, khz = 0;
-        (void)hipGetDevice(&dev);
+    // wait budget per exchange in wall time: the `peer_spin_ms` switch (default 10 min, the order of a collective library's watchdog: ordinary rank
+    // skew -- a host-bound loader, a plan compile on one rank, checkpoint IO -- must never trip it; peer_exchange.py sets a few seconds around its
+    // start-up self-test, which exists to catch a mapping that opens but does not carry peer stores). The wall-clock rate is the CURRENT device's.
+    static int khz_of[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int khz = (dev >= 0 && dev < 64) ? khz_of[dev] : 0;
+    if (khz <= 0) {
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;  // gfx9: 100 MHz
         (void)hipGetLastError();
-        spin = (unsigned long long)(e ? atoll(e) : 600000) * (unsigned long long)khz;
+        if (dev >= 0 && dev < 64) khz_of[dev] = khz;
     }
+    const int ms = sw(SW_PEER_SPIN_MS) > 0 ? sw(SW_PEER_SPIN_MS) : 600000;
+    const unsigned long long spin = (unsigned long long)ms * (unsigned long long)khz;
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, vec, n, (const uint64_t*)peer_table, world, rank,
                        (long long)data_off, (long long)flag_off, epoch, (unsigned*)err, phase, spin);
     CDET_LAUNCH_CHECK();

@@ -197,7 +197,11 @@ def try_setup(device, rank: int, world: int, group=None):
     # A mapping that opens but does not carry peer stores (or flags that never become visible) shows up HERE, not inside the first iteration.
     good = ok
     if ok:
+        # (a SHORT wait budget for this one exchange: a mapping that does not carry peer stores must fail start-up in seconds, not spin a kernel
+        #  for the 10 minutes a training exchange may wait for a slow rank -- `peer_spin_ms` switch of the library, csrc/switches.h)
+        budget = L.get_switch("peer_spin_ms")
         try:
+            L.set_switch("peer_spin_ms", int(os.environ.get("CDET_PEER_SELFTEST_MS", "5000")))
             probe = torch.full((64,), float(rank + 1), dtype=torch.float32, device=px.device)
             with torch.cuda.device(px.device):
                 px.make_call(probe)(torch.cuda.current_stream().cuda_stream)
@@ -208,6 +212,8 @@ def try_setup(device, rank: int, world: int, group=None):
         except Exception as e:  # noqa: BLE001
             note("self-test", e)
             good = False
+        finally:
+            L.set_switch("peer_spin_ms", budget)
     ok = _all_ok(good, world, group)
     if not ok:
         if px is not None:

@@ -61,6 +61,59 @@ class ModelEMA:
         return ema_decay(x, self.decay_base)
 
 
+class CommTimer:
+    """Where a COMPUTE stream waits for communication, measured with event pairs on that stream: the join on the gradient all-reduce handles in
+    front of the optimizer step ("grad_wait": what of the 421 MB exchange the backward did not hide) and every SyncBatchNorm statistics
+    collective ("syncbn": they sit on the dependent chain of their layer, so their whole duration is exposed). bench.py --gpus N attaches one to
+    the model (`model._comm_timer`) and prints the per-iteration sums as `comm_exposed_ms`, so that the first real multi-GPU run explains itself.
+    Off (None) everywhere else: two event records per collective are not free."""
+
+    def __init__(self):
+        self.pairs: List[tuple] = []
+
+    class _Span:
+        def __init__(self, timer, kind):
+            self.timer, self.kind = timer, kind
+
+        def __enter__(self):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+        def __exit__(self, *exc):
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            self.timer.pairs.append((self.kind, self.e0, e1))
+            return False
+
+    def span(self, kind: str):
+        return CommTimer._Span(self, kind)
+
+    def reset(self):
+        self.pairs = []
+
+    def collect(self) -> Dict[str, float]:
+        """Milliseconds per kind since the last reset (synchronises)."""
+        torch.cuda.synchronize()
+        out: Dict[str, float] = {}
+        for kind, e0, e1 in self.pairs:
+            out[kind] = out.get(kind, 0.0) + e0.elapsed_time(e1)
+        out["n_spans"] = float(len(self.pairs))
+        return out
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def comm_span(model, kind: str):
+    t = getattr(model, "_comm_timer", None)
+    return t.span(kind) if t is not None else _NoSpan()
+
+
 class GradReducer:
     """Bucketed gradient all-reduce keyed on the block DAG. One flat fp32 bucket per block, sent as REDUCTION UNITS: the slices that become
     final at one point of the backward -- every backbone row of block 0, every other block as a whole. A unit is reduced (SUM, async) when the
@@ -232,6 +285,14 @@ class Averaging:
         self._slots_host = (L.ParamSlot * self.n_slots)()
         self._slots_dev = torch.empty(C.sizeof(self._slots_host), dtype=torch.uint8, device=device)
         self._norm_buf = torch.zeros(1 + 32 * self.n_slots, dtype=torch.float32, device=device)
+        # GradScaler (reference trainers/averaging.py:61: amp.GradScaler(enabled=cuda), driven at 158 / 207 / 219-220), device-resident so that no
+        # step needs a host sync: {scale, growth_tracker, skipped steps, found_inf of the last step}. fp16 plans (model.half(): the reference's own
+        # AMP dtype) scale the loss -- init 65536, x2 every 2000 good steps, /2 on a skipped step (torch's defaults); bf16 plans have fp32's
+        # exponent range and keep scale 1 (growth off). The found-inf SKIP applies to both: a non-finite gradient anywhere leaves weights and
+        # momentum untouched, zeroes the gradients, still runs the EMA lerp (csrc/optim.hip).
+        self.loss_scaling = model.compute_dtype == torch.float16
+        self._scaler = torch.tensor([65536.0 if self.loss_scaling else 1.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.scaler_growth, self.scaler_backoff, self.scaler_interval = 2.0, 0.5, (2000 if self.loss_scaling else 0)
         self._slot_key = None
         self.reducer = GradReducer(buckets, self.serving, self.task_ids)
         self.group_sizes = [len(g2), len(g0), len(g1)]  # optimizer.param_groups order of the reference: bias, decay, bn
@@ -317,7 +378,7 @@ class Averaging:
         if self._gt_dropped is None:
             self._gt_dropped = torch.zeros(1, dtype=torch.int32, device=img.device)
         gt = pad_targets(batch, img.shape[0], (img.shape[2], img.shape[3]), img.device, n_max=n_max, dropped=self._gt_dropped)
-        loss5 = plan.loss(task, gt, self.gains[task], grad_scale=float(self.loss_weights[task]))
+        loss5 = plan.loss(task, gt, self.gains[task], grad_scale=float(self.loss_weights[task]), scaler=self._scaler if self.loss_scaling else None)
         yield from plan.iter_backward(fired)
         return loss5
 
@@ -445,7 +506,8 @@ class Averaging:
         their gradients None (torch >= 2.0 default set_to_none), so torch's SGD skips them entirely -- no weight decay, no momentum
         coasting, no momentum-buffer initialisation; here their slots become EMA-only for this step and are not marked stepped."""
         self.join_tail()  # (a previous deferred tail still owns its slots)
-        self.reducer.wait()
+        with comm_span(self.model, "grad_wait"):
+            self.reducer.wait()
         idle = set(idle_blocks)
         live = [m["g"] is not None and m["p"].requires_grad and int(m["key"].split(".")[1]) not in idle for m in self.slots_meta]
         fresh = sum(1 for m, a in zip(self.slots_meta, live) if a and not m.get("stepped", True))
@@ -467,7 +529,8 @@ class Averaging:
             self._slots_dev.copy_(torch.frombuffer(bytearray(bytes(self._slots_host)), dtype=torch.uint8), non_blocking=False)
             self._slot_key = key
         st = torch.cuda.current_stream().cuda_stream
-        L.check(self.lib.cdet_grad_sqnorm(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), st), "cdet_grad_sqnorm")
+        sc = self._scaler.data_ptr() if self.loss_scaling else None  # (unscale only when the loss was scaled; the skip needs the norm alone)
+        L.check(self.lib.cdet_grad_sqnorm(self._slots_dev.data_ptr(), self.n_slots, self._norm_buf.data_ptr(), sc, st), "cdet_grad_sqnorm")
         n_head = self.n_head_slots if (defer_tail and 0 < self.n_head_slots < self.n_slots) else self.n_slots
         if n_head < self.n_slots:
             from ..engine import lane_stream
@@ -482,17 +545,23 @@ class Averaging:
             d = self.ema.decay(self.ema.updates)
         lr_arr = (C.c_float * len(lrs))(*[float(v) for v in lrs])
         L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), n_head, self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs),
-                                           float(momentum), float(d), st), "cdet_sgd_ema_step")
+                                           float(momentum), float(d), sc, st), "cdet_sgd_ema_step")
         if n_head < self.n_slots:
             # the tail: the same kernel over the slots of the unshared blocks, on a side stream behind the clipping norm -- it runs under the next
             # iteration's trunk (HBM-bound update beside MFMA-bound convolutions); same arithmetic per slot, same results
             ts = self._tail_stream
             ts.wait_event(self._norm_event)
             L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr() + n_head * C.sizeof(L.ParamSlot), self.n_slots - n_head,
-                                               self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs), float(momentum), float(d), ts.cuda_stream),
+                                               self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs), float(momentum), float(d), sc, ts.cuda_stream),
                     "cdet_sgd_ema_step")
+            # scaler.update() behind BOTH update launches (the tail reads the old scale too)
+            L.check(self.lib.cdet_scaler_update(self._scaler.data_ptr(), self._norm_buf.data_ptr(), self.scaler_growth, self.scaler_backoff,
+                                                self.scaler_interval, ts.cuda_stream), "cdet_scaler_update")
             self._tail_event.record(ts)
             self._tail_pending = True
+        else:
+            L.check(self.lib.cdet_scaler_update(self._scaler.data_ptr(), self._norm_buf.data_ptr(), self.scaler_growth, self.scaler_backoff,
+                                                self.scaler_interval, st), "cdet_scaler_update")
         if fresh:
             for m, a in zip(self.slots_meta, live):
                 if a:
@@ -531,6 +600,13 @@ class Averaging:
             self.join_tail()
         return out
 
+    def scaler_state(self):
+        """GradScaler state (host sync): dict(scale, growth_tracker, skipped_steps, found_inf) -- `skipped_steps` counts the optimizer steps a
+        non-finite gradient has cancelled so far (reference: scaler.step() returns without stepping, trainers/averaging.py:219)."""
+        self.join_tail()
+        v = self._scaler.tolist()
+        return dict(scale=v[0], growth_tracker=int(v[1]), skipped_steps=int(v[2]), found_inf=bool(v[3]))
+
     def check_targets(self):
         """Call where the training loop synchronises anyway (loss read-back): raises if a label did not fit the `n_max` given to
         train_step() -- the sync-free target padding drops such labels (and counts them) instead of overwriting others."""
@@ -556,7 +632,7 @@ class Averaging:
                     momentum={m["key"]: m["mom"].detach().cpu() for m in self.slots_meta if m.get("mom") is not None},
                     stepped={m["key"]: bool(m.get("stepped", True)) for m in self.slots_meta if m.get("mom") is not None},
                     ema=({k: v.detach().cpu() for k, v in self.ema.ema.state_dict().items()} if self.ema else None),
-                    ema_updates=(self.ema.updates if self.ema else 0))
+                    ema_updates=(self.ema.updates if self.ema else 0), scaler=self._scaler.detach().cpu())
 
     def load_state_dict(self, sd):
         assert sd.get("format") == "cerberusdet_amd/trainer/1", "not a cerberusdet_amd trainer state"
@@ -569,4 +645,6 @@ class Averaging:
             if self.ema and sd.get("ema") is not None:
                 self.ema.ema.load_state_dict(sd["ema"])
                 self.ema.updates = int(sd["ema_updates"])
+            if sd.get("scaler") is not None:
+                self._scaler.copy_(sd["scaler"])
         self._slot_key = None

@@ -42,6 +42,16 @@ const char* cdet_last_error(void);
 /* device properties the host needs to size workspaces: out[0]=CU count, out[1]=LDS bytes/CU, out[2]=gfx arch number */
 int cdet_device_info(int32_t* out3);
 
+/* Kernel-form switches (csrc/switches.h): pins for A/B timing and for the parity tests that compare two forms of one kernel. The library reads
+ * its CDET_* environment variables ONCE, when it is loaded; no launch path calls getenv afterwards. The reference has no counterpart (its
+ * "switches" are torch.backends flags set at import, train.py:28-30); bench.py prints cdet_active_switches() so that a run's configuration is
+ * part of its record. name: the switch ("conv_pp") or its environment variable ("CDET_CONV_PP"); value CDET_SWITCH_DEFAULT restores the default. */
+#define CDET_SWITCH_DEFAULT (-2147483647 - 1)
+int cdet_set_switch(const char* name, int32_t value);
+int cdet_get_switch(const char* name, int32_t* value);   /* CDET_SWITCH_DEFAULT-valued result: not pinned, the geometry rules decide */
+int cdet_active_switches(char* buf, int32_t n);          /* "name=value ..." of every switch off its default + the build flavour; returns the length */
+int cdet_has_experiments(void);                          /* 1: built with -DCDET_EXPERIMENTS (the opt-in forms kept for the record are present) */
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA (bf16/f16 in, fp32 accumulate).
  * Replaces nn.Conv2d inside Conv.forward / fuseforward (models/common.py:57-68), the biased 1x1 head
@@ -449,6 +459,8 @@ typedef struct {
                                    /* pad channels get zero gradient)                                */
     int32_t topk;                  /* 10                                                             */
     float alpha, beta;             /* 0.5, 6.0                                                       */
+    const float* grad_scale_dev;   /* NULL, or a DEVICE float the gradient is ALSO multiplied by: the GradScaler's scale, read when the */
+                                   /* kernel runs (scaler.scale(loss).backward(), averaging.py:158) -- the loss items are not scaled   */
 } cdet_loss_desc;
 /* Loss.preprocess (utils/loss.py:111-124): n label rows -> gt [N, n_max, 5] fp32 (cls, x1, y1, x2, y2 px), zero rows = padding.
  * batch_idx / cls: [n] fp32, bboxes: [n, 4] fp32 normalised (cx, cy, w, h). Labels keep their order inside an image. A label
@@ -527,14 +539,24 @@ typedef struct {
     float weight_decay, inv_div;                  /* inv_div = 1 / #tasks served by the block */
     int32_t first_step;                           /* momentum buffer uninitialised            */
 } cdet_param_slot;
-/* sum of squares of all gradients -> out[0]; `out` must hold 1 + 32*n_slots floats (block partials, fixed-order reduce).
- * A slot with g == NULL takes part in the EMA only (BatchNorm running statistics). */
-int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, void* stream);
-/* clip by global norm (coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))), per-block division, SGD-nesterov, EMA, zero grad.
+/* GradScaler state (torch.cuda.amp.GradScaler as the reference drives it, trainers/averaging.py:61, 158, 207, 219-220), DEVICE float[4]:
+ * {scale, growth_tracker, skipped steps so far, found_inf of the last step}. Every `scaler` argument below may be NULL (no loss scaling: the
+ * found-inf SKIP still applies -- it is decided by the norm alone). The scale multiplies the loss gradient (cdet_loss_desc.grad_scale_dev). */
+/* sum of squares of all UNSCALED gradients (g / scale) -> out[0]; `out` must hold 1 + 32*n_slots floats (block partials, fixed-order reduce).
+ * A slot with g == NULL takes part in the EMA only (BatchNorm running statistics). A non-finite gradient anywhere makes out[0] non-finite:
+ * the found-inf flag of the step. */
+int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* out, const float* scaler, void* stream);
+/* unscale, clip by global norm (coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6))), per-block division, SGD-nesterov, EMA, zero grad.
+ * *sqnorm not finite (found_inf): the step is SKIPPED like scaler.step() does -- weights and momentum keep their bits, the gradients are zeroed,
+ * the EMA lerp still runs (the reference calls ema.update regardless, averaging.py:222-223).
  * lrs: HOST array of n_groups (<= 4) learning rates, passed by value with the launch -- the slot table does not change while the
  * warm-up / schedule moves the rates (trainers/averaging.py:160-180 of the reference recomputes them every iteration). */
 int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm,
-                      const float* lrs, int32_t n_groups, float momentum, float ema_decay, void* stream);
+                      const float* lrs, int32_t n_groups, float momentum, float ema_decay, const float* scaler, void* stream);
+/* scaler.update() (averaging.py:220): found_inf (*sqnorm not finite) -> scale *= backoff_factor, tracker = 0, skipped += 1; otherwise tracker += 1
+ * and scale *= growth_factor every growth_interval good steps (GradScaler defaults 2.0 / 0.5 / 2000, init scale 65536). growth_interval <= 0: the
+ * scale stays fixed and only the skip counter / found_inf flag are kept (bf16 plans). Enqueue BEHIND the update launches of the step. */
+int cdet_scaler_update(float* scaler, const float* sqnorm, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream);
 /* dst[i] += src[i]; src[i] = 0 (fp32, 16-byte aligned). The reference accumulates the gradients of a block that several tasks share in one
  * .grad tensor, task after task (trainers/averaging.py:140-160: backward per task, one optimizer step). Here every task but the first owns a
  * gradient bucket of its own for those blocks, so that the task passes are independent launch streams; the buckets are folded into the block's

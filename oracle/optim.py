@@ -38,10 +38,37 @@ def block_of(key: str) -> int:
     return int(key.split(".")[1])
 
 
+class GradScalerState:
+    """torch.cuda.amp.GradScaler as the reference drives it (trainers/averaging.py:61 `amp.GradScaler(enabled=self.cuda)`; 158 scale(loss).backward();
+    207 unscale_; 219 step; 220 update), restated: defaults init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000.
+    growth_interval <= 0 keeps the scale fixed (the engine's bf16 plans: scale 1, only the found-inf skip applies)."""
+
+    def __init__(self, scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(scale), growth_factor, backoff_factor, growth_interval
+        self.growth_tracker, self.skipped = 0, 0
+
+    def update(self, found_inf: bool):  # torch/amp/grad_scaler.py::update -> _amp_update_scale_
+        if found_inf:
+            self.skipped += 1
+            if self.growth_interval > 0:
+                self.scale *= self.backoff_factor
+                self.growth_tracker = 0
+        elif self.growth_interval > 0:
+            self.growth_tracker += 1
+            if self.growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self.growth_tracker = 0
+
+
 def optimizer_step(weights: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], momentum_buf: Dict[str, torch.Tensor],
                    n_serving: Dict[int, int], lr=(0.00309, 0.00309, 0.00309), momentum=0.952, weight_decay=0.00037,
-                   max_norm=10.0):
-    """One Averaging.optimizer_step on CPU tensors (no GradScaler: scale == 1).
+                   max_norm=10.0, scaler: "GradScalerState | None" = None):
+    """One Averaging.optimizer_step on CPU tensors.
+
+    scaler: None = scale 1 and no skip bookkeeping (the pre-round-6 behaviour for finite gradients). With a GradScalerState the gradients are the
+    SCALED ones (scaler.scale(loss).backward()): unscale_ divides them by the scale and records found_inf = any non-finite element; on found_inf
+    scaler.step() skips optimizer.step() -- weights and momentum buffers untouched -- and update() backs the scale off (averaging.py:207-220). The
+    caller's zero_grad() / ema.update() happen either way. Returns the total norm of the unscaled gradients (non-finite on a skipped step).
 
     grads: accumulated over this iteration's task passes (keys missing = no grad).
     n_serving: block idx -> number of tasks served (averaging.py:124-127; max(len, 1)).
@@ -49,10 +76,17 @@ def optimizer_step(weights: Dict[str, torch.Tensor], grads: Dict[str, torch.Tens
     Returns the total gradient norm before clipping.
     """
     keys = [k for k in weights if is_trainable(k) and k in grads]
-    total = torch.sqrt(sum((grads[k].double() ** 2).sum() for k in keys)).float()
+    inv = 1.0 / scaler.scale if scaler is not None else 1.0
+    found_inf = any(not bool(torch.isfinite(grads[k]).all()) for k in keys)
+    total = torch.sqrt(sum(((grads[k].double() * inv) ** 2).sum() for k in keys)).float()
+    if scaler is not None or found_inf:
+        if scaler is not None:
+            scaler.update(found_inf)
+        if found_inf:
+            return float(total)  # scaler.step(): optimizer.step() skipped
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     for k in keys:
-        g = grads[k] * coef  # clip over ALL params first (averaging.py:208)
+        g = grads[k] * inv * coef  # unscale_, then clip over ALL params (averaging.py:207-208)
         g = g / float(n_serving[block_of(k)])  # then the per-block division (averaging.py:211-217)
         grp = param_group(k)
         p = weights[k]

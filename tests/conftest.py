@@ -17,3 +17,21 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture
+def sw():
+    """Pin kernel-form switches of the library for one test (csrc/switches.h: the library reads its CDET_* environment once, at load; inside a
+    process the forms are switched through cdet_set_switch). `sw("CDET_HALO_NG", 2)`; `sw("CDET_HALO_NG", None)` = not pinned. Restored afterwards."""
+    from cerberusdet_amd import _lib as L
+
+    before = {}
+
+    def pin(name, value):
+        if name not in before:
+            before[name] = L.get_switch(name)
+        L.set_switch(name, value)
+
+    yield pin
+    for name, value in before.items():
+        L.set_switch(name, value)

@@ -180,3 +180,41 @@ def test_bench_sharding_gives_distinct_rank_data():
     assert not torch.equal(a["img"], b["img"]) and not torch.equal(a["img"], c["img"])
     assert a["img"].dtype == torch.uint8 and a["bboxes"].shape == (16, 4) and float(a["bboxes"][:, :2].min()) >= 0.2
     assert torch.equal(a["img"], bench.synth_batch(0, 0, 0, 2, 20, 64, "cpu")["img"])  # deterministic
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, str(root / "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return p.returncode, [json.loads(l) for l in lines if l.startswith("{")], lines, p.stderr
+
+
+def test_bench_gpus2_launcher_path_with_gloo_stub_ranks():
+    """`python bench.py --gpus 2 --steps K --warmup W` WITHOUT a launcher (what a user types; the driver wraps it in torch.distributed.run itself):
+    the parent must pick a free port, start torch.distributed.run with two ranks on 127.0.0.1, hand the arguments through unchanged, leave stdout
+    to rank 0's ONE JSON line and relay the exit code. CDET_BENCH_STUB=1 replaces the GPU step by a stand-in behind the same barrier /
+    MAX-over-ranks protocol, rendezvous over gloo -- this path had never executed anywhere."""
+    rc, objs, lines, err = _run_bench({"CDET_BENCH_STUB": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1 and len(objs) == 1, lines  # exactly one line on stdout: rank 0's
+    o = objs[0]
+    assert o["stub"] and o["n_gpus"] == 2 and o["steps"] == 3 and o["warmup"] == 1 and o["scaling"] == "weak"
+    assert o["argv"] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5"]
+    assert o["sum_of_ranks"] == 3.0                      # both ranks took part in the stand-in's exchange
+    assert 1024 < int(o["master_port"]) < 65536
+    assert o["value"] == round(5 * 2 * 2 * 3 / (o["ms_per_step"] * 3 / 1e3), 2) or abs(o["value"] - 5 * 2 * 2 / (o["ms_per_step"] / 1e3)) < 0.01 * o["value"]
+    # a rank that dies makes the whole command fail (the launcher's exit code reaches the caller), and nothing lands on stdout
+    rc, objs, lines, err = _run_bench({"CDET_BENCH_STUB": "fail"}, "--gpus", "2", "--steps", "2", "--warmup", "0")
+    assert rc != 0 and objs == []
+    # a --gpus / WORLD_SIZE mismatch under an outer launcher is refused, not silently run at another size
+    rc, objs, lines, err = _run_bench({"CDET_BENCH_STUB": "1", "WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
+    assert rc != 0 and objs == [] and "--gpus 2 but WORLD_SIZE=4" in err

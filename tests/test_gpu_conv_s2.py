@@ -130,7 +130,7 @@ WGRAD_CASES = [
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES)
-def test_s2_weight_gradient_parity_planes(case, monkeypatch):
+def test_s2_weight_gradient_parity_planes(case, sw):
     """dW of the stride-2 3x3 convolution (autograd's convolution_backward(weight) of models/common.py:57 with s = 2) against fp32 autograd
     on the same 16-bit-rounded operands (1e-3 of the tensor scale), against the round-1 im2col kernel (1e-4), and the accumulate form."""
     from cerberusdet_amd import _lib as L
@@ -155,10 +155,10 @@ def test_s2_weight_gradient_parity_planes(case, monkeypatch):
     d = ops.conv_desc(src, dyv, 3, 2)
     d.Cd = Co
     lib = L.load()
-    monkeypatch.setenv("CDET_WGRAD_S2", "0")
+    sw("CDET_WGRAD_S2", int("0"))
     n_old = lib.cdet_conv2d_wgrad_ws_elems(C.byref(d))
     old = ops.conv2d_wgrad(src, dyv, torch.empty(Co, Ci, 3, 3, device=DEV), 3, 2)
-    monkeypatch.delenv("CDET_WGRAD_S2")
+    sw("CDET_WGRAD_S2", None)
     n_new = lib.cdet_conv2d_wgrad_ws_elems(C.byref(d))
     assert n_new != n_old or Co * Ci < 160 * 32, "the case must be taken by the parity-plane kernel (different slab plan)"
     base = torch.randn(Co, Ci, 3, 3, generator=g).to(DEV)

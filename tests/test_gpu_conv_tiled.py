@@ -53,9 +53,9 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("ng", [0, 1, 2, 3, 4, "wg3", "ks1", "ks2"])
+@pytest.mark.parametrize("ng", [0, 1, 2, 3, 4, "wg3", "ks1", "ks2", "pp0", "pp2"])
 @pytest.mark.parametrize("case", CASES)
-def test_tiled_conv_fwd_epilogue_stats(case, ng, monkeypatch):
+def test_tiled_conv_fwd_epilogue_stats(case, ng, sw):
     """ng: 0 = the library's own choice of tile (half tiles when 256-pixel tiles would under-fill the chip), 1 / 2 = pinned; 4 = the round-5
     experiment: 512-pixel tiles, one workgroup per CU, 16 of 20 accumulator tiles in AccVGPRs, six-stage weight ring (3x3, 160-cout blocks,
     maps up to 95 wide; other geometries keep the library's choice) -- correct, measured slower, opt-in only (profiles/r05_halo_ng4.txt); 3 = the
@@ -64,18 +64,23 @@ def test_tiled_conv_fwd_epilogue_stats(case, ng, monkeypatch):
     ops = _ops()
     from cerberusdet_amd import _lib as L
 
-    monkeypatch.delenv("CDET_HALO_WG3", raising=False)
-    monkeypatch.delenv("CDET_HALO_KS", raising=False)
-    if ng in ("ks1", "ks2"):  # the half-tile form with its K loop as one chain / split inside the workgroup (conv_halo.hip: KS); other geometries unaffected
-        monkeypatch.setenv("CDET_HALO_KS", ng[2])
-        monkeypatch.setenv("CDET_HALO_NG", "1")
+    sw("CDET_HALO_WG3", None)
+    sw("CDET_HALO_KS", None)
+    if ng in (3, 4) and not L.load().cdet_has_experiments():
+        pytest.skip("the 384- / 512-pixel tiles are compiled into -DCDET_EXPERIMENTS builds of the library only (measured slower, profiles/r05_halo_ng4.txt)")
+    if ng in ("pp0", "pp2"):  # 256-pixel tiles on the 4-wave form everywhere / on the 8-wave ping-pong form wherever it fits (csrc/conv_pp.hip); ng = 2
+        sw("CDET_CONV_PP", int(ng[2]))  # alone takes the ping-pong form for single-round grids (the default rule)
+        sw("CDET_HALO_NG", 2)
+    elif ng in ("ks1", "ks2"):  # the half-tile form with its K loop as one chain / split inside the workgroup (conv_halo.hip: KS); other geometries unaffected
+        sw("CDET_HALO_KS", int(ng[2]))
+        sw("CDET_HALO_NG", int("1"))
     elif ng == "wg3":  # three workgroups per CU for the 96-cout patch form (conv_halo.hip: TRI); other geometries keep the library's choice
-        monkeypatch.setenv("CDET_HALO_WG3", "1")
-        monkeypatch.delenv("CDET_HALO_NG", raising=False)
+        sw("CDET_HALO_WG3", int("1"))
+        sw("CDET_HALO_NG", None)
     elif ng:
-        monkeypatch.setenv("CDET_HALO_NG", str(ng))
+        sw("CDET_HALO_NG", int(str(ng)))
     else:
-        monkeypatch.delenv("CDET_HALO_NG", raising=False)
+        sw("CDET_HALO_NG", None)
 
     N, H, W, Ci, Co, k, dtype = case
     g = torch.Generator().manual_seed(11)
@@ -135,6 +140,51 @@ def test_tiled_conv_dgrad_is_forward_on_flipped_operand(case):
     _close(out.nchw(), x.grad + prev.nchw().float().cpu(), 2 ** -7, 4e-3 * float(x.grad.abs().max()))
 
 
+PP_CASES = [
+    (3, 20, 20, 64, 320, torch.bfloat16),    # linear halo, 5 pixel tiles (odd: the last pair's second group is idle), two cout blocks
+    (2, 32, 32, 96, 160, torch.bfloat16),    # 16 x 16 patches, 8 tiles
+    (1, 40, 40, 80, 200, torch.float16),     # Cin = 80: partial last chunk; Cout = 200: partial second cout block; 7 tiles
+    (5, 16, 16, 32, 160, torch.bfloat16),    # one chunk (9 K steps); patches, 5 tiles (odd)
+]
+
+
+@pytest.mark.parametrize("case", PP_CASES)
+def test_ping_pong_form_carries_the_bits_of_the_four_wave_form(case, sw):
+    """csrc/conv_pp.hip: the 8-wave two-phase form owns the same 256-pixel tiles / 160-cout blocks and adds in the same K order as
+    conv_halo_kernel<.., 9, 5, .., 2>: raw output, BatchNorm partial-sum rows and the fused epilogue (scale, bias, SiLU, residual) must be
+    IDENTICAL, incl. an odd number of pixel tiles (the last pair's second group only carries its share of the weight stream), partial chunks
+    and partial cout blocks. 20 launches each: the counted waits of the shared weight ring have to hold under repetition."""
+    ops = _ops()
+    from cerberusdet_amd import _lib as L
+
+    N, H, W, Ci, Co, dtype = case
+    g = torch.Generator().manual_seed(17)
+    x = _rt(torch.randn(N, Ci, H, W, generator=g), dtype)
+    w = _rt(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9), dtype)
+    scale, bias = (torch.rand(Co, generator=g) + 0.5).to(DEV), (torch.randn(Co, generator=g) * 0.1).to(DEV)
+    src = ops.from_nchw(x.to(DEV), dtype)
+    rv = ops.from_nchw(_rt(torch.randn(N, Co, H, W, generator=g), dtype).to(DEV), dtype)
+    wf, _ = ops.pack_weight_tiled(w.to(DEV), dtype)
+    sw("CDET_HALO_NG", 2)
+    out = {}
+    for form in (0, 2):
+        sw("CDET_CONV_PP", form)
+        raw, act = ops.new_act(N, H, W, Co, dtype), ops.new_act(N, H, W, Co, dtype)
+        nblk = ops.conv_tiled_stat_blocks(src, raw, 3)
+        stats = torch.zeros(nblk * 2 * Co, device=DEV)
+        for _ in range(20 if form else 1):
+            raw.torch().fill_(7.0)
+            stats.fill_(-1.0)
+            ops.conv2d_tiled(src, wf, raw, 3, stats=stats)
+            ops.conv2d_tiled(src, wf, act, 3, scale=scale, bias=bias, act=L.ACT_SILU, res=rv)
+            torch.cuda.synchronize()
+            if form:
+                assert torch.equal(raw.torch(), out[0][0]) and torch.equal(stats, out[0][1]) and torch.equal(act.torch(), out[0][2])
+        out[form] = (raw.torch().clone(), stats.clone(), act.torch().clone())
+    ref = F.conv2d(x, w, None, 1, 1)
+    _close(out[2][0].permute(0, 3, 1, 2).float().cpu(), ref, 2 ** -7, 1e-3)
+
+
 def test_tiled_matches_generic_kernel_on_dominant_shape():
     """40x40 320->320 3x3 at batch 4: both kernels see identical inputs; results agree to one output rounding."""
     ops = _ops()
@@ -160,7 +210,7 @@ PAIR_CASES = [
 
 
 @pytest.mark.parametrize("case", PAIR_CASES)
-def test_pair_kernel_forward_epilogue_stats_and_data_gradient(case, monkeypatch):
+def test_pair_kernel_forward_epilogue_stats_and_data_gradient(case, sw):
     """The shared-pixel-tile 1x1 kernel on small shapes (CDET_CONV_PAIR=2 takes it whenever the geometry allows; the library itself uses it
     from 256 workgroups on), through the same entry point cdet_conv2d_tiled: raw output + BN partial sums, fused epilogue into a channel
     slice, and the data gradient (a forward launch on the DGRAD operand) incl. the fan-in form -- against F.conv2d and against the
@@ -185,7 +235,7 @@ def test_pair_kernel_forward_epilogue_stats_and_data_gradient(case, monkeypatch)
     res = _rt(torch.randn(N, Co, H, W, generator=g), dtype)
     outs = {}
     for mode in ("2", "0"):
-        monkeypatch.setenv("CDET_CONV_PAIR", mode)
+        sw("CDET_CONV_PAIR", int(mode))
         dst = ops.new_act(N, H, W, Co, dtype)
         nblk = ops.conv_tiled_stat_blocks(src, dst, 1)
         stats = torch.zeros(nblk * 2 * Co, device=DEV)
@@ -204,7 +254,7 @@ def test_pair_kernel_forward_epilogue_stats_and_data_gradient(case, monkeypatch)
         outs[mode] = (dst.torch().clone(), stats.clone())
     assert torch.equal(outs["2"][0], outs["0"][0])  # same products, same fp32 accumulation order per output: identical bits
     # data gradient: rows = Cin (needs an even number of 160-row blocks to take the pair kernel; otherwise this is the 4-wave kernel)
-    monkeypatch.setenv("CDET_CONV_PAIR", "2")
+    sw("CDET_CONV_PAIR", int("2"))
     dyv = ops.from_nchw(dy.to(DEV), dtype)
     dx = ops.new_act(N, H, W, Ci, dtype)
     ops.conv2d_tiled(dyv, wd, dx, 1)
@@ -305,14 +355,14 @@ CAT_CASES = [
 
 
 @pytest.mark.parametrize("case", CAT_CASES)
-def test_conv_over_virtual_concat_equals_the_materialised_one(case, monkeypatch):
+def test_conv_over_virtual_concat_equals_the_materialised_one(case, sw):
     """cdet_conv2d_tiled_cat: the 1x1 convolution behind a Concat (+ Upsample) reading its inputs from their own buffers (slices of wider
     buffers, NaN around them) must give the SAME BITS as cdet_conv2d_tiled on the materialised tensor -- same K order, same kernel body."""
     ops = _ops()
     from cerberusdet_amd import _lib as L
 
     N, H, W, parts, Co, dtype, pair = case
-    monkeypatch.setenv("CDET_CONV_PAIR", "2" if pair else "0")
+    sw("CDET_CONV_PAIR", int("2" if pair else "0"))
     g = torch.Generator().manual_seed(71)
     views, mats = [], []
     for Cp, up in parts:

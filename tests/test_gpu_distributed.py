@@ -384,7 +384,7 @@ def test_peer_exchange_kernel_virtual_ranks_on_streams(monkeypatch):
     the box share the hardware slots). When they do not, the PRECONDITION of this test is missing: it is SKIPPED with that reason -- after checking
     that the timed-out exchange poisoned its vector with NaN instead of handing stale rows on -- never retried into a pass. A wrong sum always fails.
     The split form below covers the same arithmetic without that precondition."""
-    monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")
+    monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")  # (read by the worker process's library when it loads)
     res = _run_virtual_ranks(split=False)
     if res.startswith("not concurrent"):
         pytest.skip(f"the three streams of the worker did not run side by side on this box -- {res}")
@@ -396,7 +396,7 @@ def test_peer_exchange_split_form_virtual_ranks_cannot_time_out(monkeypatch):
     barrier): all three virtual ranks publish, the host synchronises, all three collect. Every flag is in place before any wait starts, so the
     kernel's bounded wait never spins: same slots, same parity double-buffering over 60 epochs, same rank-ordered sums, bit for bit, with no
     dependence on how the runtime schedules the streams. A time-out here is a visibility bug, not a scheduling artefact, and fails."""
-    monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")
+    monkeypatch.setenv("CDET_PEER_SPIN_MS", "3000")  # (read by the worker process's library when it loads)
     res = _run_virtual_ranks(split=True)
     assert res == "ok", res
 

@@ -179,6 +179,35 @@ def test_predict_batch_128_rows_equal_oracle_nms_on_the_downloaded_outputs():
     print(f"[predict bs128] {n_res:.1f} detections per image, {total} rows of 4 images equal the oracle's")
 
 
+@pytest.mark.parametrize("bs", [32, 128])
+def test_v8x_fp16_eval_plan_meets_1e3_of_the_full_precision_forward_at_full_width(bs):
+    """BASELINE.json north_star asks for >= 40 % of the MFMA peak AND boxes / loss within 1e-3 rel of the reference. The bf16 plans meet the first and
+    miss the second end to end (1.1 - 1.5 px of 640 = 2e-3: seven mantissa bits); the fp16 plans -- the reference's own inference dtype
+    (cerberusdet_inference.py:34-40 `model.half()`, models/yolo.py:87-100) -- run the same kernels at the same MFMA rate with three more bits. ASSERTED
+    here at full width (YOLOv8x 2-task, randomised BatchNorm statistics so that every layer is O(1)), at the north-star batch 32 and at config 5's 128,
+    against model.full_precision() (the fp32 reference's numbers to ~1e-6, tests/test_gpu_full_precision.py) on four images of the batch:
+    boxes <= 1e-3 x 640 px, class probabilities <= 1e-3 absolute. bench.py times this very plan as `north_star_fwd_fp16`."""
+    model = _model(torch.float16)
+    x = _image(bs, torch.float16)
+    with torch.no_grad():
+        out = model(x)  # the full batch: the plan of the timed workload
+        lo = {t: y[:4].float().clone() for t, (y, maps) in out.items()}
+        del out
+        model.full_precision()
+        hi = model(x[:4].contiguous())
+    torch.cuda.synchronize()
+    box = max(float((lo[t][:, :4] - hi[t][0][:, :4]).abs().max()) for t in hi)
+    prob = max(float((lo[t][:, 4:] - hi[t][0][:, 4:]).abs().max()) for t in hi)
+    var = min(float((b - b.mean(dim=(0, 2, 3), keepdim=True)).abs().max()) for t in hi for b in hi[t][1])  # the part of a head map the network computes
+    wh = min(float(hi[t][0][:, 2:4].max() - hi[t][0][:, 2:4].min()) for t in hi)
+    print(f"[v8x fp16 bs{bs} vs full precision] boxes max |d| {box:.3f} px = {box / 640:.2e} of the image, class probabilities max |d| {prob:.2e} "
+          f"(smallest head-map variation {var:.3f}, box sizes spread over {wh:.1f} px)")
+    assert box <= 1e-3 * 640, box
+    assert prob <= 1e-3, prob
+    assert var > 1e-2 and wh > 1.0  # nothing degenerate was compared
+    model.half()
+
+
 @pytest.mark.parametrize("cfg", list(CONFIGS))
 def test_v8x_16_bit_eval_plan_against_the_full_precision_forward_of_the_same_weights(cfg):
     """Whole-model accuracy of the 16-bit eval plans at full width, on non-degenerate activations (the randomised BatchNorm statistics of _model keep

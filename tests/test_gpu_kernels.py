@@ -147,7 +147,7 @@ WGRAD_HALO_CASES = [
 
 @pytest.mark.parametrize("tile", ["32", "64"])
 @pytest.mark.parametrize("case", WGRAD_HALO_CASES)
-def test_conv_wgrad_tap_resident(case, tile, monkeypatch):
+def test_conv_wgrad_tap_resident(case, tile, sw):
     """The tap-resident weight gradient against autograd AND against the im2col kernel it replaces on the same operands (channel
     slices of wider buffers on both sides)."""
     ops = _ops()
@@ -169,16 +169,16 @@ def test_conv_wgrad_tap_resident(case, tile, monkeypatch):
     if tile == "64":
         if Ci % 64:
             pytest.skip("the 64-cin tile needs Cin % 64 == 0")
-        monkeypatch.setenv("CDET_WGRAD_HALO", "4")
+        sw("CDET_WGRAD_HALO", int("4"))
     dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
     ops.conv2d_wgrad(xv, dyv, dw, 3, 1)
     torch.cuda.synchronize()
     _close(dw, w.grad, 2e-3, 2e-3 * float(w.grad.abs().max()))
-    monkeypatch.setenv("CDET_WGRAD_HALO", "0")
+    sw("CDET_WGRAD_HALO", int("0"))
     dw0 = torch.zeros(Co, Ci, 3, 3, device=DEV)
     ops.conv2d_wgrad(xv, dyv, dw0, 3, 1)
     torch.cuda.synchronize()
-    monkeypatch.setenv("CDET_WGRAD_HALO", "4" if tile == "64" else "1")
+    sw("CDET_WGRAD_HALO", int("4" if tile == "64" else "1"))
     _close(dw, dw0, 1e-4, 1e-4 * float(w.grad.abs().max()))  # same bf16 products, fp32 sums in a different order
     ops.conv2d_wgrad(xv, dyv, dw, 3, 1, accumulate=True)
     torch.cuda.synchronize()
@@ -201,7 +201,7 @@ WGRAD_PATCH_CASES = [
 
 
 @pytest.mark.parametrize("case", WGRAD_PATCH_CASES)
-def test_conv_wgrad_patch_form(case, monkeypatch):
+def test_conv_wgrad_patch_form(case, sw):
     """The 8 x 16 patch form of the narrow tap-resident weight gradient (default where the map splits into whole patches) against autograd, against
     the linear 128-pixel-run form of the same kernel (CDET_WGRAD_PATCH=0) and against the im2col kernel: same bf16 products, fp32 sums in another
     order. Source and gradient are channel slices of wider buffers; the accumulate variant doubles the result."""
@@ -225,13 +225,13 @@ def test_conv_wgrad_patch_form(case, monkeypatch):
     out = {}
     for name, env in (("patch", {}), ("linear", {"CDET_WGRAD_PATCH": "0"}), ("im2col", {"CDET_WGRAD_HALO": "0"})):
         for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+            sw(k_, int(v_))
         dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
         ops.conv2d_wgrad(xv, dyv, dw, 3, 1)
         torch.cuda.synchronize()
         out[name] = dw
         for k_ in env:
-            monkeypatch.delenv(k_)
+            sw(k_, None)
     _close(out["patch"], w.grad, 2e-3, 2e-3 * scale)
     _close(out["patch"], out["linear"], 1e-4, 1e-4 * scale)
     _close(out["patch"], out["im2col"], 1e-4, 1e-4 * scale)
@@ -243,7 +243,7 @@ def test_conv_wgrad_patch_form(case, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 20, 20, 256, 160, torch.bfloat16), (1, 24, 40, 800, 320, torch.bfloat16), (3, 16, 16, 288, 136, torch.float16),
                                   (1, 13, 11, 1600, 200, torch.bfloat16), (1, 20, 20, 576, 640, torch.bfloat16)])
-def test_conv_wgrad_1x1_transpose_read_kernel(case, monkeypatch):
+def test_conv_wgrad_1x1_transpose_read_kernel(case, sw):
     """1x1 weight gradient on wgrad_gemm_kernel (csrc/conv_wgrad_halo.hip) against autograd and against the im2col kernel; operands are
     channel slices of wider buffers; pixel counts that are not multiples of the 64-pixel stage; a cin tile that is partly empty."""
     ops = _ops()
@@ -262,17 +262,17 @@ def test_conv_wgrad_1x1_transpose_read_kernel(case, monkeypatch):
     yb[..., 8:8 + Cop] = 0
     yb[..., 8:8 + Co] = dy.permute(0, 2, 3, 1).to(dtype).to(DEV)
     dyv = ops.View(yb, 8, Cop)
-    monkeypatch.setenv("CDET_WGRAD_HALO", "3")  # the kernel for every Cout >= 128 (by default only Cout > 320 goes there)
+    sw("CDET_WGRAD_HALO", int("3"))  # the kernel for every Cout >= 128 (by default only Cout > 320 goes there)
     dw = torch.zeros(Co, Ci, 1, 1, device=DEV)
     ops.conv2d_wgrad(xv, dyv, dw, 1, 1)
     torch.cuda.synchronize()
     scale = float(w.grad.abs().max())
     _close(dw, w.grad, 2e-3, 2e-3 * scale)
-    monkeypatch.setenv("CDET_WGRAD_HALO", "0")
+    sw("CDET_WGRAD_HALO", int("0"))
     dw0 = torch.zeros_like(dw)
     ops.conv2d_wgrad(xv, dyv, dw0, 1, 1)
     torch.cuda.synchronize()
-    monkeypatch.setenv("CDET_WGRAD_HALO", "3")
+    sw("CDET_WGRAD_HALO", int("3"))
     _close(dw, dw0, 1e-4, 1e-4 * scale)
     ops.conv2d_wgrad(xv, dyv, dw, 1, 1, accumulate=True)
     torch.cuda.synchronize()
@@ -626,9 +626,9 @@ def test_sgd_ema_step_matches_oracle():
             slots[i].inv_div, slots[i].first_step = 1.0 / serving[oo.block_of(k)], int(step == 0)
         sdev = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(DEV)
         out = torch.zeros(1 + 32 * len(keys), device=DEV)
-        L.check(lib.cdet_grad_sqnorm(sdev.data_ptr(), len(keys), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        L.check(lib.cdet_grad_sqnorm(sdev.data_ptr(), len(keys), out.data_ptr(), None, torch.cuda.current_stream().cuda_stream))
         d = oo.ema_decay(upd + 1)
-        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d,
+        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d, None,
                                       torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         total = oo.optimizer_step(wref, {k: v.clone() for k, v in gr.items()}, mom_ref, serving, lr=lrs, momentum=0.952, weight_decay=0.00037)
@@ -639,6 +639,81 @@ def test_sgd_ema_step_matches_oracle():
             _close(ed[k], eref[k], 1e-5, 1e-6)
             assert float(gd[k].abs().max()) == 0.0
             gd[k].copy_(gr[k])
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_sgd_ema_step_skips_on_a_non_finite_gradient_like_gradscaler(scaled):
+    """reference trainers/averaging.py:61, 205-223 (amp.GradScaler: unscale_ -> clip -> step -> update -> zero_grad -> ema.update): a non-finite
+    gradient ANYWHERE cancels the optimizer step -- every weight and momentum buffer keeps its bits, the gradients are zeroed, the EMA lerp still
+    runs -- the scale backs off, and the next step is an ordinary one. Six steps with inf / NaN injected into different tensors at steps 1, 2 and 4,
+    against oracle/optim.py (whose scaler restatement is pinned to torch's own GradScaler on the CPU, tests/test_oracle_golden.py). `scaled`: the
+    fp16 plans' loss scaling (gradients arrive multiplied by the scale; growth every 2 good steps here) / the bf16 plans' fixed scale 1."""
+    import ctypes as C
+
+    from cerberusdet_amd import _lib as L
+    from oracle import optim as oo
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(19)
+    keys = ["blocks.0.model.0.conv.weight", "blocks.0.model.0.bn.weight", "blocks.0.model.0.bn.bias", "blocks.3.cv1.conv.weight"]
+    shapes = [(16, 3, 3, 3), (16,), (16,), (64, 32, 3, 3)]
+    w = {k: torch.randn(s, generator=g) for k, s in zip(keys, shapes)}
+    ema = {k: v.clone() + 0.1 for k, v in w.items()}
+    serving = {0: 2, 3: 1}
+    lrs = (0.01, 0.02, 0.03)
+    wd = {k: w[k].clone().to(DEV) for k in keys}
+    gd = {k: torch.zeros_like(wd[k]) for k in keys}
+    md = {k: torch.zeros_like(wd[k]) for k in keys}
+    ed = {k: ema[k].clone().to(DEV) for k in keys}
+    interval = 2 if scaled else 0
+    ref_sc = oo.GradScalerState(scale=65536.0 if scaled else 1.0, growth_interval=interval)
+    sc_dev = torch.tensor([ref_sc.scale, 0.0, 0.0, 0.0], device=DEV)
+    mom_ref, upd = {}, 0
+    wref, eref = {k: v.clone() for k, v in w.items()}, {k: v.clone() for k, v in ema.items()}
+    poison = {1: (keys[3], float("inf")), 2: (keys[1], float("nan")), 4: (keys[0], float("-inf"))}
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(6):
+        gr = {k: torch.randn(s, generator=g) * 3 * ref_sc.scale for k, s in zip(keys, shapes)}  # scaled gradients, as the backward leaves them
+        if step in poison:
+            k_, v_ = poison[step]
+            gr[k_].view(-1)[7] = v_
+        for k in keys:
+            gd[k].copy_(gr[k])
+        slots = (L.ParamSlot * len(keys))()
+        for i, k in enumerate(keys):
+            grp = oo.param_group(k)
+            slots[i].p, slots[i].g, slots[i].mom, slots[i].ema = wd[k].data_ptr(), gd[k].data_ptr(), md[k].data_ptr(), ed[k].data_ptr()
+            slots[i].n, slots[i].group = wd[k].numel(), grp
+            slots[i].weight_decay = 0.00037 if grp == 0 else 0.0
+            slots[i].inv_div, slots[i].first_step = 1.0 / serving[oo.block_of(k)], int(step == 0)
+        sdev = torch.frombuffer(bytearray(bytes(slots)), dtype=torch.uint8).to(DEV)
+        out = torch.zeros(1 + 32 * len(keys), device=DEV)
+        before_w = {k: wd[k].clone() for k in keys}
+        before_m = {k: md[k].clone() for k in keys}
+        scp = sc_dev.data_ptr() if scaled else None
+        L.check(lib.cdet_grad_sqnorm(sdev.data_ptr(), len(keys), out.data_ptr(), scp, st))
+        d = oo.ema_decay(upd + 1)
+        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d, scp, st))
+        L.check(lib.cdet_scaler_update(sc_dev.data_ptr(), out.data_ptr(), 2.0, 0.5, interval, st))
+        torch.cuda.synchronize()
+        total = oo.optimizer_step(wref, {k: v.clone() for k, v in gr.items()}, mom_ref, serving, lr=lrs, momentum=0.952, weight_decay=0.00037,
+                                  scaler=ref_sc)
+        upd = oo.ema_update(eref, wref, upd)
+        for k in keys:
+            assert float(gd[k].abs().max()) == 0.0, "zero_grad() happens on a skipped step too"
+            if step in poison:
+                assert torch.equal(wd[k], before_w[k]) and torch.equal(md[k], before_m[k]), f"step {step}: {k} moved on a skipped step"
+            _close(wd[k], wref[k], 1e-5, 1e-6)
+            _close(ed[k], eref[k], 1e-5, 1e-6)
+            if k in mom_ref:
+                _close(md[k], mom_ref[k], 1e-5, 1e-6)
+        if step in poison:
+            assert not math.isfinite(float(out[0])) and not math.isfinite(total)
+        else:
+            assert abs(math.sqrt(float(out[0])) - total) < 1e-3 * total
+        scv = sc_dev.tolist()
+        assert scv[0] == ref_sc.scale and int(scv[1]) == ref_sc.growth_tracker and int(scv[2]) == ref_sc.skipped and bool(scv[3]) == (step in poison), (step, scv)
+    assert ref_sc.skipped == 3 and all(bool(torch.isfinite(wd[k]).all()) and bool(torch.isfinite(ed[k]).all()) for k in keys)
 
 
 def test_pack_weights_batched_equals_per_item_pack():

@@ -97,6 +97,21 @@ CONV = [
 @pytest.mark.parametrize("shape", CONV)
 @pytest.mark.parametrize("form", ["train", "eval"])
 def test_stride1_conv_reproduces_its_bits_under_contention(shape, form, hog):
+    _stride1_case(shape, form, hog)
+
+
+@pytest.mark.parametrize("shape", [(40, 40, 320, 320, 3), (80, 80, 160, 160, 3), (80, 80, 320, 320, 3), (40, 40, 640, 320, 3)])
+@pytest.mark.parametrize("pp", [0, 2])
+def test_ping_pong_and_four_wave_forms_reproduce_their_bits_under_contention(shape, pp, hog, sw):
+    """Round 6, csrc/conv_pp.hip: the 8-wave ping-pong form shares ONE weight ring between two pixel tiles whose groups read every tile one phase
+    apart, with one counted wait per phase -- exactly the kind of wait a quiet GPU forgives. conv_pp = 2 takes it on every 3x3 / 160-cout shape
+    (by default only single-round grids do), 0 pins the 4-wave form on the shapes that now default to the ping-pong one."""
+    sw("CDET_CONV_PP", pp)
+    for form in ("train", "eval"):
+        _stride1_case(shape, form, hog)
+
+
+def _stride1_case(shape, form, hog):
     ops = _ops()
     from cerberusdet_amd import _lib as L
 

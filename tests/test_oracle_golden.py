@@ -347,3 +347,34 @@ def test_train_wc_fixture_oracle_matches_reference_and_is_well_conditioned():
             elif k.startswith(f"B/it{it}/ema/"):
                 name = k[len(f"B/it{it}/ema/"):]
                 assert rel_err(synth.sample(ema[name].numpy()), arrays[k]) < 1e-4, (it, name)
+
+
+def test_gradscaler_restatement_matches_torchs_own_gradscaler():
+    """oracle/optim.py::GradScalerState against torch.amp.GradScaler itself (the class the reference instantiates, trainers/averaging.py:61), on
+    the CPU: the scale schedule over a pattern of good and inf / NaN steps, and the parameter -- stepped on the good steps only."""
+    import torch
+
+    from oracle import optim as oo
+
+    sc = torch.amp.GradScaler("cpu", init_scale=65536.0, growth_interval=3)
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.SGD([p], lr=0.1)
+    o = oo.GradScalerState(growth_interval=3)
+    q = torch.ones(4)
+    pattern = [0, 0, 1, 0, 0, 0, 0, 2, 1, 0, 0, 0, 0, 0, 0]
+    for bad in pattern:
+        c = torch.tensor([1.0, 2.0, 3.0, 4.0])
+        cb = c.clone()
+        if bad:
+            cb[3] = float("inf") if bad == 1 else float("nan")
+        opt.zero_grad()
+        sc.scale((p * cb).sum()).backward()
+        sc.unscale_(opt)
+        sc.step(opt)
+        sc.update()
+        o.update(bool(bad))
+        if not bad:
+            q = q - 0.1 * c
+        assert sc.get_scale() == o.scale
+        assert torch.allclose(p.data, q, rtol=0, atol=1e-6)  # (stepped on the good steps only)
+    assert o.skipped == 3 and o.scale == 65536.0

@@ -9,7 +9,7 @@ mkdir -p $OUT/obj
 SRCS=$(sed -n 's/^SRCS *= *//p' Makefile)
 for s in $SRCS; do
   f=${s%.hip}
-  if [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ] || [ common.h -nt $OUT/obj/$f.o ] || [ halo_common.h -nt $OUT/obj/$f.o ] || [ wgrad_tr.h -nt $OUT/obj/$f.o ] || [ bn_fold.h -nt $OUT/obj/$f.o ]; then
+  if [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ] || [ common.h -nt $OUT/obj/$f.o ] || [ switches.h -nt $OUT/obj/$f.o ] || [ halo_common.h -nt $OUT/obj/$f.o ] || [ wgrad_tr.h -nt $OUT/obj/$f.o ] || [ bn_fold.h -nt $OUT/obj/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -Wno-unused-lambda-capture -DCDET_PROFILING $EXTRA -c $f.hip -o $OUT/obj/$f.o &
   fi
 done

@@ -56,15 +56,29 @@ def main():
     fn(None)
     t = buf.cpu().numpy().reshape(nblk, 8).astype(np.int64)
     assert (t[:, 3] > 0).all(), "no records: not a ping-pong launch (or not the profiling build)"
-    t0 = t[:, 0].min()
-    nsteps = ((ci + 31) // 32) * 9
-    pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-    print(f"shape {(H, W, ci, co)} mode {a.mode}: {nblk} workgroups, launch {e0.elapsed_time(e1) * 1e3:.1f} us (instrumented), span {(t[:, 3] - t0).max()} clocks")
-    print(f"per workgroup (median clocks): prologue {np.median(pro):.0f}  loop {np.median(loop):.0f} ({np.median(loop) / nsteps:.0f} per K step = two phases)  epilogue {np.median(epi):.0f}")
-    print(f"start spread: last workgroup starts {(t[:, 0] - t0).max()} clocks after the first; end spread {(t[:, 3].max() - t[:, 3].min())}")
-    print(f"group 0 / wave 0, mean per phase: memory body {np.median(t[:, 4]) / nsteps:.0f}, memory phase to release {np.median(t[:, 5]) / nsteps:.0f}, "
-          f"compute phase to release {np.median(t[:, 6]) / nsteps:.0f} clocks (640 = 20 MFMAs)")
     xcc = t[:, 7] & 0xf
+    nsteps = ((ci + 31) // 32) * 9
+    # s_memtime counters of different XCCs are not synchronised: every time is taken relative to the first start on the workgroup's own XCC
+    t0 = np.zeros(nblk, dtype=np.int64)
+    for xc in range(8):
+        m = xcc == xc
+        if m.any():
+            t0[m] = t[m, 0].min()
+    st, lo, ep, en = (t[:, i] - t0 for i in range(4))
+    pro, loop, epi = lo - st, ep - lo, en - ep
+    print(f"shape {(H, W, ci, co)} mode {a.mode}: {nblk} workgroups, launch {e0.elapsed_time(e1) * 1e3:.1f} us (event-timed, this build), span per XCC (max end) {[int(en[xcc == xc].max()) for xc in range(8) if (xcc == xc).any()]}")
+    print(f"per workgroup clocks  (min / median / max): start {st.min()}/{int(np.median(st))}/{st.max()}  prologue {pro.min()}/{int(np.median(pro))}/{pro.max()}  "
+          f"loop {loop.min()}/{int(np.median(loop))}/{loop.max()} ({np.median(loop) / nsteps:.0f} per K step)  epilogue {epi.min()}/{int(np.median(epi))}/{epi.max()}  end {en.min()}/{int(np.median(en))}/{en.max()}")
+    if t[:, 6].max() == 0:  # no per-phase stamps: slots 4 / 5 hold s_memrealtime (100 MHz, chip-wide) at the workgroup's start and end
+        r0 = t[:, 4].min()
+        rs, re_ = (t[:, 4] - r0) / 100.0, (t[:, 5] - r0) / 100.0
+        print(f"chip-wide clock (us after the first workgroup's start): starts min/median/max {rs.min():.2f}/{np.median(rs):.2f}/{rs.max():.2f}   "
+              f"ends {re_.min():.2f}/{np.median(re_):.2f}/{re_.max():.2f}   workgroup life median {np.median(re_ - rs):.2f} us = {np.median(en - st) / np.median(re_ - rs) / 1e3:.2f} GHz of s_memtime")
+        order = np.argsort(rs)
+        print("  start times (us) of every 20th workgroup in start order:", [round(float(rs[i]), 2) for i in order[::20]])
+    else:
+        print(f"group 0 / wave 0, mean per phase: memory body {np.median(t[:, 4]) / nsteps:.0f}, memory phase to release {np.median(t[:, 5]) / nsteps:.0f}, "
+              f"compute phase to release {np.median(t[:, 6]) / nsteps:.0f} clocks (640 = 20 MFMAs; the stamps stretch the phases)")
     print("workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
 
 
