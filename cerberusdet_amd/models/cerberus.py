@@ -372,7 +372,7 @@ class CerberusDet(nn.Module):
             if type(m) is Conv:
                 m.fuse_()
         self.mark_weights_changed()
-        self._plans = {}
+        self._drop_plans()
         return self
 
     def mark_weights_changed(self):
@@ -453,8 +453,17 @@ class CerberusDet(nn.Module):
                 m.num_batches_tracked += n
                 m._nbt_pending = 0
 
+    def _drop_plans(self):
+        """Forget every compiled plan. Plans register their argument lists on the modules (`_plan_slots`, re-bound by every weight pack): release()
+        unregisters them -- dropping the dict alone left dead (kind, slot) entries behind for every dtype switch."""
+        for plan in list(getattr(self, "_plans", {}).values()):
+            rel = getattr(plan, "release", None)
+            if rel is not None:
+                rel()
+        self._plans = {}
+
     def _apply(self, fn, *a, **k):
-        self._plans = {}  # device / dtype moves invalidate every pre-bound pointer
+        self._drop_plans()  # device / dtype moves invalidate every pre-bound pointer
         self._pgrad = {}
         self.__dict__.pop("_anchor", None)
         for m in self.modules():
@@ -470,13 +479,13 @@ class CerberusDet(nn.Module):
         only the compute/storage dtype of activations and packed weights switches to fp16."""
         if self.compute_dtype != torch.float16:
             self.compute_dtype = torch.float16
-            self._plans = {}
+            self._drop_plans()
         return self
 
     def bfloat16(self):
         if self.compute_dtype != torch.bfloat16:
             self.compute_dtype = torch.bfloat16
-            self._plans = {}
+            self._drop_plans()
         return self
 
     def float(self):
@@ -491,7 +500,7 @@ class CerberusDet(nn.Module):
         `loss.backward()` accumulates into the parameters' fp32 `.grad`; trainers.Averaging runs such a model as sequential task passes."""
         if self.compute_dtype != torch.float32:
             self.compute_dtype = torch.float32
-            self._plans = {}
+            self._drop_plans()
         return self
 
     def set_task(self, task_id):
@@ -582,7 +591,10 @@ class CerberusDet(nn.Module):
         """The cached PrecisePlan of (tasks, image shape / dtype, mode) of a full_precision() model."""
         from ..precise import PrecisePlan
 
-        key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision", bool(training))
+        # (train plans are compiled for the CURRENT set of trainable parameters -- frozen ones get no gradient and cut the data-gradient chain,
+        #  precise.PrecisePlan -- so the mask is part of the key: freeze_shared_layers / unfreeze_shared_layers select different plans)
+        mask = hash(tuple(p.requires_grad for p in super().parameters())) if training else 0
+        key = (tuple(tasks), tuple(x.shape), x.dtype, False, torch.float32, "full_precision", mask, bool(training))
         plan = self._plans.pop(key, None)
         if plan is None:
             cap = int(os.environ.get("CDET_MAX_EVAL_PLANS", "6"))

@@ -108,6 +108,11 @@ class PrecisePlan:
         self._scratch: Optional[torch.Tensor] = None
         self._scratch_elems = 0
         self._late: List = []
+        # frozen parameters (reference models/cerberus.py:885-925 freeze_shared_layers: requires_grad False, no gradient at all): no weight / gamma /
+        # beta / bias gradient is computed for them, and a map none of whose producers has a trainable parameter carries no gradient buffer -- the
+        # data-gradient chain stops above an all-frozen trunk, as engine.Plan does for the 16-bit plans (`frozen`). The mask is part of the plan's
+        # cache key (models/cerberus.py::full_precision_plan).
+        self._rg = True
         self.feats: Dict[str, List[torch.Tensor]] = {}
         self.y: Dict[str, torch.Tensor] = {}
         self._img: List[Optional[torch.Tensor]] = [None]
@@ -178,7 +183,8 @@ class PrecisePlan:
             else:
                 dpath, dfn, rec.ddesc = "generic", lib.cdet_conv2d, _acc(conv_desc(dzv, dxv, k, s, L.CONV_DGRAD))
         rec.dfn, rec.dpath = dfn, dpath
-        if self.training:
+        rec.want_dw = bool(self.training and weight.requires_grad)
+        if rec.want_dw:
             wd = conv_desc(xv, _GeomView(x.N, Ho, Wo, Op, torch.bfloat16), k, s)
             wd.Cd = Op
             rec.wdesc = wd
@@ -221,10 +227,11 @@ class PrecisePlan:
         """dW (+= into weight.grad) and dX (+= into grad(x)) of one convolution from the three terms of dz [N, Ho, Wo, Op] (pad channels zero)."""
         lib, x = self.lib, rec.x
         st = stream()
-        for n_, (i, j) in enumerate(_PAIRS):   # dW = sum over term pairs x_i (x) dz_j
-            L.check(lib.cdet_conv2d_wgrad(C.byref(rec.wdesc), x.s[i].data_ptr(), dz_terms[j].data_ptr(), rec.dw.data_ptr(), self._wg_ws.data_ptr(),
-                                          1 if n_ > 0 else 0, st), "precise weight gradient")
-        _grad_of(rec.weight).add_(rec.dw[:rec.O, :rec.Ci])
+        if rec.want_dw:  # (a frozen weight gets no gradient: the reference leaves .grad None on requires_grad=False parameters)
+            for n_, (i, j) in enumerate(_PAIRS):   # dW = sum over term pairs x_i (x) dz_j
+                L.check(lib.cdet_conv2d_wgrad(C.byref(rec.wdesc), x.s[i].data_ptr(), dz_terms[j].data_ptr(), rec.dw.data_ptr(), self._wg_ws.data_ptr(),
+                                              1 if n_ > 0 else 0, st), "precise weight gradient")
+            _grad_of(rec.weight).add_(rec.dw[:rec.O, :rec.Ci])
         if rec.need_dx:
             # dX += conv(dz_i, W_j^T): every launch accumulates (other consumers of x may have written already). The three entry points -- tiled kernel on the
             # DGRAD operand, stride-2 parity-class kernel, generic kernel in DGRAD mode -- share one argument list
@@ -248,7 +255,7 @@ class PrecisePlan:
                 raise RuntimeError("training needs un-fused Conv modules (BatchNorm present)")
             bn, lib, M = m.bn, self.lib, self.N * Ho * Wo
             self.bns.append(bn)
-            self._gparams += [bn.weight, bn.bias]
+            self._gparams += [p_ for p_ in (bn.weight, bn.bias) if p_.requires_grad]
             mean = torch.empty(m.c2, dtype=torch.float32, device=self.device)
             invstd = torch.empty(m.c2, dtype=torch.float32, device=self.device)
             self._ws_doubles = max(self._ws_doubles, int(lib.cdet_bn_train_f32_ws_doubles(m.c2)))
@@ -266,13 +273,16 @@ class PrecisePlan:
 
             def backward():
                 st = stream()
-                if res is not None:   # y = res + SiLU(...): the shortcut takes grad(y) as it is (models/common.py:107-117)
+                if res is not None and res.g is not None:   # y = res + SiLU(...): the shortcut takes grad(y) as it is (models/common.py:107-117)
                     L.check(lib.cdet_add_f32(y.g.data_ptr(), y.ld, y.coff, res.g.data_ptr(), res.ld, res.coff, y.N, y.H, y.W, y.C, 0, 1, st), "cdet_add_f32")
                 L.check(lib.cdet_bn_silu_bwd_f32(y.g.data_ptr(), y.ld, y.coff, rec.z.data_ptr(), Op, scale.data_ptr(), bias.data_ptr(), mean.data_ptr(),
-                                                 invstd.data_ptr(), M, m.c2, self._ws.data_ptr(), _grad_of(bn.weight).data_ptr(), _grad_of(bn.bias).data_ptr(),
+                                                 invstd.data_ptr(), M, m.c2, self._ws.data_ptr(),
+                                                 _grad_of(bn.weight).data_ptr() if bn.weight.requires_grad else None,
+                                                 _grad_of(bn.bias).data_ptr() if bn.bias.requires_grad else None,
                                                  None, dz[0].data_ptr(), dz[1].data_ptr(), dz[2].data_ptr(), Op, st), "cdet_bn_silu_bwd_f32")
                 self._conv_backward(rec, dz)
-            self.bwd.append(backward)
+            if y.g is not None:  # (None: neither this layer nor anything above it trains -- the backward never comes here)
+                self.bwd.append(backward)
         else:
             def pack():
                 if getattr(m, "fused", False):
@@ -289,7 +299,7 @@ class PrecisePlan:
     # ------------------------------------------------------------------------------------------------ layers
     def _new(self, H, W, Cn, terms=True, value=True) -> Map:
         m = Map.new(self.N, H, W, Cn, self.device, terms, value)
-        if self.training:
+        if self.training and self._rg:  # (no trainable parameter at or above this layer: nothing would ever read the gradient)
             m.g = torch.zeros((self.N, H, W, m.ld), dtype=torch.float32, device=self.device)
             self._grads.append(m.g)
         return m
@@ -301,7 +311,8 @@ class PrecisePlan:
         def backward():
             L.check(lib.cdet_add_f32(src.g.data_ptr(), src.ld, src.coff, dst.g.data_ptr(), dst.ld, dst.coff, dst.N, dst.H, dst.W, dst.C, int(down), 1, stream()),
                     "cdet_add_f32")
-        self.bwd.append(backward)
+        if src.g is not None and dst.g is not None:
+            self.bwd.append(backward)
 
     def _copy_into(self, src: Map, dst: Map, up=False):
         """dst slice <- src (value and terms), optionally through the nearest 2x upsample."""
@@ -311,6 +322,14 @@ class PrecisePlan:
             self._add_grad(dst, src, down=up)
 
     def _layer(self, m, xs: List[Map]) -> Map:
+        # does anything at or above this layer train? (inputs that carry a gradient buffer, or a trainable parameter of the layer itself)
+        self._rg = any(getattr(v.src if isinstance(v, _Up) else v, "g", None) is not None for v in xs) or any(p_.requires_grad for p_ in m.parameters())
+        try:
+            return self._layer_body(m, xs)
+        finally:
+            self._rg = True
+
+    def _layer_body(self, m, xs: List[Map]) -> Map:
         if isinstance(m, Conv):
             x = xs[0]
             y = self._new((x.H + 2 * (m.k // 2) - m.k) // m.s + 1, (x.W + 2 * (m.k // 2) - m.k) // m.s + 1, m.c2)
@@ -343,7 +362,7 @@ class PrecisePlan:
                                                  stream()), "cdet_maxpool_f32")
                 self.steps.append(run)
                 self.counts["pool"] += 1
-                if self.training:
+                if self.training and a.g is not None:
                     def pool_bwd(a=a, b=b):
                         L.check(lib.cdet_maxpool_bwd_f32(a.fptr(), a.ld, a.coff, b.g.data_ptr(), b.ld, b.coff, a.g.data_ptr(), a.ld, a.coff, a.N, a.H, a.W, a.C,
                                                          m.k, stream()), "cdet_maxpool_bwd_f32")
@@ -390,7 +409,8 @@ class PrecisePlan:
                 self.packs.append(lambda pb=pb, proj=proj: pb.copy_(proj.bias.detach().float()))
                 self._epilogue(rec, None, lambda pb=pb: pb.data_ptr(), L.ACT_NONE, None, fb.slice(off, cn))
                 if self.training:
-                    self._gparams.append(proj.bias)
+                    if proj.bias.requires_grad:
+                        self._gparams.append(proj.bias)
                     dz = [torch.zeros((self.N, xl.H, xl.W, rec.Op), dtype=torch.bfloat16, device=self.device) for _ in range(3)]
                     M = self.N * xl.H * xl.W
 
@@ -399,7 +419,8 @@ class PrecisePlan:
                         # the projection has no BatchNorm: dz IS the head map's gradient (its channel slice), split into terms; db = its column sums
                         L.check(lib.cdet_split3(df.data_ptr(), L.F32, df.shape[3], off, 0, 0, None, dz[0].data_ptr(), dz[1].data_ptr(), dz[2].data_ptr(), rec.Op, 0,
                                                 self.N, H, W, cn, st), "cdet_split3")
-                        L.check(lib.cdet_colsum_f32(df.data_ptr(), df.shape[3], off, M, cn, self._ws.data_ptr(), _grad_of(proj.bias).data_ptr(), st), "cdet_colsum_f32")
+                        if proj.bias.requires_grad:
+                            L.check(lib.cdet_colsum_f32(df.data_ptr(), df.shape[3], off, M, cn, self._ws.data_ptr(), _grad_of(proj.bias).data_ptr(), st), "cdet_colsum_f32")
                         self._conv_backward(rec, dz)
                     self.bwd.append(backward)
             feats.append(fb.f)
@@ -495,7 +516,7 @@ class _GeomView:
 class _ConvRec:
     """What one convolution of the plan leaves for its epilogue and its backward."""
 
-    __slots__ = ("x", "xC", "Op", "O", "Ci", "k", "s", "Ho", "Wo", "weight", "z", "need_dx", "dfn", "dpath", "ddesc", "wdesc", "dw", "packed_d")
+    __slots__ = ("x", "xC", "Op", "O", "Ci", "k", "s", "Ho", "Wo", "weight", "z", "need_dx", "dfn", "dpath", "ddesc", "wdesc", "dw", "packed_d", "want_dw")
 
 
 def _acc(d):

@@ -114,6 +114,13 @@ def comm_span(model, kind: str):
     return t.span(kind) if t is not None else _NoSpan()
 
 
+def _block_of(key: str) -> int:
+    """Block index of a state-dict key 'blocks.<i>. ...'; -1 (= the optimizer's tail) for anything else, e.g. a floating-point buffer registered on
+    the model itself -- such EMA-only slots must not break the trainer's construction."""
+    parts = key.split(".")
+    return int(parts[1]) if len(parts) > 2 and parts[0] == "blocks" and parts[1].isdigit() else -1
+
+
 class GradReducer:
     """Bucketed gradient all-reduce keyed on the block DAG. One flat fp32 bucket per block, sent as REDUCTION UNITS: the slices that become
     final at one point of the backward -- every backbone row of block 0, every other block as a whole. A unit is reduced (SUM, async) when the
@@ -203,7 +210,7 @@ class Averaging:
         names = dict(model.named_parameters())
         ema_sd = self.ema.ema.state_dict() if self.ema else {}
         self.slots_meta = []
-        model._plans = {}  # plans pre-bind gradient pointers: compile them after the buckets below exist
+        model._drop_plans()  # plans pre-bind gradient pointers: compile them after the buckets below exist
         buckets: Dict[int, torch.Tensor] = {}
         for bi, block in enumerate(model.blocks):
             ps = list(block.parameters())  # frozen parameters get a (zero) bucket slice too: they may be unfrozen later
@@ -245,17 +252,27 @@ class Averaging:
         alt_of = {}
         for flat, alt in model._alt_pairs:
             alt_of.setdefault(flat.data_ptr(), []).append(alt)
+        self._row_alias: Dict[tuple, int] = {}
         for bi, flat in buckets.items():
             serving = list(self.serving.get(bi, ()))
             alts = list(zip(serving[1:], alt_of.get(flat.data_ptr(), [])))
             if bi == 0 and hasattr(model.blocks[0], "model"):
-                off = 0
+                off, rows = 0, []
                 for li, layer in enumerate(model.blocks[0].model):
                     n = sum(p.numel() for p in layer.parameters())
                     if n:
-                        self.units[(0, li)] = dict(block=0, main=flat[off:off + n], alts=[(t, a[off:off + n]) for t, a in alts], serving=serving)
+                        rows.append((li, off, n))
                     off += n
                 assert off == flat.numel(), "block 0's bucket is not the concatenation of its rows' parameters"
+                # the row units are slices of the bucket, folded with cdet_accumulate_clear, which wants 16-byte aligned pointers: true when every
+                # row holds a multiple of 4 floats (widths from make_divisible(8)). A model that breaks it keeps block 0 as ONE unit instead of
+                # raising from a hook in the middle of a backward
+                if all(o % 4 == 0 for _, o, _ in rows):
+                    for li, o, n in rows:
+                        self.units[(0, li)] = dict(block=0, main=flat[o:o + n], alts=[(t, a[o:o + n]) for t, a in alts], serving=serving)
+                else:
+                    self.units[0] = dict(block=0, main=flat, alts=alts, serving=serving)
+                    self._row_alias[(0, rows[0][0])] = 0  # (the backward finishes the rows last to first: the whole bucket is complete at row 0's mark)
             else:
                 self.units[bi] = dict(block=bi, main=flat, alts=alts, serving=serving)
         self._unit_events: Dict[tuple, "torch.cuda.Event"] = {}
@@ -264,7 +281,7 @@ class Averaging:
         self._fold_stream = None
         self.trace_cb = None
         for k, p in names.items():
-            bi = int(k.split(".")[1])
+            bi = _block_of(k)
             self.slots_meta.append(dict(p=p, g=model._pgrad[id(p)], mom=torch.zeros_like(p), ema=ema_sd.get(k), group=group_of[id(p)],
                                         div=max(len(self.serving[bi]), 1), key=k, stepped=False))
         if self.ema:
@@ -276,8 +293,8 @@ class Averaging:
         # table, so that the update can run as two launches -- the trunk's on the current stream, the rest on a side stream under the NEXT
         # iteration's trunk kernels (train_step(defer_tail=True)); every pass waits for the tail in front of its first block outside the trunk.
         self._early_blocks = frozenset(self._shared_blocks) if os.environ.get("CDET_LATE_PACK", "1") != "0" else frozenset()
-        self.slots_meta.sort(key=lambda m: 0 if int(m["key"].split(".")[1]) in self._early_blocks else 1)  # (stable: block order inside each half)
-        self.n_head_slots = sum(1 for m in self.slots_meta if int(m["key"].split(".")[1]) in self._early_blocks)
+        self.slots_meta.sort(key=lambda m: 0 if _block_of(m["key"]) in self._early_blocks else 1)  # (stable: block order inside each half)
+        self.n_head_slots = sum(1 for m in self.slots_meta if _block_of(m["key"]) in self._early_blocks)
         self._tail_stream = None
         self._tail_event = None
         self._tail_pending = False
@@ -327,6 +344,7 @@ class Averaging:
         touched again once it is sent. Task streams: the unit is complete when the LAST serving task's stream has enqueued it (host order is
         deterministic, hence the same on every rank) -- then, on a side stream behind all serving tasks' events, the per-task buckets are
         folded in task order and the slice is all-reduced there, while both backward passes run on."""
+        key = self._row_alias.get(key, key)
         u = self.units.get(key)
         if self.trace_cb is not None:
             self.trace_cb("unit", key, task)  # (bench.py --dry-comm: where in the host enqueue order the backward passes stand)
@@ -509,7 +527,7 @@ class Averaging:
         with comm_span(self.model, "grad_wait"):
             self.reducer.wait()
         idle = set(idle_blocks)
-        live = [m["g"] is not None and m["p"].requires_grad and int(m["key"].split(".")[1]) not in idle for m in self.slots_meta]
+        live = [m["g"] is not None and m["p"].requires_grad and _block_of(m["key"]) not in idle for m in self.slots_meta]
         fresh = sum(1 for m, a in zip(self.slots_meta, live) if a and not m.get("stepped", True))
         # (the learning rates are launch arguments, not table entries: the table is rebuilt only when its structure changes)
         key = (fresh, tuple(sorted(n_serving.items())) if n_serving else None, hash(tuple(live)))
@@ -523,7 +541,7 @@ class Averaging:
                 if m["group"] >= 0:
                     s.group = m["group"]
                     s.weight_decay = self.weight_decay if m["group"] == 0 else 0.0
-                    div = m["div"] if n_serving is None else max(n_serving.get(int(m["key"].split(".")[1]), 1), 1)
+                    div = m["div"] if n_serving is None else max(n_serving.get(_block_of(m["key"]), 1), 1)
                     s.inv_div = 1.0 / div
                 s.first_step = int(not m.get("stepped", True))  # momentum buffer starts as the first clipped gradient (torch SGD)
             self._slots_dev.copy_(torch.frombuffer(bytearray(bytes(self._slots_host)), dtype=torch.uint8), non_blocking=False)
