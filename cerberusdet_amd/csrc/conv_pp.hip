@@ -303,6 +303,14 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
             tp_prev = tq;
         }
 #endif
+#ifdef CDET_PROFILING
+        if ((ABL & 64) && g_pp_dbg != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 256) && st < 400) {
+            // ABL 64: one s_memtime stamp per K step at the start of the compute phase (wave 0 of each group of workgroup 0 only), parked in LDS behind the
+            // loop's buffers (an LDS store does not touch vmcnt) and copied out at the end
+            const unsigned long long tq2 = __builtin_readcyclecounter();
+            reinterpret_cast<unsigned long long*>(smem + HZERO + 4 * XHB + 3 * WTILE)[grp * 400 + st] = tq2;
+        }
+#endif
         // ---- compute phase ----
         __builtin_amdgcn_s_setprio(1);
         if (!(ABL & 4)) {
@@ -347,6 +355,12 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #ifdef CDET_PROFILING
     if (g_pp_dbg != nullptr && tid == 0) tp_epi = __builtin_readcyclecounter();
+    if ((ABL & 64) && g_pp_dbg != nullptr && blockIdx.x == 0) {  // the per-step stamps -> the record buffer behind the per-workgroup records
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(smem + HZERO + 4 * XHB + 3 * WTILE);
+        unsigned long long* dst = g_pp_dbg + (size_t)gridDim.x * 8;
+        for (int i = tid; i < 800; i += 512) dst[i] = src[i];
+        __syncthreads();
+    }
 #endif
 
     unsigned char* const esm = smem + grp * PP_EREG;  // the group's epilogue region (the loop's buffers are dead)
@@ -507,7 +521,7 @@ static void launch_pp(const PpArgs& a, size_t lds, int nblocks, hipStream_t s) {
         hipLaunchKernelGGL((conv_pp_kernel<DT, EPI, PATCH, N>), dim3(nblocks), dim3(512), lds, s, a);                                        \
         return;
         switch (abl) {
-            CDET_PPABL(1) CDET_PPABL(2) CDET_PPABL(3) CDET_PPABL(4) CDET_PPABL(5) CDET_PPABL(6) CDET_PPABL(7) CDET_PPABL(32)
+            CDET_PPABL(1) CDET_PPABL(2) CDET_PPABL(3) CDET_PPABL(4) CDET_PPABL(5) CDET_PPABL(6) CDET_PPABL(7) CDET_PPABL(32) CDET_PPABL(64)
             default: break;
         }
 #undef CDET_PPABL
@@ -547,6 +561,9 @@ int pp_launch(const cdet_conv_desc* d, bool patch, int XH, int n_pblk, const voi
     a.w_bytes = (unsigned)((int64_t)a.n_cblk * a.nchunk * 9 * 160 * HROW);
     size_t lds = (size_t)HZERO + 4 * (size_t)XH * HROW + 3 * (size_t)(160 * HROW);
     if (lds < 2 * (size_t)PP_EREG) lds = 2 * (size_t)PP_EREG;
+#ifdef CDET_PROFILING
+    lds = (size_t)HZERO + 4 * (size_t)XH * HROW + 3 * (size_t)(160 * HROW) + 8192 > lds ? (size_t)HZERO + 4 * (size_t)XH * HROW + 3 * (size_t)(160 * HROW) + 8192 : lds;  // (ABL 64: per-step stamps)
+#endif
     const bool full = scale || bias || residual || d->act != CDET_ACT_NONE;
     const int nblocks = a.n_ppair * a.n_cblk;
 #define CDET_PP_GO(DT_)                                                                      \

@@ -29,14 +29,14 @@ for z in ("rand", "zeros"):
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 m = re.search(r"cdet::([A-Za-z0-9_]+<[^>]*>|[A-Za-z0-9_]+)", r["Kernel_Name"])
-                if not m or not re.match(r"conv_halo|conv_pair|conv_vt|wgrad_halo", m.group(1)):
+                if not m or not re.match(r"conv_halo|conv_pp|conv_pair|conv_vt|wgrad_halo", m.group(1)):
                     continue
                 ctr[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if i == 1:
             for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
                     m = re.search(r"cdet::([A-Za-z0-9_]+<[^>]*>|[A-Za-z0-9_]+)", r["Kernel_Name"])
-                    if m and re.match(r"conv_halo|conv_pair|conv_vt|wgrad_halo", m.group(1)):
+                    if m and re.match(r"conv_halo|conv_pp|conv_pair|conv_vt|wgrad_halo", m.group(1)):
                         wall[m.group(1)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k in ctr:
         c = {n: sum(v[-6:]) / len(v[-6:]) for n, v in ctr[k].items()}

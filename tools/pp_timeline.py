@@ -43,7 +43,7 @@ def main():
         run()
     n_p = ops.conv_tiled_stat_blocks(src, y, k)
     nblk = ((n_p + 1) // 2) * ((co + 159) // 160)
-    buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nblk * 8 + 800, dtype=torch.int64, device=dev)
     fn = lib.cdet_debug_pp_timeline
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
     assert fn(buf.data_ptr()) == 0
@@ -54,7 +54,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     fn(None)
-    t = buf.cpu().numpy().reshape(nblk, 8).astype(np.int64)
+    raw = buf.cpu().numpy().astype(np.int64)
+    steps = raw[nblk * 8:].reshape(2, 400)
+    t = raw[:nblk * 8].reshape(nblk, 8)
     assert (t[:, 3] > 0).all(), "no records: not a ping-pong launch (or not the profiling build)"
     xcc = t[:, 7] & 0xf
     nsteps = ((ci + 31) // 32) * 9
@@ -79,6 +81,13 @@ def main():
     else:
         print(f"group 0 / wave 0, mean per phase: memory body {np.median(t[:, 4]) / nsteps:.0f}, memory phase to release {np.median(t[:, 5]) / nsteps:.0f}, "
               f"compute phase to release {np.median(t[:, 6]) / nsteps:.0f} clocks (640 = 20 MFMAs; the stamps stretch the phases)")
+    if steps[0, 1] > 0:  # CDET_PP_ABLATE=64: per-step stamps of workgroup 0 (start of every compute phase, wave 0 of group 0 / group 1)
+        for gi in (0, 1):
+            d = np.diff(steps[gi, :nsteps])
+            print(f"workgroup 0, group {gi}: clocks per K step (compute-phase start to compute-phase start): first 12 {d[:12].tolist()}  median {int(np.median(d))}  "
+                  f"last 6 {d[-6:].tolist()}  max {int(d.max())} at step {int(d.argmax())}; every 9th (chunk boundaries) median {int(np.median(d[8::9]))}")
+        print(f"  group 1 lags group 0 by (clocks) first / median / last: {int(steps[1, 0] - steps[0, 0])} / {int(np.median(steps[1, :nsteps] - steps[0, :nsteps]))} / {int(steps[1, nsteps - 1] - steps[0, nsteps - 1])}")
+        print(f"  loop start -> first compute phase {int(steps[0, 0] - t[0, 1])} clocks; last compute-phase start -> epilogue stamp {int(t[0, 2] - steps[0, nsteps - 1])}")
     print("workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
 
 
