@@ -818,7 +818,7 @@ def main():
             if tf:
                 kern = json.load(open(tf[-1]))["kernels"]
                 fam = [f"conv_igemm_{v}_kernel<0, {t}" for v in ("pipe", "glds") for t in ("2, 2", "3, 1", "4, 2")]
-                main, extra = {"conv_halo_kernel": (("conv_halo_kernel", "conv_pair_kernel"), ()),  # (the entry point's 1x1 layers with K >= 640 run the pair tile)
+                main, extra = {"conv_halo_kernel": (("conv_halo_kernel", "conv_pair_kernel", "conv_pp_kernel"), ()),  # (the entry point's 1x1 layers with K >= 640 run the pair tile, its single-round 3x3 / 160-cout layers the 8-wave ping-pong form)
                                "cdet_conv2d_wgrad": (("wgrad_halo_kernel", "conv_wgrad_pipe_kernel", "conv_wgrad_kernel"), ("wgrad_reduce",)),
                                "cdet_conv2d[fwd]": (tuple(f"{f}, 0," for f in fam), ()),
                                "cdet_conv2d[dgrad]": (tuple(f"{f}, {m}," for f in fam for m in (1, 2)), ())}[dom]
