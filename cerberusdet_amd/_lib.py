@@ -187,7 +187,7 @@ _SIGS = {
     "cdet_peer_allreduce": (i32, [vp, i32, vp, i32, i32, i64, i64, C.c_uint32, vp, i32, vp]),
     "cdet_grad_sqnorm": (i32, [vp, i32, vp, vp, vp]),
     "cdet_accumulate_clear": (i32, [vp, vp, i64, vp]),
-    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, C.POINTER(f32), i32, f32, f32, vp, vp]),
+    "cdet_sgd_ema_step": (i32, [vp, i32, vp, f32, C.POINTER(f32), i32, f32, f32, vp, vp, vp]),
     "cdet_scaler_update": (i32, [vp, vp, f32, f32, i32, vp]),
 }
 

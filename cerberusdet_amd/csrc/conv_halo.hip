@@ -75,7 +75,7 @@ __device__ unsigned long long* g_halo_dbg = nullptr;
 // stages (2 or 3). PATCH: the pixel tile is a 16 x 16 patch (halo 18 x 18 = 324 rows; maps whose sides are multiples of 16) instead
 // of 256 consecutive pixels (halo 256 + 2W + 2 rows) -- half the halo on the 80-wide maps, and the only form that fits for 160-wide.
 // ABL (timing experiments only, -DCDET_PROFILING): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no epilogue
-// stores, 16 = no K loop
+// stores, 16 = no K loop, 32 = plus the arithmetic of an in-LDS BatchNorm + SiLU rewrite of one pixel piece per K step (round-6 pricing experiment)
 // NG = 4 (round 5): the 512-pixel tile. ONE workgroup per CU, one wave per SIMD with all 512 registers of a lane: a wave owns 128 pixels x 160 couts =
 // 20 accumulator tiles (16 of them in AccVGPRs). Per k16 it reads (128 + 160) x 32 B of fragments for 20 MFMAs -- 461 B per MFMA against the 717 B of
 // the 64 x 160 wave tile -- and the workgroup's weight ring serves twice the pixels: LDS reads per FLOP -36 %, weight LDS-DMA per FLOP -50 %, one
@@ -483,6 +483,28 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((P
         t_wait += tw1 - tw0;
         t_bar += __builtin_readcyclecounter() - tw1;
 #endif
+        if ((ABL & 32) && NT == 9 && u >= 2) {
+            // PRICING EXPERIMENT (round 6, VERDICT r05 item 4, profiling builds only; results are wrong by design): what "normalise in LDS" would add to a K
+            // step -- the wave rewrites ONE of its pixel pieces per step in place: a ds_read_b128 (8 values of one pixel), scale / shift / SiLU
+            // (v_exp + v_rcp per value), pack, a ds_write_b128. Seven pieces per chunk = the 42 - 44 values per lane and chunk of the halo tile.
+            unsigned char* pp_ = smem + HZ + ((chunk + 1) & 1) * XHB + (4 * (u - 2) + wave) * 1024 + lane * 16;
+            u32x4 v4 = *reinterpret_cast<u32x4*>(pp_);
+            float f8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f8[2 * r] = Elem<DT>::to_f32((uint16_t)(v4[r] & 0xffff));
+                f8[2 * r + 1] = Elem<DT>::to_f32((uint16_t)(v4[r] >> 16));
+            }
+            const float ksc = 1.0009765625f + (float)(lane & 3) * 0.001f, ksh = 0.01f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float a_ = f8[r] * ksc + ksh;
+                f8[r] = a_ * __builtin_amdgcn_rcpf(1.0f + __expf(-a_));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = hpack2<DT>(f8[2 * r], f8[2 * r + 1]);
+            *reinterpret_cast<u32x4*>(pp_) = v4;
+        }
         // ---- phase B: MFMAs of (st, k16 #1); DMA of the tile NSW steps ahead into the stage just freed and the fragment reads of
         //      (st+1, k16 #0) in their shadow
 #pragma unroll
@@ -956,14 +978,14 @@ static void launch_halo(const HaloArgs& a, size_t lds, int nblocks, hipStream_t 
         abl = e ? atoi(e) : 0;
         if (abl) fprintf(stderr, "[cdet] CDET_HALO_ABLATE=%d: conv results are WRONG by design (timing experiment)\n", abl);
     }
-    if constexpr (DT == CDET_BF16 && NT == 9 && EPI == HEPI_FULL && NSW == 3 && NG == 2 && ((NF == 5 && !PATCH) || (NF == 3 && PATCH))) {
+    if constexpr (DT == CDET_BF16 && NT == 9 && EPI == HEPI_FULL && NSW == 3 && NG == 2 && (NF == 5 || (NF == 3 && PATCH))) {
 #define CDET_HABL(N)                                                                                                                                      \
     case N:                                                                                                                                                \
         (void)hipFuncSetAttribute((const void*)conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((conv_halo_kernel<DT, NT, NF, EPI, NSW, PATCH, NG, N>), dim3(nblocks), dim3(256), lds, s, a);                                       \
         return;
         switch (abl) {
-            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(7) CDET_HABL(8) CDET_HABL(15) CDET_HABL(16) CDET_HABL(24)
+            CDET_HABL(1) CDET_HABL(2) CDET_HABL(3) CDET_HABL(4) CDET_HABL(7) CDET_HABL(8) CDET_HABL(15) CDET_HABL(16) CDET_HABL(24) CDET_HABL(32)
             default: break;
         }
 #undef CDET_HABL

@@ -73,7 +73,8 @@ struct GroupLr {
 // and momentum buffers keep their bits, the gradients are zeroed, and the EMA lerp still runs (the reference calls ema.update regardless). The norm
 // is the found-inf flag: inf^2 = inf and NaN propagate through the fixed-order sum of cdet_grad_sqnorm.
 __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __restrict__ slots, const float* __restrict__ sqnorm, float max_norm,
-                                                      GroupLr lrs, float momentum, float ema_decay, const float* __restrict__ scaler) {
+                                                      GroupLr lrs, float momentum, float ema_decay, const float* __restrict__ scaler,
+                                                      float* __restrict__ skip_count) {
     const cdet_param_slot sl = slots[blockIdx.y];
     const float lr = lrs.v[sl.group & 3];
     float coef = 1.f;
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(const cdet_param_slot* __r
         coef = fminf(max_norm / (total + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
     }
     if (scaler) coef *= 1.f / scaler[0];                // scaler.unscale_ (a power of two: exact)
+    if (skip_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {  // plans without loss scaling: the skip bookkeeping rides on this launch
+        skip_count[1] = skip ? 1.f : 0.f;                                        // (nothing in the launch reads these two words)
+        if (skip) skip_count[0] += 1.f;
+    }
     if (skip) {
         // found_inf: p and the momentum buffer are not touched; optimizer.zero_grad() and ema.update(model) still happen
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sl.n; i += (int64_t)gridDim.x * 256) {
@@ -203,12 +208,12 @@ extern "C" int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slot
 }
 
 extern "C" int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm, const float* lrs,
-                                 int32_t n_groups, float momentum, float ema_decay, const float* scaler, void* stream) {
+                                 int32_t n_groups, float momentum, float ema_decay, const float* scaler, float* skip_count, void* stream) {
     CDET_CHECK_ARG(slots_dev && n_slots > 0 && lrs && n_groups >= 1 && n_groups <= 4, "cdet_sgd_ema_step: bad arguments");
     GroupLr gl{{0.f, 0.f, 0.f, 0.f}};
     for (int i = 0; i < n_groups; ++i) gl.v[i] = lrs[i];
     hipLaunchKernelGGL(sgd_ema_kernel, dim3(tune_env("CDET_OPT_BLOCKS", OPT_SGD_BLOCKS), n_slots), dim3(256), 0, (hipStream_t)stream, slots_dev, sqnorm,
-                       max_norm, gl, momentum, ema_decay, scaler);
+                       max_norm, gl, momentum, ema_decay, scaler, skip_count);
     CDET_LAUNCH_CHECK();
     return 0;
 }

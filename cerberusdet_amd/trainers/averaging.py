@@ -562,22 +562,24 @@ class Averaging:
             self.ema.updates += 1
             d = self.ema.decay(self.ema.updates)
         lr_arr = (C.c_float * len(lrs))(*[float(v) for v in lrs])
+        # (without loss scaling the skip bookkeeping -- skipped-step counter, found_inf flag = words 2, 3 of the state -- rides on the update launch itself)
+        cnt = None if self.loss_scaling else self._scaler.data_ptr() + 8
         L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr(), n_head, self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs),
-                                           float(momentum), float(d), sc, st), "cdet_sgd_ema_step")
+                                           float(momentum), float(d), sc, cnt, st), "cdet_sgd_ema_step")
         if n_head < self.n_slots:
             # the tail: the same kernel over the slots of the unshared blocks, on a side stream behind the clipping norm -- it runs under the next
             # iteration's trunk (HBM-bound update beside MFMA-bound convolutions); same arithmetic per slot, same results
             ts = self._tail_stream
             ts.wait_event(self._norm_event)
             L.check(self.lib.cdet_sgd_ema_step(self._slots_dev.data_ptr() + n_head * C.sizeof(L.ParamSlot), self.n_slots - n_head,
-                                               self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs), float(momentum), float(d), sc, ts.cuda_stream),
+                                               self._norm_buf.data_ptr(), 10.0, lr_arr, len(lrs), float(momentum), float(d), sc, None, ts.cuda_stream),
                     "cdet_sgd_ema_step")
-            # scaler.update() behind BOTH update launches (the tail reads the old scale too)
-            L.check(self.lib.cdet_scaler_update(self._scaler.data_ptr(), self._norm_buf.data_ptr(), self.scaler_growth, self.scaler_backoff,
-                                                self.scaler_interval, ts.cuda_stream), "cdet_scaler_update")
+            if self.loss_scaling:  # scaler.update() behind BOTH update launches (the tail reads the old scale too)
+                L.check(self.lib.cdet_scaler_update(self._scaler.data_ptr(), self._norm_buf.data_ptr(), self.scaler_growth, self.scaler_backoff,
+                                                    self.scaler_interval, ts.cuda_stream), "cdet_scaler_update")
             self._tail_event.record(ts)
             self._tail_pending = True
-        else:
+        elif self.loss_scaling:
             L.check(self.lib.cdet_scaler_update(self._scaler.data_ptr(), self._norm_buf.data_ptr(), self.scaler_growth, self.scaler_backoff,
                                                 self.scaler_interval, st), "cdet_scaler_update")
         if fresh:

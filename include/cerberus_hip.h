@@ -552,7 +552,9 @@ int cdet_grad_sqnorm(const cdet_param_slot* slots_dev, int32_t n_slots, float* o
  * lrs: HOST array of n_groups (<= 4) learning rates, passed by value with the launch -- the slot table does not change while the
  * warm-up / schedule moves the rates (trainers/averaging.py:160-180 of the reference recomputes them every iteration). */
 int cdet_sgd_ema_step(const cdet_param_slot* slots_dev, int32_t n_slots, const float* sqnorm, float max_norm,
-                      const float* lrs, int32_t n_groups, float momentum, float ema_decay, const float* scaler, void* stream);
+                      const float* lrs, int32_t n_groups, float momentum, float ema_decay, const float* scaler, float* skip_count, void* stream);
+/* skip_count (may be NULL): DEVICE float[2] = {skipped steps so far, found_inf of this step}, written by this launch -- the bookkeeping of plans
+ * WITHOUT loss scaling (bf16: scale fixed at 1), which then need no cdet_scaler_update launch; pass elements 2..3 of the scaler state. */
 /* scaler.update() (averaging.py:220): found_inf (*sqnorm not finite) -> scale *= backoff_factor, tracker = 0, skipped += 1; otherwise tracker += 1
  * and scale *= growth_factor every growth_interval good steps (GradScaler defaults 2.0 / 0.5 / 2000, init scale 65536). growth_interval <= 0: the
  * scale stays fixed and only the skip counter / found_inf flag are kept (bf16 plans). Enqueue BEHIND the update launches of the step. */

@@ -628,7 +628,7 @@ def test_sgd_ema_step_matches_oracle():
         out = torch.zeros(1 + 32 * len(keys), device=DEV)
         L.check(lib.cdet_grad_sqnorm(sdev.data_ptr(), len(keys), out.data_ptr(), None, torch.cuda.current_stream().cuda_stream))
         d = oo.ema_decay(upd + 1)
-        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d, None,
+        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d, None, None,
                                       torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         total = oo.optimizer_step(wref, {k: v.clone() for k, v in gr.items()}, mom_ref, serving, lr=lrs, momentum=0.952, weight_decay=0.00037)
@@ -693,8 +693,11 @@ def test_sgd_ema_step_skips_on_a_non_finite_gradient_like_gradscaler(scaled):
         scp = sc_dev.data_ptr() if scaled else None
         L.check(lib.cdet_grad_sqnorm(sdev.data_ptr(), len(keys), out.data_ptr(), scp, st))
         d = oo.ema_decay(upd + 1)
-        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d, scp, st))
-        L.check(lib.cdet_scaler_update(sc_dev.data_ptr(), out.data_ptr(), 2.0, 0.5, interval, st))
+        # (scaled: scaler.update() is a launch of its own behind the update; unscaled: the skip counter / found_inf words ride on the update launch)
+        L.check(lib.cdet_sgd_ema_step(sdev.data_ptr(), len(keys), out.data_ptr(), 10.0, (C.c_float * 3)(*lrs), 3, 0.952, d, scp,
+                                      None if scaled else sc_dev.data_ptr() + 8, st))
+        if scaled:
+            L.check(lib.cdet_scaler_update(sc_dev.data_ptr(), out.data_ptr(), 2.0, 0.5, interval, st))
         torch.cuda.synchronize()
         total = oo.optimizer_step(wref, {k: v.clone() for k, v in gr.items()}, mom_ref, serving, lr=lrs, momentum=0.952, weight_decay=0.00037,
                                   scaler=ref_sc)
