@@ -278,6 +278,23 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((P
         }
     };
 
+    // ---- prologue DMA: chunk 0 of X (1x1: chunks 0 and 1), weight tiles of steps 0 .. NSW-1. Issued HERE (round 6), in front of the tap-mask
+    //      divisions and the accumulator initialisation below: that arithmetic (~700 VALU cycles) now runs under the fetch latency
+#pragma unroll
+    for (int i = 0; i < MAXXPK; ++i)
+        if (i < nxpw) dma_x(i, cbeg, cbeg & 1);
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) dma_w1(cbeg * NT, 0, j);
+    if (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < NXP1; ++i) dma_x(i, 1, 1);
+    }
+#pragma unroll
+    for (int sg = 1; sg < NSW; ++sg) {
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) dma_w1(cbeg * NT + sg, sg, j);
+    }
+
     // ---- fragment read offsets -------------------------------------------------------------------------------------------------
     // A (weights): row f*32 + l31 of the stage, k-slot 2*s + h
     const int aoff0 = l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
@@ -333,21 +350,7 @@ __global__ __launch_bounds__(KS == 2 ? 512 : 256, (NG == 4 || KS == 2) ? 1 : ((P
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
 
-    // ---- prologue: chunk 0 of X (1x1: chunks 0 and 1), weight tiles of steps 0 .. NSW-1 -------------------------------------------
-#pragma unroll
-    for (int i = 0; i < MAXXPK; ++i)
-        if (i < nxpw) dma_x(i, cbeg, cbeg & 1);
-#pragma unroll
-    for (int j = 0; j < NWP; ++j) dma_w1(cbeg * NT, 0, j);
-    if (NT == 1) {
-#pragma unroll
-        for (int i = 0; i < NXP1; ++i) dma_x(i, 1, 1);
-    }
-#pragma unroll
-    for (int sg = 1; sg < NSW; ++sg) {
-#pragma unroll
-        for (int j = 0; j < NWP; ++j) dma_w1(cbeg * NT + sg, sg, j);
-    }
+    // (the prologue's DMA was issued above, in front of the index arithmetic)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NT == 1 ? NXP1 : 0) + (NSW - 1) * NWP) : "memory");  // tile 0 and chunk 0 have landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
