@@ -146,6 +146,19 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
         dma16(rs, (unsigned)((real ? pid : 0) * 1024 + lane * 16), soff, dst);
     };
 
+    // ---- prologue DMA: pixel chunks 0 and 1, weight tiles of steps 0 .. 2 -- issued in front of the fragment offsets and the accumulator
+    //      initialisation (round 6: ~400 VALU cycles under the fetch latency); waited for right before the first barrier
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) dma_x(i, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) dma_w(0, 0, j);
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) dma_x(i, 1, 1);
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) dma_w(1, 1, j);
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) dma_w(2, 2, j);
+
     const int aoff0 = cb * WTILE + l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
     int bo0[NG];  // byte offset of the lane's pixel rows inside a pixel buffer (0: the zero row)
 #pragma unroll
@@ -162,18 +175,7 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
 
-    // ---- prologue: pixel chunks 0 and 1, weight tiles of steps 0 .. 2 ---------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < NXP; ++i) dma_x(i, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NWP; ++j) dma_w(0, 0, j);
-#pragma unroll
-    for (int i = 0; i < NXP; ++i) dma_x(i, 1, 1);
-#pragma unroll
-    for (int j = 0; j < NWP; ++j) dma_w(1, 1, j);
-#pragma unroll
-    for (int j = 0; j < NWP; ++j) dma_w(2, 2, j);
-    wait_vm(NXP + 2 * NWP);  // chunk 0 and tile 0 have landed
+    wait_vm(NXP + 2 * NWP);  // chunk 0 and tile 0 have landed (the prologue's DMA was issued above, in front of the accumulator initialisation)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 

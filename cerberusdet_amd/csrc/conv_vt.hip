@@ -173,6 +173,21 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
     const unsigned prow = (unsigned)a.Ws * (unsigned)a.src_ld * 2u, pcol = (unsigned)a.src_ld * 2u;
     auto plane_off = [&](int pl) -> unsigned { return FWD ? (pl == 0 ? prow + pcol : (pl == 1 ? prow : (pl == 2 ? pcol : 0u))) : 0u; };
 
+    // ---- prologue DMA: the first virtual chunk's pixels, weight tiles of steps 0 .. 2 -- issued in front of the index divisions and the
+    //      accumulator initialisation below (round 6: that arithmetic runs under the fetch latency); waited for right before the first barrier
+#pragma unroll
+    for (int i = 0; i < VT_NXP; ++i) dma_x(i, 0, plane_off(0), 0);
+    if (NT == 1) {
+#pragma unroll
+        for (int i = 0; i < VT_NXP; ++i) dma_x(i, 1, 0u, 1);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < NSW; ++s_) {
+        const int wt = FWD ? vt_ky<MODE>(s_ % NT) * 3 + vt_kx<MODE>(s_ % NT) : 8 - (vt_ky<MODE>(s_ % NT) * 3 + vt_kx<MODE>(s_ % NT));
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) dma_w1(s_ / NT, wt, s_, j);
+    }
+
     // ---- fragment offsets ------------------------------------------------------------------------------------------------------------
     const int aoff0 = l31 * HROW + ((h ^ ((l31 >> 2) & 3)) << 4);
     int pixh[NG];
@@ -217,20 +232,7 @@ __device__ __forceinline__ void vt_body(const VtArgs& a, const int pblk, const i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][g][r] = 0.f;
 
-    // ---- prologue: the first virtual chunk's pixels, weight tiles of steps 0 .. 2 ---------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < VT_NXP; ++i) dma_x(i, 0, plane_off(0), 0);
-    if (NT == 1) {
-#pragma unroll
-        for (int i = 0; i < VT_NXP; ++i) dma_x(i, 1, 0u, 1);
-    }
-#pragma unroll
-    for (int s_ = 0; s_ < NSW; ++s_) {
-        const int wt = FWD ? vt_ky<MODE>(s_ % NT) * 3 + vt_kx<MODE>(s_ % NT) : 8 - (vt_ky<MODE>(s_ % NT) * 3 + vt_kx<MODE>(s_ % NT));
-#pragma unroll
-        for (int j = 0; j < NWP; ++j) dma_w1(s_ / NT, wt, s_, j);
-    }
-    wait_vm((NSW - 1) * NWP);
+    wait_vm((NSW - 1) * NWP);  // (the prologue's DMA was issued above, in front of the fragment offsets and the accumulator initialisation)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
