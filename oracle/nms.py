@@ -25,8 +25,8 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-MAX_WH = 7680.0  # general.py:413
-MAX_NMS = 30000  # general.py:414
+MAX_WH = 7680.0  # general.py:415
+MAX_NMS = 30000  # general.py:416
 
 
 def greedy_nms(boxes: np.ndarray, scores: np.ndarray, iou_thres: float) -> np.ndarray:
