@@ -785,6 +785,8 @@ def main():
             from cerberusdet_amd import _lib as _L
 
             out["switches"] = _L.active_switches()  # every library switch off its default + the build flavour ("" = the product configuration)
+            # ... and every CDET_* variable of the process environment: the host side reads its own (plan forms, schedules) when a plan is compiled
+            out["switches_env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("CDET_")}
             st = trainer.scaler_state()
             out["grad_scaler"] = {"scale": st["scale"], "skipped_steps": st["skipped_steps"]}
         except Exception as e:  # noqa: BLE001
