@@ -686,6 +686,12 @@ def main():
         # tests/test_distributed_cpu.py: the launcher path without a GPU -- the ranks rendezvous over gloo and run the SAME timing protocol
         # (warm-up, barrier, K steps, barrier, MAX over ranks, rank 0 prints the one JSON line) around a stand-in step. Not a measurement.
         return stub_ranks(args, rank, world, emit)
+    # CDET_BENCH_ONE_GPU=1 (tests only: tests/test_gpu_distributed.py): every rank on cuda:0 and the process group on gloo -- RCCL refuses two ranks on
+    # one device -- so that the WHOLE N > 1 path of this file (rendezvous, weight broadcast, sharded batches, reducer, comm timer, MAX over ranks,
+    # rank-0 line) runs on a one-GPU box. Not a measurement.
+    one_gpu = os.environ.get("CDET_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("CDET_REDUCE_ALWAYS") == "1"
@@ -694,7 +700,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from cerberusdet_amd.trainers import Averaging
 

@@ -455,3 +455,35 @@ def test_dry_comm_every_virtual_rank_enqueues_the_same_collective_sequence():
     assert two[1]["collectives"] < two[0]["collectives"] and two[1]["collectives"] >= per_pass
     assert two[0]["collectives"] == two[2]["collectives"] and two[0]["bytes"] == two[2]["bytes"]
     assert out["plans"]["v8x_3task.yaml"]["steps"][0]["collectives"] > two[0]["collectives"]
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_bench_n2_path_end_to_end_two_ranks_on_one_gpu(sync_bn):
+    """`bench.py --gpus 2` end to end -- launcher, rendezvous, rank-0 weight broadcast, per-rank synthetic shards, the gradient reducer under the
+    backward, SyncBatchNorm's statistics collectives, the comm timer, the barrier / MAX-over-ranks timing protocol, rank 0's ONE JSON line -- with both
+    ranks on this box's one GPU and the process group on gloo (CDET_BENCH_ONE_GPU=1: RCCL refuses two ranks on one device). What the driver runs on
+    2 / 4 / 8 GPUs at round end had never executed as a whole anywhere; this is everything of it that one GPU can run. Not a measurement."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, CDET_BENCH_ONE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--imgsz", "256", "--no-breakdown"]
+    if sync_bn:
+        cmd.append("--sync-bn")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["steps"] == 2 and o["scaling"] == "weak" and o["loss_finite"] is True
+    assert o["config"]["global_batch"] == 4 * 2 * 2 and o["config"]["parallelism"] == "dp2"
+    assert abs(o["value"] - 16 / (o["ms_per_step"] / 1e3)) < 0.01 * o["value"]
+    ce = o["comm_exposed_ms"]
+    assert ce["total"] >= 0 and "grad_wait" in ce and ce["spans_per_step"] >= 1
+    if sync_bn:
+        assert ce["spans_per_step"] > 100 and ce.get("syncbn", 0) > 0   # every statistics collective is timed
