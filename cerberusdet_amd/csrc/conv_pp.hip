@@ -61,7 +61,8 @@ constexpr int PP_STAGE_OFF = 6912;    // (= HEPI_STAGE_OFF)
 __device__ unsigned long long* g_pp_dbg = nullptr;
 #endif
 
-// ABL (timing experiments, -DCDET_PROFILING builds only): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 32 = per-phase s_memtime stamps
+// ABL (timing experiments, -DCDET_PROFILING builds only): 1 = no DMA in the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no s_setprio around the compute phase
+// (results stay correct), 32 = per-phase s_memtime stamps
 // (tools/pp_timeline.py; the stamps themselves stretch every phase -- read them as proportions)
 template <int DT, int EPI, bool PATCH, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
         }
 #endif
         // ---- compute phase ----
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
         if (!(ABL & 4)) {
 #pragma unroll
             for (int i = 0; i < NM; ++i) mfma32<DT>(a0[i / NG], b0[i % NG], acc[i / NG][i % NG]);
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(const PpArgs a) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(b0[i]), "v"(b1[i]));
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (!last) {
             __builtin_amdgcn_s_barrier();
@@ -523,7 +524,7 @@ static void launch_pp(const PpArgs& a, size_t lds, int nblocks, hipStream_t s) {
         hipLaunchKernelGGL((conv_pp_kernel<DT, EPI, PATCH, N>), dim3(nblocks), dim3(512), lds, s, a);                                        \
         return;
         switch (abl) {
-            CDET_PPABL(1) CDET_PPABL(2) CDET_PPABL(3) CDET_PPABL(4) CDET_PPABL(5) CDET_PPABL(6) CDET_PPABL(7) CDET_PPABL(32) CDET_PPABL(64)
+            CDET_PPABL(1) CDET_PPABL(2) CDET_PPABL(3) CDET_PPABL(4) CDET_PPABL(5) CDET_PPABL(6) CDET_PPABL(7) CDET_PPABL(8) CDET_PPABL(32) CDET_PPABL(64)
             default: break;
         }
 #undef CDET_PPABL
