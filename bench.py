@@ -280,7 +280,8 @@ def north_star_forward(model, device, bs=32, imgsz=640, reps=40, dtype=torch.bfl
         # right after a training loop (tools/debug/ns_probe.py); warm up for >= 1 s like the training measurement does with its steps
         t_w = time.perf_counter()
         n_w = 0
-        while n_w < 5 or time.perf_counter() - t_w < 1.0:
+        warm_s = float(os.environ.get("CDET_NS_WARM_S", "1.0"))
+        while n_w < 5 or time.perf_counter() - t_w < warm_s:
             model(x)
             n_w += 1
             if n_w % 10 == 0:
